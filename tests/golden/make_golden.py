@@ -1,0 +1,135 @@
+"""Generate the committed golden fixtures by EXECUTING THE REFERENCE's own python.
+
+Run in the authoring container only (needs /root/reference):
+    python tests/golden/make_golden.py
+Writes tests/golden/*.npz.  The GPU box never runs this (no /root/reference there); it only
+reads the committed .npz files.
+
+What is pinned here (reference code executed, CPU, float32):
+  k0_mesh.npz        GaussianMeshModel.update_alpha + prepare_scaling_rot forward and autograd
+                     backward (games/mesh_splatting/scene/gaussian_mesh_model.py:86-169),
+                     incl. degenerate faces, negative _alpha / _scale entries
+  k0_multi_mesh.npz  GaussianMultiMeshModel (games/multi_mesh_splatting/.../gaussian_multi_mesh_model.py:99-199)
+  stages.npz         eval_sh (utils/sh_utils.py:57), geom_transform_points (utils/graphics_utils.py:22),
+                     build_covariance_from_scaling_rotation (scene/gaussian_model.py:27-31),
+                     rot_to_quat_batch (utils/general_utils.py:43), getProjectionMatrix/getWorld2View2
+The rasterizer itself cannot be pinned this way (source absent from the reference tree).
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gaussian-mesh-splatting_amd"))
+
+from oracle import ref_import  # noqa: E402
+from games_hip import synthetic as syn  # noqa: E402
+
+
+def k0_inputs(seed, n_lat, n_lon, S, degenerate=True):
+    g = torch.Generator().manual_seed(seed)
+    vertices, faces = syn.uv_sphere(n_lat, n_lon)
+    vertices = vertices + 0.01 * torch.randn(vertices.shape, generator=g)
+    if degenerate:
+        faces = faces.clone()
+        faces[3] = torch.tensor([faces[3, 0], faces[3, 0], faces[3, 2]])   # repeated vertex
+        faces[7] = torch.tensor([faces[7, 1], faces[7, 1], faces[7, 1]])   # point face
+    F = faces.shape[0]
+    _alpha = torch.rand(F, S, 3, generator=g)
+    _alpha[1, 0] = torch.tensor([-0.3, 0.2, 0.5])      # relu-clipped entry
+    _alpha[2, 0] = torch.tensor([-1.0, -2.0, -0.1])    # all clipped -> uniform 1e-8
+    _scale = torch.exp(0.3 * torch.randn(F * S, 1, generator=g))
+    _scale[5] = -0.7                                    # negative -> all three scales collapse to eps
+    return vertices, faces, _alpha, _scale
+
+
+def run_mesh_model(ref, vertices, faces, _alpha, _scale, seed):
+    m = ref.mesh_model.GaussianMeshModel(3)
+    m.vertices = torch.nn.Parameter(vertices.clone())
+    m.faces = faces
+    m._alpha = torch.nn.Parameter(_alpha.clone())
+    m._scale = torch.nn.Parameter(_scale.clone())
+    m.update_alpha()
+    m.prepare_scaling_rot()
+    g = torch.Generator().manual_seed(seed + 100)
+    P = m._xyz.shape[0]
+    gx, gs, gr = (torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g))
+    # the rasterizer consumes exp(_scaling) and normalize(_rotation) (scene/gaussian_model.py:95-101)
+    loss = (m.get_xyz * gx).sum() + (m.get_scaling * gs).sum() + (m.get_rotation * gr).sum()
+    loss.backward()
+    return dict(
+        vertices=vertices, faces=faces, _alpha=_alpha, _scale=_scale,
+        alpha=m.alpha.detach(), triangles=m.triangles.detach(), xyz=m._xyz.detach(),
+        scaling=m._scaling.detach(), rotation=m._rotation.detach(),
+        g_xyz=gx, g_scaling_act=gs, g_rotation_act=gr,
+        d_vertices=m.vertices.grad, d_alpha=m._alpha.grad, d_scale=m._scale.grad)
+
+
+def main():
+    ref = ref_import.import_reference()
+    torch.manual_seed(0)
+    tonp = lambda d: {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+    # ---- K0 single mesh
+    v, f, a, s = k0_inputs(0, 8, 10, 2)
+    np.savez_compressed(os.path.join(HERE, "k0_mesh.npz"), **tonp(run_mesh_model(ref, v, f, a, s, 0)))
+    v, f, a, s = k0_inputs(1, 6, 7, 5, degenerate=False)
+    np.savez_compressed(os.path.join(HERE, "k0_mesh_s5.npz"), **tonp(run_mesh_model(ref, v, f, a, s, 1)))
+
+    # ---- K0 multi mesh (two meshes, different splat counts)
+    mm = ref.multi_mesh_model.GaussianMultiMeshModel(3)
+    parts = [k0_inputs(2, 6, 8, 2, degenerate=False), k0_inputs(3, 5, 6, 3, degenerate=False)]
+    mm.vertices = [torch.nn.Parameter(p[0].clone()) for p in parts]
+    mm.faces = [p[1] for p in parts]
+    mm._alpha = [torch.nn.Parameter(p[2].clone()) for p in parts]
+    mm._scale = [torch.nn.Parameter(p[3].clone()) for p in parts]
+    mm.update_alpha()
+    mm.prepare_scaling_rot()
+    g = torch.Generator().manual_seed(7)
+    P = mm._xyz.shape[0]
+    gx, gs, gr = torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g)
+    ((mm.get_xyz * gx).sum() + (mm.get_scaling * gs).sum() + (mm.get_rotation * gr).sum()).backward()
+    d = dict(xyz=mm._xyz.detach(), scaling=mm._scaling.detach(), rotation=mm._rotation.detach(),
+             g_xyz=gx, g_scaling_act=gs, g_rotation_act=gr)
+    for i, p in enumerate(parts):
+        d[f"vertices{i}"], d[f"faces{i}"], d[f"_alpha{i}"], d[f"_scale{i}"] = p
+        d[f"d_vertices{i}"] = mm.vertices[i].grad
+        d[f"d_alpha{i}"] = mm._alpha[i].grad
+        d[f"d_scale{i}"] = mm._scale[i].grad
+    np.savez_compressed(os.path.join(HERE, "k0_multi_mesh.npz"), **tonp(d))
+
+    # ---- in-tree python stages of the rasterizer path
+    g = torch.Generator().manual_seed(11)
+    P = 64
+    xyz = torch.randn(P, 3, generator=g)
+    shs = torch.randn(P, 16, 3, generator=g) * 0.4
+    campos = torch.tensor([0.3, -2.0, 1.1])
+    dirs = xyz - campos
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    sh_rgb = {f"sh_rgb_deg{deg}": ref.sh_utils.eval_sh(deg, shs.transpose(1, 2), dirs) for deg in range(4)}
+    scales = torch.rand(P, 3, generator=g) * 0.3 + 0.01
+    rots = torch.randn(P, 4, generator=g)           # un-normalised on purpose: build_rotation normalises
+    gm = ref.gaussian_model.GaussianModel(3)
+    with ref_import.cuda_literals_on_cpu():
+        cov6 = gm.covariance_activation(scales, 1.7, rots)
+        R = ref.general_utils.build_rotation(rots)
+    quat = ref.general_utils.rot_to_quat_batch(R)
+    cam = syn.orbit_camera(1, width=200, height=160)
+    proj = ref.graphics_utils.getProjectionMatrix(0.01, 100.0, cam.FoVx, cam.FoVy)
+    ndc = ref.graphics_utils.geom_transform_points(xyz, cam.full_proj_transform)
+    Rw = np.array([[0.36, 0.48, -0.8], [-0.8, 0.6, 0.0], [0.48, 0.64, 0.6]])
+    w2v = ref.graphics_utils.getWorld2View2(Rw, np.array([0.1, -0.2, 3.0]))
+    d = dict(xyz=xyz, shs=shs, campos=campos, dirs=dirs, scales=scales, rots=rots, cov6_mod1p7=cov6, R=R,
+             quat_of_R=quat, proj_fovx=np.float64(cam.FoVx), proj_fovy=np.float64(cam.FoVy), proj=proj,
+             full_proj=cam.full_proj_transform, ndc=ndc, w2v_R=Rw, w2v_t=np.array([0.1, -0.2, 3.0]), w2v=w2v,
+             **sh_rgb)
+    np.savez_compressed(os.path.join(HERE, "stages.npz"), **tonp(d))
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
