@@ -1,0 +1,163 @@
+// gms_common.h -- shared device/host helpers for the gfx950 rasterizer kernels.
+// Written for CDNA4 only: wave = 64 lanes, 4 waves per 16x16 pixel tile.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gmsplat.h"
+
+namespace gms {
+
+constexpr int TILE = 16;            // pixel tile edge (binning granularity)
+constexpr int TILE_PIX = TILE * TILE;
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;          // threads per block everywhere: 4 waves
+constexpr float NEAR_Z = 0.2f;
+constexpr float DILATE = 0.3f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float T_MIN = 0.0001f;
+
+// SH constants (utils/sh_utils.py:26-43 of the reference)
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+// Per-Gaussian splat record consumed by the blend kernels: 48 bytes, gathered by id.
+//   q0 = (pix.x, pix.y, conic.A, conic.B)
+//   q1 = (conic.C, opacity', r, g)
+//   q2 = (b, 1/depth, ext.x, ext.y)   ext = half extent of the alpha >= 1/255 ellipse's bounding box
+struct __attribute__((aligned(16))) SplatRec {
+    float4 q0, q1, q2;
+};
+
+// ---- scratch buffer layouts (carved from the caller's three buffers, 256-B aligned chunks)
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GeomState {
+    SplatRec *rec;      // [P]
+    float *depth;       // [P]
+    uint8_t *clamped;   // [P] bit c set => colour channel c was clamped at 0
+    static __host__ __device__ size_t bytes(size_t P)
+    {
+        return align_up(P * sizeof(SplatRec), 256) + align_up(P * 4, 256) + align_up(P, 256);
+    }
+    static __host__ __device__ GeomState carve(void *base, size_t P)
+    {
+        GeomState g;
+        char *p = (char *)base;
+        g.rec = (SplatRec *)p; p += align_up(P * sizeof(SplatRec), 256);
+        g.depth = (float *)p;  p += align_up(P * 4, 256);
+        g.clamped = (uint8_t *)p;
+        return g;
+    }
+};
+
+struct ImageState {
+    float *final_T;         // [H*W]
+    uint32_t *n_contrib;    // [H*W]
+    uint32_t *tile_count;   // [T]     instances per tile (atomically counted in preprocess)
+    uint32_t *tile_cursor;  // [T]     emit cursors
+    uint32_t *tile_offset;  // [T+1]   exclusive scan of tile_count; tile_offset[T] = N
+    static __host__ __device__ size_t bytes(size_t W, size_t H)
+    {
+        size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + align_up((T + 1) * 4, 256);
+    }
+    static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
+    {
+        size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+        ImageState s;
+        char *p = (char *)base;
+        s.final_T = (float *)p;        p += align_up(W * H * 4, 256);
+        s.n_contrib = (uint32_t *)p;   p += align_up(W * H * 4, 256);
+        s.tile_count = (uint32_t *)p;  p += align_up(T * 4, 256);
+        s.tile_cursor = (uint32_t *)p; p += align_up(T * 4, 256);
+        s.tile_offset = (uint32_t *)p;
+        return s;
+    }
+};
+
+struct BinningState {
+    uint64_t *keys;   // [N]  (depth_bits << 32) | gaussian id ; sorted in place per tile segment
+    static __host__ __device__ size_t bytes(size_t N) { return align_up((N > 0 ? N : 1) * 8, 256); }
+    static __host__ __device__ BinningState carve(void *base, size_t)
+    {
+        BinningState b;
+        b.keys = (uint64_t *)base;
+        return b;
+    }
+};
+
+// ---- wave64 reductions with DPP (row ops + row broadcasts; result valid in lane 63)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return v + __builtin_bit_cast(float, moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_lane63(float v)
+{
+    v = dpp_add<0xB1>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);       // row_half_mirror
+    v = dpp_add<0x140>(v);       // row_mirror      -> every lane of a 16-row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast31 into rows 2,3 -> lane 63 (row 3) holds the wave sum
+    return v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Tile rectangle of a splat: identical code in preprocess (count) and emit, so both agree.
+__device__ __forceinline__ void tile_rect(float px, float py, float radius, int gx, int gy, int &minx, int &miny,
+                                          int &maxx, int &maxy)
+{
+    const float big = 1048576.0f;
+    float q0 = (px - radius) / TILE, q1 = (py - radius) / TILE;
+    float q2 = (px + radius + (TILE - 1)) / TILE, q3 = (py + radius + (TILE - 1)) / TILE;
+    minx = (int)fminf(big, fmaxf(-big, q0));
+    miny = (int)fminf(big, fmaxf(-big, q1));
+    maxx = (int)fminf(big, fmaxf(-big, q2));
+    maxy = (int)fminf(big, fmaxf(-big, q3));
+    minx = min(gx, max(0, minx)); maxx = min(gx, max(0, maxx));
+    miny = min(gy, max(0, miny)); maxy = min(gy, max(0, maxy));
+}
+
+// a*b + c*d + e*f + g in the documented order ((a*b (+) c*d) (+) e*f) + g, each (+) fused.
+__device__ __forceinline__ float dot3p(float a, float b, float c, float d, float e, float f, float g)
+{
+    float t = a * b;
+    t = __fmaf_rn(c, d, t);
+    t = __fmaf_rn(e, f, t);
+    return t + g;
+}
+
+// thread-local error text for gms_last_error()
+void set_error(const char *fmt, ...);
+
+}  // namespace gms
+
+#define GMS_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            gms::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return GMS_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define GMS_KERNEL_CHECK(dbg, stream, name)                                                    \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e == hipSuccess && (dbg)) _e = hipStreamSynchronize(stream);                      \
+        if (_e != hipSuccess) {                                                                \
+            gms::set_error("kernel %s failed: %s", name, hipGetErrorString(_e));               \
+            return GMS_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)

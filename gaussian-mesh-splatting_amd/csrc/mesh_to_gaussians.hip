@@ -1,0 +1,394 @@
+// mesh_to_gaussians.hip -- fused mesh-face -> Gaussian parameterization (K0) for gfx950.
+//
+// Replaces the ~40 elementwise/gather PyTorch kernels (and 2-3 host syncs from boolean-mask
+// indexing) of GaussianMeshModel.update_alpha + _calc_xyz + prepare_scaling_rot
+// (games/mesh_splatting/scene/gaussian_mesh_model.py:86-169) and rot_to_quat_batch
+// (utils/general_utils.py:43-96) with one forward kernel and two backward kernels:
+//   mesh_fwd        1 thread / splat: barycentric centre, face frame (recomputed per splat -- the
+//                   three vertices are L1/L2 hits for the face's other splats), log-scales,
+//                   rotation-matrix -> quaternion.  HBM-bound: reads 16 B, writes 52 B per splat.
+//   mesh_bwd_splat  1 thread / splat: d_alpha (through relu+L1-normalise or softmax), d_scale.
+//   mesh_bwd_face   per face (1 thread, or 1 wave when the face carries >= 16 splats): sums the
+//                   splats' quaternion / scale / centre gradients, differentiates quaternion
+//                   selection, Gram-Schmidt frame, norms and the cross product once per face and
+//                   scatters into vertices.grad with 9 float atomics per face.
+// Operation order follows the reference line by line; contraction is off so the discrete
+// argmax in the quaternion conversion sees the same values as a float32 CPU evaluation.
+#include "gms_common.h"
+
+namespace gms {
+
+constexpr float EPS = 1e-8f;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b)
+{
+#pragma clang fp contract(off)
+    return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+#pragma clang fp contract(off)
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 ldv(const float *p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
+
+struct Frame {
+    V3 t0, t1, t2;
+    V3 N;  float nN;          // cross product and its norm
+    V3 v0, v1, v2;
+    V3 u1; float n1, v1n;     // t1 - mean, |u1|, |u1| + eps
+    V3 v2i, w; float nw;      // t2 - mean, Gram-Schmidt residual and its norm
+    float s1, s2;
+};
+
+__device__ __forceinline__ void face_frame(V3 t0, V3 t1, V3 t2, Frame &f)
+{
+#pragma clang fp contract(off)
+    f.t0 = t0; f.t1 = t1; f.t2 = t2;
+    f.N = cross(t1 - t0, t2 - t0);
+    f.nN = norm(f.N);
+    f.v0 = {f.N.x / (f.nN + EPS), f.N.y / (f.nN + EPS), f.N.z / (f.nN + EPS)};
+    V3 sum = (t0 + t1) + t2;
+    V3 mean = {sum.x / 3.f, sum.y / 3.f, sum.z / 3.f};
+    f.u1 = t1 - mean;
+    f.n1 = norm(f.u1);
+    f.v1n = f.n1 + EPS;
+    f.v1 = {f.u1.x / f.v1n, f.u1.y / f.v1n, f.u1.z / f.v1n};
+    f.v2i = t2 - mean;
+    float c0 = dot(f.v2i, f.v0), c1 = dot(f.v2i, f.v1);
+    f.w = (f.v2i - c0 * f.v0) - c1 * f.v1;
+    f.nw = norm(f.w);
+    f.v2 = {f.w.x / (f.nw + EPS), f.w.y / (f.nw + EPS), f.w.z / (f.nw + EPS)};
+    f.s1 = f.v1n / 2.f;
+    f.s2 = dot(f.v2i, f.v2) / 2.f;
+}
+
+// rotation matrix with columns (v0,v1,v2) -> quaternion; also reports the selected candidate
+struct QuatSel { int sel; float a; float sign; float cand[4]; float x[4]; };
+
+__device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel *qs)
+{
+#pragma clang fp contract(off)
+    const float m00 = f.v0.x, m01 = f.v1.x, m02 = f.v2.x;
+    const float m10 = f.v0.y, m11 = f.v1.y, m12 = f.v2.y;
+    const float m20 = f.v0.z, m21 = f.v1.z, m22 = f.v2.z;
+    float x[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
+    float qa[4];
+    int sel = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) qa[k] = x[k] > 0.f ? sqrtf(x[k]) : 0.f;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (qa[k] > qa[sel]) sel = k;          // first maximum wins, as torch.argmax
+    const float a = qa[sel];
+    float c[4];
+    const float a2 = a * a;
+    if (sel == 0) { c[0] = a2; c[1] = m21 - m12; c[2] = m02 - m20; c[3] = m10 - m01; }
+    else if (sel == 1) { c[0] = m21 - m12; c[1] = a2; c[2] = m10 + m01; c[3] = m02 + m20; }
+    else if (sel == 2) { c[0] = m02 - m20; c[1] = m10 + m01; c[2] = a2; c[3] = m12 + m21; }
+    else { c[0] = m10 - m01; c[1] = m20 + m02; c[2] = m21 + m12; c[3] = a2; }
+    const float den = 2.0f * fmaxf(a, 0.1f);
+    float o[4] = {c[0] / den, c[1] / den, c[2] / den, c[3] / den};
+    const float sign = o[0] < 0.f ? -1.f : 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = o[0] < 0.f ? -o[k] : o[k];
+    if (qs) {
+        qs->sel = sel; qs->a = a; qs->sign = sign;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { qs->cand[k] = c[k]; qs->x[k] = x[k]; }
+    }
+}
+
+__device__ __forceinline__ int splat_to_face(const GmsMeshArgs &a, int64_t p)
+{
+    return a.splats_per_face > 0 ? (int)(p / a.splats_per_face) : a.splat_face[p];
+}
+
+__device__ __forceinline__ void load_face(const GmsMeshArgs &a, int f, V3 &t0, V3 &t1, V3 &t2)
+{
+    const int64_t i0 = a.faces[3 * (size_t)f], i1 = a.faces[3 * (size_t)f + 1], i2 = a.faces[3 * (size_t)f + 2];
+    t0 = ldv(a.vertices, (size_t)i0); t1 = ldv(a.vertices, (size_t)i1); t2 = ldv(a.vertices, (size_t)i2);
+}
+
+__device__ __forceinline__ void barycentric(int mode, const float *raw, float al[3], float &rsum)
+{
+#pragma clang fp contract(off)
+    if (mode == GMS_ALPHA_RELU) {
+        float r0 = fmaxf(raw[0], 0.f) + 1e-8f, r1 = fmaxf(raw[1], 0.f) + 1e-8f, r2 = fmaxf(raw[2], 0.f) + 1e-8f;
+        rsum = (r0 + r1) + r2;
+        al[0] = r0 / rsum; al[1] = r1 / rsum; al[2] = r2 / rsum;
+    } else {
+        float mx = fmaxf(raw[0], fmaxf(raw[1], raw[2]));
+        float e0 = expf(raw[0] - mx), e1 = expf(raw[1] - mx), e2 = expf(raw[2] - mx);
+        rsum = (e0 + e1) + e2;
+        al[0] = e0 / rsum; al[1] = e1 / rsum; al[2] = e2 / rsum;
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *alpha_out, float *xyz, float *scaling,
+                                                         float *rotation)
+{
+#pragma clang fp contract(off)
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= a.P) return;
+    const int f = splat_to_face(a, p);
+    V3 t0, t1, t2;
+    load_face(a, f, t0, t1, t2);
+    const float raw[3] = {a._alpha[3 * p], a._alpha[3 * p + 1], a._alpha[3 * p + 2]};
+    float al[3], rsum;
+    barycentric(a.alpha_mode, raw, al, rsum);
+    if (alpha_out) { alpha_out[3 * p] = al[0]; alpha_out[3 * p + 1] = al[1]; alpha_out[3 * p + 2] = al[2]; }
+    xyz[3 * p] = al[0] * t0.x + al[1] * t1.x + al[2] * t2.x;
+    xyz[3 * p + 1] = al[0] * t0.y + al[1] * t1.y + al[2] * t2.y;
+    xyz[3 * p + 2] = al[0] * t0.z + al[1] * t1.z + al[2] * t2.z;
+    Frame fr;
+    face_frame(t0, t1, t2, fr);
+    const float sc = a._scale[p];
+    scaling[3 * p] = logf(fmaxf(sc * EPS, 0.f) + EPS);
+    scaling[3 * p + 1] = logf(fmaxf(sc * fr.s1, 0.f) + EPS);
+    scaling[3 * p + 2] = logf(fmaxf(sc * fr.s2, 0.f) + EPS);
+    float q[4];
+    rot_to_quat(fr, q, nullptr);
+    *reinterpret_cast<float4 *>(rotation + 4 * p) = make_float4(q[0], q[1], q[2], q[3]);
+}
+
+// ------------------------------------------------------------------ backward, per splat
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                               float *dL_dalpha, float *dL_dscale)
+{
+    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= a.P) return;
+    const int f = splat_to_face(a, p);
+    V3 t0, t1, t2;
+    load_face(a, f, t0, t1, t2);
+    const float raw[3] = {a._alpha[3 * p], a._alpha[3 * p + 1], a._alpha[3 * p + 2]};
+    float al[3], rsum;
+    barycentric(a.alpha_mode, raw, al, rsum);
+    const V3 g = ldv(dL_dxyz, (size_t)p);
+    const float da[3] = {dot(g, t0), dot(g, t1), dot(g, t2)};
+    const float s = da[0] * al[0] + da[1] * al[1] + da[2] * al[2];
+    if (a.alpha_mode == GMS_ALPHA_RELU) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dalpha[3 * p + k] = raw[k] > 0.f ? (da[k] - s) / rsum : 0.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dalpha[3 * p + k] = al[k] * (da[k] - s);
+    }
+    Frame fr;
+    face_frame(t0, t1, t2, fr);
+    const float sc = a._scale[p];
+    const float sj[3] = {EPS, fr.s1, fr.s2};
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float u = sc * sj[j];
+        if (u > 0.f) acc += dL_dscaling[3 * p + j] * sj[j] / (u + EPS);
+    }
+    dL_dscale[p] = acc;
+}
+
+// ------------------------------------------------------------------ backward, per face
+struct FaceGrad { float dq[4]; float ds1, ds2; V3 dt0, dt1, dt2; };
+
+__device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, const Frame &fr, const float *dL_dxyz,
+                                              const float *dL_dscaling, const float *dL_drot, FaceGrad &G)
+{
+    const float raw[3] = {a._alpha[3 * p], a._alpha[3 * p + 1], a._alpha[3 * p + 2]};
+    float al[3], rsum;
+    barycentric(a.alpha_mode, raw, al, rsum);
+    const V3 g = ldv(dL_dxyz, (size_t)p);
+    G.dt0 = G.dt0 + al[0] * g; G.dt1 = G.dt1 + al[1] * g; G.dt2 = G.dt2 + al[2] * g;
+    const float4 gq = *reinterpret_cast<const float4 *>(dL_drot + 4 * p);
+    G.dq[0] += gq.x; G.dq[1] += gq.y; G.dq[2] += gq.z; G.dq[3] += gq.w;
+    const float sc = a._scale[p];
+    const float u1 = sc * fr.s1, u2 = sc * fr.s2;
+    if (u1 > 0.f) G.ds1 += dL_dscaling[3 * p + 1] * sc / (u1 + EPS);
+    if (u2 > 0.f) G.ds2 += dL_dscaling[3 * p + 2] * sc / (u2 + EPS);
+}
+
+// differentiate quaternion + frame once per face and scatter into the three vertices
+__device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float *dL_dvertices)
+{
+    // ---- quaternion -> dL/dR (columns v0, v1, v2)
+    float q[4];
+    QuatSel qs;
+    rot_to_quat(fr, q, &qs);
+    const float den = 2.0f * fmaxf(qs.a, 0.1f);
+    float gc[4];
+    float dden = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float gk = qs.sign * G.dq[k];
+        gc[k] = gk / den;
+        dden -= gk * qs.cand[k] / (den * den);
+    }
+    // a enters through den (if a > 0.1) and through cand[sel] = a^2
+    float da = (qs.a > 0.1f ? 2.f * dden : 0.f) + 2.f * qs.a * gc[qs.sel];
+    const float dx = (qs.x[qs.sel] > 0.f) ? da / (2.f * qs.a) : 0.f;   // a = sqrt(x), zero subgradient at x <= 0
+    float d00 = 0, d01 = 0, d02 = 0, d10 = 0, d11 = 0, d12 = 0, d20 = 0, d21 = 0, d22 = 0;
+    switch (qs.sel) {
+    case 0:
+        d00 += dx; d11 += dx; d22 += dx;
+        d21 += gc[1]; d12 -= gc[1]; d02 += gc[2]; d20 -= gc[2]; d10 += gc[3]; d01 -= gc[3];
+        break;
+    case 1:
+        d00 += dx; d11 -= dx; d22 -= dx;
+        d21 += gc[0]; d12 -= gc[0]; d10 += gc[2]; d01 += gc[2]; d02 += gc[3]; d20 += gc[3];
+        break;
+    case 2:
+        d00 -= dx; d11 += dx; d22 -= dx;
+        d02 += gc[0]; d20 -= gc[0]; d10 += gc[1]; d01 += gc[1]; d12 += gc[3]; d21 += gc[3];
+        break;
+    default:
+        d00 -= dx; d11 -= dx; d22 += dx;
+        d10 += gc[0]; d01 -= gc[0]; d20 += gc[1]; d02 += gc[1]; d21 += gc[2]; d12 += gc[2];
+        break;
+    }
+    // m[i][j] = v_j[i]
+    V3 g0 = {d00, d10, d20}, g1 = {d01, d11, d21}, g2 = {d02, d12, d22};
+
+    // ---- scales
+    float g_v1n = G.ds1 * 0.5f;                       // s1 = v1n / 2
+    V3 g_v2i = (G.ds2 * 0.5f) * fr.v2;                // s2 = <v2i, v2> / 2
+    g2 = g2 + (G.ds2 * 0.5f) * fr.v2i;
+
+    // ---- v2 = w / (|w| + eps)
+    const float nwe = fr.nw + EPS;
+    V3 gw = (1.f / nwe) * g2;
+    if (fr.nw > 0.f) gw = gw - ((dot(g2, fr.w) / (nwe * nwe)) / fr.nw) * fr.w;
+    // w = v2i - <v2i,v0> v0 - <v2i,v1> v1
+    const float c0 = dot(fr.v2i, fr.v0), c1 = dot(fr.v2i, fr.v1);
+    const float gw0 = dot(gw, fr.v0), gw1 = dot(gw, fr.v1);
+    g_v2i = g_v2i + ((gw - gw0 * fr.v0) - gw1 * fr.v1);
+    g0 = g0 - (c0 * gw + gw0 * fr.v2i);
+    g1 = g1 - (c1 * gw + gw1 * fr.v2i);
+
+    // ---- v1 = u1 / v1n, v1n = |u1| + eps
+    V3 g_u1 = (1.f / fr.v1n) * g1;
+    if (fr.n1 > 0.f) g_u1 = g_u1 + ((g_v1n - dot(g1, fr.u1) / (fr.v1n * fr.v1n)) / fr.n1) * fr.u1;
+
+    // ---- v0 = N / (|N| + eps), N = (t1 - t0) x (t2 - t0)
+    const float nNe = fr.nN + EPS;
+    V3 gN = (1.f / nNe) * g0;
+    if (fr.nN > 0.f) gN = gN - ((dot(g0, fr.N) / (nNe * nNe)) / fr.nN) * fr.N;
+    const V3 e1 = fr.t1 - fr.t0, e2 = fr.t2 - fr.t0;
+    const V3 g_e1 = cross(e2, gN), g_e2 = cross(gN, e1);
+
+    // ---- back to the triangle
+    const V3 g_mean = (-1.f / 3.f) * (g_u1 + g_v2i);
+    V3 dt0 = G.dt0 + g_mean - (g_e1 + g_e2);
+    V3 dt1 = G.dt1 + g_mean + g_u1 + g_e1;
+    V3 dt2 = G.dt2 + g_mean + g_v2i + g_e2;
+    const int64_t i0 = a.faces[3 * (size_t)f], i1 = a.faces[3 * (size_t)f + 1], i2 = a.faces[3 * (size_t)f + 2];
+    unsafeAtomicAdd(dL_dvertices + 3 * i0, dt0.x); unsafeAtomicAdd(dL_dvertices + 3 * i0 + 1, dt0.y); unsafeAtomicAdd(dL_dvertices + 3 * i0 + 2, dt0.z);
+    unsafeAtomicAdd(dL_dvertices + 3 * i1, dt1.x); unsafeAtomicAdd(dL_dvertices + 3 * i1 + 1, dt1.y); unsafeAtomicAdd(dL_dvertices + 3 * i1 + 2, dt1.z);
+    unsafeAtomicAdd(dL_dvertices + 3 * i2, dt2.x); unsafeAtomicAdd(dL_dvertices + 3 * i2 + 1, dt2.y); unsafeAtomicAdd(dL_dvertices + 3 * i2 + 2, dt2.z);
+}
+
+__device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, int64_t &b, int64_t &e)
+{
+    if (a.splats_per_face > 0) { b = (int64_t)f * a.splats_per_face; e = b + a.splats_per_face; }
+    else { b = a.face_splat_offset[f]; e = a.face_splat_offset[f + 1]; }
+}
+
+// few splats per face: one thread per face
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                                     const float *dL_drot, float *dL_dvertices)
+{
+    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    if (f >= a.F) return;
+    V3 t0, t1, t2;
+    load_face(a, f, t0, t1, t2);
+    Frame fr;
+    face_frame(t0, t1, t2, fr);
+    FaceGrad G = {};
+    int64_t b, e;
+    face_splat_range(a, f, b, e);
+    for (int64_t p = b; p < e; p++) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
+    face_backward(a, f, fr, G, dL_dvertices);
+}
+
+// many splats per face (FLAME-like, 50-100): one wave per face, lanes stride over the splats
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_face_wave_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                                   const float *dL_drot, float *dL_dvertices)
+{
+    const int lane = threadIdx.x & 63;
+    const int f = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (f >= a.F) return;                         // wave-uniform
+    V3 t0, t1, t2;
+    load_face(a, f, t0, t1, t2);
+    Frame fr;
+    face_frame(t0, t1, t2, fr);
+    FaceGrad G = {};
+    int64_t b, e;
+    face_splat_range(a, f, b, e);
+    for (int64_t p = b + lane; p < e; p += WAVE) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
+    float *v = reinterpret_cast<float *>(&G);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(FaceGrad) / 4); k++) v[k] = wave_sum_to_lane63(v[k]);
+    if (lane == 63) face_backward(a, f, fr, G, dL_dvertices);
+}
+
+}  // namespace gms
+
+using namespace gms;
+
+static int32_t check_mesh_args(const GmsMeshArgs *A)
+{
+    if (!A || A->F < 0 || A->P < 0 || A->V < 0) { set_error("mesh args: negative size"); return GMS_ERR_INVALID_ARGUMENT; }
+    if (A->P == 0) return GMS_OK;
+    if (!A->vertices || !A->faces || !A->_alpha || !A->_scale) { set_error("mesh args: null input"); return GMS_ERR_INVALID_ARGUMENT; }
+    if (A->splats_per_face > 0) {
+        if ((int64_t)A->F * A->splats_per_face != A->P) { set_error("mesh args: P != F * splats_per_face"); return GMS_ERR_INVALID_ARGUMENT; }
+    } else if (!A->face_splat_offset || !A->splat_face) {
+        set_error("mesh args: non-uniform splat counts need face_splat_offset and splat_face");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    if (A->alpha_mode != GMS_ALPHA_RELU && A->alpha_mode != GMS_ALPHA_SOFTMAX) { set_error("mesh args: bad alpha_mode"); return GMS_ERR_INVALID_ARGUMENT; }
+    return GMS_OK;
+}
+
+extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *alpha, float *xyz, float *scaling,
+                                                 float *rotation, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    set_error("%s", "");
+    int32_t rc = check_mesh_args(A);
+    if (rc != GMS_OK) return rc;
+    if (A->P == 0) return GMS_OK;
+    if (!xyz || !scaling || !rotation) { set_error("mesh forward: null output"); return GMS_ERR_INVALID_ARGUMENT; }
+    mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation);
+    GMS_KERNEL_CHECK(0, stream, "mesh_fwd");
+    return GMS_OK;
+}
+
+extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const float *dL_dxyz, const float *dL_dscaling,
+                                                  const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
+                                                  float *dL_dscale, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    set_error("%s", "");
+    int32_t rc = check_mesh_args(A);
+    if (rc != GMS_OK) return rc;
+    if (A->P == 0) return GMS_OK;
+    if (!dL_dxyz || !dL_dscaling || !dL_drotation || !dL_dvertices || !dL_dalpha || !dL_dscale) {
+        set_error("mesh backward: null gradient pointer");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale);
+    GMS_KERNEL_CHECK(0, stream, "mesh_bwd_splat");
+    const double avg = (double)A->P / (double)(A->F > 0 ? A->F : 1);
+    if (avg >= 16.0) {
+        const int fpb = BLOCK / WAVE;
+        mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices);
+    } else {
+        mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices);
+    }
+    GMS_KERNEL_CHECK(0, stream, "mesh_bwd_face");
+    return GMS_OK;
+}

@@ -1,0 +1,460 @@
+// raster_backward.hip -- backward pass of the gfx950 Gaussian rasterizer.
+//
+//   K7  blend_bwd       one block (4 waves) per 16x16 tile, back-to-front over the tile's sorted
+//                       segment, same LDS splat queue + per-quadrant ballot cull as the forward.
+//                       Per (wave, splat) the ten partial gradients are summed over the 64 lanes
+//                       with DPP row operations (6 v_add_f32_dpp each) and leave the wave as ONE
+//                       hardware float atomic per value instead of 64 -- global float atomics are
+//                       the scarce resource on CDNA4, not VALU.
+//   K8+K9 preprocess_bwd 1 thread / Gaussian: conic -> cov2D -> (cov3D, mean) through the EWA
+//                       Jacobian, pixel mean -> world mean through the projection, inverse
+//                       depth, SH backward (coefficients staged in, gradients staged out through
+//                       the same LDS rows so both the 192-B read and the 192-B write per Gaussian
+//                       are coalesced float4 streams), cov3D -> scale / quaternion.
+//
+// Gradient conventions: SURVEY.md appendix A.4/A.5 (straight-through alpha clamp, constant
+// skip tests, clamp masks, 1/(det^2+1e-7), NDC-scaled mean2D gradient).
+#include "gms_common.h"
+#include "gms_project.h"
+
+namespace gms {
+
+struct BlendBwdArgs {
+    int W, H, gx, gy;
+    const uint32_t *tile_offset;
+    const uint64_t *keys;
+    const SplatRec *rec;
+    const float *bg;
+    const float *final_T;
+    const uint32_t *n_contrib;
+    const float *dL_dpix;       // [3,H,W]
+    const float *dL_dinvd;      // [H,W] or NULL
+    float *dL_dmean2D;          // [P,3]
+    float *dL_dconic;           // [P,4]
+    float *dL_dopacity;         // [P]
+    float *dL_dcolors;          // [P,3]
+    float *dL_dinvdepths;       // [P]
+};
+
+__device__ __forceinline__ bool block_to_tile_b(int b, int gx, int gy, int &tx, int &ty)
+{
+    const int xcd = b & 7, s = b >> 3;
+    ty = xcd + 8 * (s / gx);
+    tx = s % gx;
+    return ty < gy;
+}
+
+__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a)
+{
+    __shared__ SplatRec recs[BLOCK];
+    __shared__ uint32_t ids[BLOCK];
+    __shared__ uint32_t wave_max[4];
+    int tx, ty;
+    if (!block_to_tile_b(blockIdx.x, a.gx, a.gy, tx, ty)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx = tx * TILE + (wave & 1) * 8, qy = ty * TILE + (wave >> 1) * 8;
+    const int pxi = qx + (lane & 7), pyi = qy + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float wx0 = (float)qx, wy0 = (float)qy, wx1 = (float)(qx + 7), wy1 = (float)(qy + 7);
+    const int tile = ty * a.gx + tx;
+    const uint32_t beg = a.tile_offset[tile], end = a.tile_offset[tile + 1];
+    if (end <= beg) return;
+
+    const size_t HW = (size_t)a.W * a.H;
+    const size_t pid = (size_t)pyi * a.W + pxi;
+    const float Tfinal = inside ? a.final_T[pid] : 0.f;
+    float T = Tfinal;
+    const uint32_t last = inside ? a.n_contrib[pid] : 0u;
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
+    if (inside) {
+        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
+        if (a.dL_dinvd) dinvd = a.dL_dinvd[pid];
+    }
+    const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lastd = 0.f;
+    const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
+
+    // the tile only needs the prefix of its segment that some pixel actually composited
+    uint32_t m = last;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (lane == 0) wave_max[wave] = m;
+    __syncthreads();
+    const uint32_t total = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+
+    for (uint32_t hi = total; hi > 0; hi = hi > BLOCK ? hi - BLOCK : 0) {
+        const int cnt = (int)min((uint32_t)BLOCK, hi);
+        __syncthreads();                              // previous queue fully consumed
+        if (tid < cnt) {
+            const uint32_t e = hi - 1 - tid;          // queue slot 0 = backmost entry
+            const uint32_t id = (uint32_t)a.keys[beg + e];
+            ids[tid] = id;
+            recs[tid] = a.rec[id];
+        }
+        __syncthreads();
+        if (m == 0) continue;                         // wave-uniform: quadrant composited nothing
+        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
+            const int j = chunk + lane;
+            bool hit = false;
+            if (j < cnt) {
+                const float4 q0 = recs[j].q0;
+                const float4 q2 = recs[j].q2;
+                hit = !(q0.x + q2.z < wx0 || q0.x - q2.z > wx1 || q0.y + q2.w < wy0 || q0.y - q2.w > wy1);
+            }
+            uint64_t mask = __ballot(hit);
+            while (mask) {
+                const int bit = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int k = chunk + bit;
+                const uint32_t pos0 = hi - 1 - (uint32_t)k;          // 0-based position in the tile segment
+                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
+                const float dx = r0.x - pxf, dy = r0.y - pyf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(ALPHA_MAX, r1.y * G);
+                const bool act = pos0 < last && power <= 0.f && alpha >= ALPHA_MIN;
+                if (!__any(act)) continue;
+                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
+                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_id = 0.f;
+                if (act) {
+                    T = T / (1.f - alpha);
+                    const float w = alpha * T;
+                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                    accd = last_alpha * lastd + (1.f - last_alpha) * accd;
+                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x; lastd = r2.y;
+                    float dL_dalpha = (r1.z - acc0) * dp0 + (r1.w - acc1) * dp1 + (r2.x - acc2) * dp2 +
+                                      (r2.y - accd) * dinvd;
+                    g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_id = w * dinvd;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-Tfinal / (1.f - alpha)) * bgdot;
+                    const float dL_dG = r1.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
+                    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
+                    g_mx = dL_dG * dG_ddx * halfW;
+                    g_my = dL_dG * dG_ddy * halfH;
+                    g_ca = -0.5f * gdx * dx * dL_dG;
+                    g_cb = -0.5f * gdx * dy * dL_dG;
+                    g_cc = -0.5f * gdy * dy * dL_dG;
+                    g_op = G * dL_dalpha;
+                }
+                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+                g_op = wave_sum_to_lane63(g_op);
+                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+                g_id = wave_sum_to_lane63(g_id);
+                if (lane == 63) {
+                    const size_t id = ids[k];
+                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id, g_mx);
+                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id + 1, g_my);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id, g_ca);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 1, g_cb);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 3, g_cc);
+                    unsafeAtomicAdd(a.dL_dopacity + id, g_op);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id, g_r);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 1, g_g);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 2, g_b);
+                    if (a.dL_dinvd) unsafeAtomicAdd(a.dL_dinvdepths + id, g_id);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ K8 + K9
+constexpr int SH_PITCH_B = 52;
+
+struct PreBwdArgs {
+    int P, D, M, W, H;
+    const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
+    float mod, tanx, tany;
+    int aa;
+    const int *radii;
+    const uint8_t *clamped;
+    const float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dinvdepths;
+    float *dL_dopacity;     // in/out (antialiasing rescales it)
+    float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+};
+
+__global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH_B];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * BLOCK + tid;
+    const bool valid = i < a.P;
+    const bool vis = valid && a.radii[i] > 0;
+    float *wl = sh_lds + wave * (WAVE * SH_PITCH_B);
+    const int rowf = a.M * 3;
+    const bool use_sh = a.shs != nullptr;
+    const bool vec_ok = use_sh && (rowf % 4 == 0) && (rowf <= 48);
+    const int nb = (a.D + 1) * (a.D + 1);
+    const int g0 = blockIdx.x * BLOCK + wave * WAVE;
+    const int rows = min(WAVE, a.P - g0);
+
+    // stage the SH rows of this wave's 64 Gaussians into LDS (coalesced)
+    if (use_sh) {
+        if (vec_ok) {
+            if (__any(vis)) {
+                const int nq = (nb * 3 + 3) / 4, rowq = rowf / 4;
+                const float4 *src = reinterpret_cast<const float4 *>(a.shs + (size_t)g0 * rowf);
+                for (int idx = lane; idx < rows * nq; idx += WAVE) {
+                    int r = idx / nq, c = idx - r * nq;
+                    *reinterpret_cast<float4 *>(wl + r * SH_PITCH_B + c * 4) = src[(size_t)r * rowq + c];
+                }
+            }
+        } else if (vis) {
+            for (int k = 0; k < nb * 3; k++) wl[lane * SH_PITCH_B + k] = a.shs[(size_t)i * rowf + k];
+        }
+        __syncthreads();
+    }
+
+    float dmean[3] = {0.f, 0.f, 0.f};
+    float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dscale[3] = {0.f, 0.f, 0.f};
+    float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dop = valid ? a.dL_dopacity[i] : 0.f;
+    float *row = wl + lane * SH_PITCH_B;
+
+    if (vis) {
+        const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+        const float *V = a.view, *Mx = a.proj;
+        float vx, vy, vz;
+        view_transform(V, px, py, pz, vx, vy, vz);
+        Cov3 cv;
+        float s_in[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+        if (a.cov3Dp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cv.c[k] = a.cov3Dp[6 * (size_t)i + k];
+        } else {
+            s_in[0] = a.scales[3 * (size_t)i]; s_in[1] = a.scales[3 * (size_t)i + 1]; s_in[2] = a.scales[3 * (size_t)i + 2];
+            const float4 qv = *reinterpret_cast<const float4 *>(a.rots + 4 * (size_t)i);
+            q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+            cov3d_from_scale_rot(s_in, a.mod, q, cv);
+        }
+        const float fx = (float)a.W / (2.f * a.tanx), fy = (float)a.H / (2.f * a.tany);
+        Ewa e;
+        ewa_project(V, vx, vy, vz, cv, fx, fy, 1.3f * a.tanx, 1.3f * a.tany, e);
+        const float b = e.b, aD = e.a0 + DILATE, cD = e.c0 + DILATE;
+        const float det = aD * cD - b * b;
+        const float4 gcon = *reinterpret_cast<const float4 *>(a.dL_dconic + 4 * (size_t)i);
+        const float gA = gcon.x, gB = gcon.y, gC = gcon.w;
+        const float d2inv = 1.f / (det * det + 0.0000001f);
+        float dL_da = d2inv * (-cD * cD * gA + 2.f * b * cD * gB + (det - aD * cD) * gC);
+        float dL_dc = d2inv * (-aD * aD * gC + 2.f * aD * b * gB + (det - aD * cD) * gA);
+        float dL_db = d2inv * 2.f * (b * cD * gA - (det + 2.f * b * b) * gB + aD * b * gC);
+        if (a.aa) {
+            const float det0 = e.a0 * e.c0 - b * b;
+            const float ratio = det0 / det;
+            const float h = sqrtf(fmaxf(0.000025f, ratio));
+            const float dL_dh = dop * a.opac[i];
+            dop = dop * h;
+            const float dL_dr = ratio <= 0.000025f ? 0.f : dL_dh / (2.f * h);
+            dL_da += dL_dr * (e.c0 / det - det0 * cD / (det * det));
+            dL_dc += dL_dr * (e.a0 / det - det0 * aD / (det * det));
+            dL_db += dL_dr * (-2.f * b / det + det0 * 2.f * b / (det * det));
+        }
+        const float *T0 = e.T0, *T1 = e.T1;
+        dcov[0] = T0[0] * T0[0] * dL_da + T0[0] * T1[0] * dL_db + T1[0] * T1[0] * dL_dc;
+        dcov[3] = T0[1] * T0[1] * dL_da + T0[1] * T1[1] * dL_db + T1[1] * T1[1] * dL_dc;
+        dcov[5] = T0[2] * T0[2] * dL_da + T0[2] * T1[2] * dL_db + T1[2] * T1[2] * dL_dc;
+        dcov[1] = 2.f * T0[0] * T0[1] * dL_da + (T0[0] * T1[1] + T0[1] * T1[0]) * dL_db + 2.f * T1[0] * T1[1] * dL_dc;
+        dcov[2] = 2.f * T0[0] * T0[2] * dL_da + (T0[0] * T1[2] + T0[2] * T1[0]) * dL_db + 2.f * T1[0] * T1[2] * dL_dc;
+        dcov[4] = 2.f * T0[2] * T0[1] * dL_da + (T0[1] * T1[2] + T0[2] * T1[1]) * dL_db + 2.f * T1[1] * T1[2] * dL_dc;
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float dT0 = 2.f * e.ST0[c] * dL_da + e.ST1[c] * dL_db;
+            const float dT1 = 2.f * e.ST1[c] * dL_dc + e.ST0[c] * dL_db;
+            dJ00 += dT0 * V[4 * c + 0]; dJ02 += dT0 * V[4 * c + 2];
+            dJ11 += dT1 * V[4 * c + 1]; dJ12 += dT1 * V[4 * c + 2];
+        }
+        const float tzi = 1.f / e.tz, tz2 = tzi * tzi, tz3 = tz2 * tzi;
+        const float dtx = e.xmul * -fx * tz2 * dJ02;
+        const float dty = e.ymul * -fy * tz2 * dJ12;
+        float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.tx) * tz3 * dJ02 + (2.f * fy * e.ty) * tz3 * dJ12;
+        dtz -= a.dL_dinvdepths[i] * tz2;
+#pragma unroll
+        for (int r = 0; r < 3; r++) dmean[r] += V[4 * r + 0] * dtx + V[4 * r + 1] * dty + V[4 * r + 2] * dtz;
+
+        // pixel mean -> world mean
+        const float hx = dot3p(Mx[0], px, Mx[4], py, Mx[8], pz, Mx[12]);
+        const float hy = dot3p(Mx[1], px, Mx[5], py, Mx[9], pz, Mx[13]);
+        const float hw = dot3p(Mx[3], px, Mx[7], py, Mx[11], pz, Mx[15]);
+        const float mw = 1.f / (hw + 0.0000001f);
+        const float gmx = a.dL_dmean2D[3 * (size_t)i], gmy = a.dL_dmean2D[3 * (size_t)i + 1];
+        const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            dmean[r] += (Mx[4 * r + 0] * mw - Mx[4 * r + 3] * mul1) * gmx + (Mx[4 * r + 1] * mw - Mx[4 * r + 3] * mul2) * gmy;
+
+        // colour
+        if (use_sh) {
+            const float ddx = px - a.campos[0], ddy = py - a.campos[1], ddz = pz - a.campos[2];
+            const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            const float x = ddx * inv, y = ddy * inv, z = ddz * inv;
+            const unsigned cl = a.clamped[i];
+            float dRGB[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) dRGB[c] = ((cl >> c) & 1u) ? 0.f : a.dL_dcolors[3 * (size_t)i + c];
+            float gdir[3] = {0.f, 0.f, 0.f};
+            // basis value and its direction derivative per coefficient; row[k*3+c] is read (sh) then
+            // overwritten in place with d loss / d sh.
+#define GMS_SH_TERM(K, BV, BDX, BDY, BDZ)                                          \
+            {                                                                      \
+                const float bv = (BV), bx = (BDX), by = (BDY), bz = (BDZ);         \
+                _Pragma("unroll") for (int c = 0; c < 3; c++) {                    \
+                    const float w = row[(K) * 3 + c] * dRGB[c];                    \
+                    gdir[0] += bx * w; gdir[1] += by * w; gdir[2] += bz * w;       \
+                    row[(K) * 3 + c] = bv * dRGB[c];                               \
+                }                                                                  \
+            }
+            GMS_SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
+            if (a.D > 0) {
+                GMS_SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
+                GMS_SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
+                GMS_SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
+                if (a.D > 1) {
+                    const float xx = x * x, yy = y * y, zz = z * z;
+                    GMS_SH_TERM(4, SH_C2[0] * x * y, SH_C2[0] * y, SH_C2[0] * x, 0.f)
+                    GMS_SH_TERM(5, SH_C2[1] * y * z, 0.f, SH_C2[1] * z, SH_C2[1] * y)
+                    GMS_SH_TERM(6, SH_C2[2] * (2.f * zz - xx - yy), -2.f * SH_C2[2] * x, -2.f * SH_C2[2] * y, 4.f * SH_C2[2] * z)
+                    GMS_SH_TERM(7, SH_C2[3] * x * z, SH_C2[3] * z, 0.f, SH_C2[3] * x)
+                    GMS_SH_TERM(8, SH_C2[4] * (xx - yy), 2.f * SH_C2[4] * x, -2.f * SH_C2[4] * y, 0.f)
+                    if (a.D > 2) {
+                        GMS_SH_TERM(9, SH_C3[0] * y * (3.f * xx - yy), SH_C3[0] * 6.f * x * y, SH_C3[0] * (3.f * xx - 3.f * yy), 0.f)
+                        GMS_SH_TERM(10, SH_C3[1] * x * y * z, SH_C3[1] * y * z, SH_C3[1] * x * z, SH_C3[1] * x * y)
+                        GMS_SH_TERM(11, SH_C3[2] * y * (4.f * zz - xx - yy), SH_C3[2] * (-2.f * x * y), SH_C3[2] * (4.f * zz - xx - 3.f * yy), SH_C3[2] * 8.f * y * z)
+                        GMS_SH_TERM(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), SH_C3[3] * (-6.f * x * z), SH_C3[3] * (-6.f * y * z), SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
+                        GMS_SH_TERM(13, SH_C3[4] * x * (4.f * zz - xx - yy), SH_C3[4] * (4.f * zz - 3.f * xx - yy), SH_C3[4] * (-2.f * x * y), SH_C3[4] * 8.f * x * z)
+                        GMS_SH_TERM(14, SH_C3[5] * z * (xx - yy), SH_C3[5] * 2.f * x * z, SH_C3[5] * (-2.f * y * z), SH_C3[5] * (xx - yy))
+                        GMS_SH_TERM(15, SH_C3[6] * x * (xx - 3.f * yy), SH_C3[6] * (3.f * xx - 3.f * yy), SH_C3[6] * (-6.f * x * y), 0.f)
+                    }
+                }
+            }
+#undef GMS_SH_TERM
+            const float dd = x * gdir[0] + y * gdir[1] + z * gdir[2];
+            dmean[0] += (gdir[0] - x * dd) * inv;
+            dmean[1] += (gdir[1] - y * dd) * inv;
+            dmean[2] += (gdir[2] - z * dd) * inv;
+        }
+
+        // cov3D -> scale / quaternion
+        if (!a.cov3Dp) {
+            const float mod = a.mod;
+            const float s[3] = {mod * s_in[0], mod * s_in[1], mod * s_in[2]};
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            const float R[3][3] = {
+                {1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+            const float Gs[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                                    {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                                    {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            float dR[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float accs = 0.f;
+#pragma unroll
+                for (int a1 = 0; a1 < 3; a1++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k2 = 0; k2 < 3; k2++) acc += Gs[a1][k2] * R[k2][j] * s[j];
+                    const float dLm = 2.f * acc;            // d loss / d L[a1][j],  L = R diag(s)
+                    accs += R[a1][j] * dLm;
+                    dR[a1][j] = dLm * s[j];
+                }
+                dscale[j] = accs * mod;
+            }
+            drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
+            drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
+            drot[2] = 2.f * (-2.f * y * dR[0][0] + x * dR[0][1] + r * dR[0][2] + x * dR[1][0] + z * dR[1][2] - r * dR[2][0] + z * dR[2][1] - 2.f * y * dR[2][2]);
+            drot[3] = 2.f * (-2.f * z * dR[0][0] - r * dR[0][1] + x * dR[0][2] + r * dR[1][0] - 2.f * z * dR[1][1] + y * dR[1][2] + x * dR[2][0] + y * dR[2][1]);
+        }
+    }
+
+    // ---- SH gradient rows: zero what was not written, then stream the wave's rows out coalesced
+    if (use_sh) {
+        const int used = vis ? nb * 3 : 0;
+        if (vec_ok) {
+            for (int k = used; k < rowf; k++) row[k] = 0.f;
+            __syncthreads();
+            if (rows > 0) {
+                const int rowq = rowf / 4;
+                float4 *dst = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)g0 * rowf);
+                for (int idx = lane; idx < rows * rowq; idx += WAVE) {
+                    int r = idx / rowq, c = idx - r * rowq;
+                    dst[(size_t)r * rowq + c] = *reinterpret_cast<const float4 *>(wl + r * SH_PITCH_B + c * 4);
+                }
+            }
+        } else if (valid) {
+            for (int k = 0; k < rowf; k++) a.dL_dsh[(size_t)i * rowf + k] = k < used ? row[k] : 0.f;
+        }
+    }
+    if (!valid) return;
+    a.dL_dopacity[i] = dop;
+    a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1]; a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
+    if (a.cov3Dp) {
+        if (a.dL_dcov3D)
+#pragma unroll
+            for (int k = 0; k < 6; k++) a.dL_dcov3D[6 * (size_t)i + k] = dcov[k];
+    } else {
+        a.dL_dscales[3 * (size_t)i] = dscale[0]; a.dL_dscales[3 * (size_t)i + 1] = dscale[1]; a.dL_dscales[3 * (size_t)i + 2] = dscale[2];
+        *reinterpret_cast<float4 *>(a.dL_drots + 4 * (size_t)i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+}
+
+}  // namespace gms
+
+using namespace gms;
+
+extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    set_error("%s", "");
+    if (!A || A->P < 0 || A->width <= 0 || A->height <= 0) {
+        set_error("gms_rasterize_backward: invalid sizes");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    const int P = A->P, W = A->width, H = A->height;
+    if (P == 0) return GMS_OK;
+    const bool sr = A->scales && A->rotations;
+    if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
+        !A->dL_dout_color || !A->dL_dmeans2D || !A->dL_dconic || !A->dL_dopacity || !A->dL_dcolors ||
+        !A->dL_dinvdepths || !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
+        (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
+        (A->cov3D_precomp && !A->dL_dcov3D)) {
+        set_error("gms_rasterize_backward: null or inconsistent pointer arguments");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+    GeomState geom = GeomState::carve(const_cast<void *>(A->geom_buffer), (size_t)P);
+    ImageState img = ImageState::carve(const_cast<void *>(A->image_buffer), (size_t)W, (size_t)H);
+    BinningState bin = BinningState::carve(const_cast<void *>(A->binning_buffer), (size_t)A->num_rendered);
+
+    if (A->num_rendered > 0) {
+        BlendBwdArgs b;
+        b.W = W; b.H = H; b.gx = gx; b.gy = gy; b.tile_offset = img.tile_offset; b.keys = bin.keys; b.rec = geom.rec;
+        b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib; b.dL_dpix = A->dL_dout_color;
+        b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D; b.dL_dconic = A->dL_dconic;
+        b.dL_dopacity = A->dL_dopacity; b.dL_dcolors = A->dL_dcolors; b.dL_dinvdepths = A->dL_dinvdepths;
+        const unsigned bblocks = 8u * (unsigned)gx * (unsigned)((gy + 7) / 8);
+        blend_bwd_kernel<<<bblocks, BLOCK, 0, stream>>>(b);
+        GMS_KERNEL_CHECK(A->debug, stream, "blend_bwd");
+    }
+    PreBwdArgs p;
+    p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;
+    p.means3D = A->means3D; p.shs = A->shs; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
+    p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
+    p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
+    p.clamped = geom.clamped; p.dL_dmean2D = A->dL_dmeans2D; p.dL_dconic = A->dL_dconic; p.dL_dcolors = A->dL_dcolors;
+    p.dL_dinvdepths = A->dL_dinvdepths; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
+    p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
+    preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p);
+    GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
+    return GMS_OK;
+}

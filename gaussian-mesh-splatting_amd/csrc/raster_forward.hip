@@ -1,0 +1,606 @@
+// raster_forward.hip -- forward pass of the gfx950 Gaussian rasterizer.
+//
+// Pipeline (one HIP stream, no MFMA anywhere: there is no dense contraction on this path):
+//   K1  preprocess_fwd   1 thread / Gaussian.  SH coefficients are staged through LDS with
+//                        wave-cooperative float4 loads (coalesced 1 KiB per wave instruction)
+//                        and read back conflict-free with a 52-dword row pitch.  Emits the
+//                        48-byte splat record, depth, clamp bits, radius and counts tile
+//                        coverage with one atomic per (Gaussian, tile).
+//   K2  tile_scan        exclusive scan of the per-tile counts (single block), N -> pinned host.
+//   K3  emit_instances   one 64-bit key (depth bits << 32 | id) per (Gaussian, tile) into the
+//                        tile's segment (slot from a per-tile cursor atomic).
+//   K4  tile_sort        one block per tile: all-ascending bitonic network on (depth,id) keys in
+//                        LDS (global fallback for segments > 4096) -- the total order makes the
+//                        result independent of the atomic emission order (== stable radix sort
+//                        of the reference: ties in depth resolve by ascending Gaussian id).
+//   K6  blend_fwd        one block (4 waves) per 16x16 tile, each wave owns an 8x8 quadrant.
+//                        Splat records are gathered into an LDS queue 256 at a time; each wave
+//                        tests 64 queue entries at once against its quadrant (exact conservative
+//                        test on the alpha>=1/255 ellipse) and walks only the ballot survivors.
+//
+// Behavioural contract: SURVEY.md appendix A (constants, skip/stop tests, pixel-centre
+// convention); reference call site renderer/gaussian_renderer/__init__.py:94-102.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gms_common.h"
+#include "gms_project.h"
+
+namespace gms {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------ K1
+constexpr int SH_PITCH = 52;   // dwords per LDS row: 48 used; 52*l mod 64 hits 16 distinct 16-B slots
+
+struct PreArgs {
+    int P, D, M, W, H, gx, gy;
+    const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
+    float mod, tanx, tany;
+    int aa;
+    int *radii;
+    GeomState geom;
+    uint32_t *tile_count;
+};
+
+// SH -> RGB (before +0.5/clamp) from an LDS row laid out [k][c]; same operation order as
+// utils/sh_utils.py:57-112 evaluated per channel.
+__device__ __forceinline__ float sh_eval_channel(int deg, const float *row, int c, float x, float y, float z)
+{
+#pragma clang fp contract(off)
+    float res = SH_C0 * row[0 * 3 + c];
+    if (deg > 0) {
+        res = res - SH_C1 * y * row[1 * 3 + c] + SH_C1 * z * row[2 * 3 + c] - SH_C1 * x * row[3 * 3 + c];
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = res + SH_C2[0] * xy * row[4 * 3 + c] + SH_C2[1] * yz * row[5 * 3 + c] +
+                  SH_C2[2] * (2.f * zz - xx - yy) * row[6 * 3 + c] + SH_C2[3] * xz * row[7 * 3 + c] +
+                  SH_C2[4] * (xx - yy) * row[8 * 3 + c];
+            if (deg > 2) {
+                res = res + SH_C3[0] * y * (3.f * xx - yy) * row[9 * 3 + c] + SH_C3[1] * xy * z * row[10 * 3 + c] +
+                      SH_C3[2] * y * (4.f * zz - xx - yy) * row[11 * 3 + c] +
+                      SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * row[12 * 3 + c] +
+                      SH_C3[4] * x * (4.f * zz - xx - yy) * row[13 * 3 + c] + SH_C3[5] * z * (xx - yy) * row[14 * 3 + c] +
+                      SH_C3[6] * x * (xx - 3.f * yy) * row[15 * 3 + c];
+            }
+        }
+    }
+    return res;
+}
+
+__global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * BLOCK + tid;
+    const bool valid = i < a.P;
+
+    float px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0;
+    bool vis = false;
+    float pix = 0, piy = 0, cA = 0, cB = 0, cC = 0, opp = 0, a_d = 0, c_d = 0, rad = 0;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    if (valid) {
+        px = a.means3D[3 * (size_t)i]; py = a.means3D[3 * (size_t)i + 1]; pz = a.means3D[3 * (size_t)i + 2];
+        view_transform(a.view, px, py, pz, vx, vy, vz);
+        vis = vz > NEAR_Z;
+    }
+    if (vis) {
+        const float *Mx = a.proj;
+        float hx = dot3p(Mx[0], px, Mx[4], py, Mx[8], pz, Mx[12]);
+        float hy = dot3p(Mx[1], px, Mx[5], py, Mx[9], pz, Mx[13]);
+        float hw = dot3p(Mx[3], px, Mx[7], py, Mx[11], pz, Mx[15]);
+        float pw = 1.f / (hw + 0.0000001f);
+        float ndcx = hx * pw, ndcy = hy * pw;
+        Cov3 cv;
+        if (a.cov3Dp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) cv.c[k] = a.cov3Dp[6 * (size_t)i + k];
+        } else {
+            float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
+            const float4 qv = *reinterpret_cast<const float4 *>(a.rots + 4 * (size_t)i);
+            float q[4] = {qv.x, qv.y, qv.z, qv.w};
+            cov3d_from_scale_rot(s, a.mod, q, cv);
+        }
+        const float fx = (float)a.W / (2.f * a.tanx), fy = (float)a.H / (2.f * a.tany);
+        Ewa e;
+        ewa_project(a.view, vx, vy, vz, cv, fx, fy, 1.3f * a.tanx, 1.3f * a.tany, e);
+        float det0 = e.a0 * e.c0 - e.b * e.b;
+        a_d = e.a0 + DILATE; c_d = e.c0 + DILATE;
+        float det = a_d * c_d - e.b * e.b;
+        float hconv = 1.f;
+        if (a.aa) hconv = sqrtf(fmaxf(0.000025f, det0 / det));
+        if (det == 0.f) vis = false;
+        float dinv = 1.f / det;
+        cA = c_d * dinv; cB = -e.b * dinv; cC = a_d * dinv;
+        float mid = 0.5f * (a_d + c_d);
+        float disc = sqrtf(fmaxf(0.1f, mid * mid - det));
+        float l1 = mid + disc, l2 = mid - disc;
+        rad = ceilf(3.f * sqrtf(fmaxf(l1, l2)));
+        pix = ((ndcx + 1.f) * a.W - 1.f) * 0.5f;
+        piy = ((ndcy + 1.f) * a.H - 1.f) * 0.5f;
+        tile_rect(pix, piy, rad, a.gx, a.gy, minx, miny, maxx, maxy);
+        if ((maxx - minx) * (maxy - miny) == 0) vis = false;
+        opp = a.opac[i] * hconv;
+    }
+
+    // ---- colour
+    float rgb[3] = {0, 0, 0};
+    unsigned clampbits = 0;
+    if (a.shs) {
+        const int nb = (a.D + 1) * (a.D + 1);
+        const int rowf = a.M * 3;                 // floats per Gaussian in memory
+        float *wl = sh_lds + wave * (WAVE * SH_PITCH);
+        const bool any_vis = __any(vis);          // wave-uniform
+        const bool vec_ok = (rowf % 4 == 0) && (rowf <= 48);
+        if (any_vis && vec_ok) {
+            const int g0 = blockIdx.x * BLOCK + wave * WAVE;
+            const int rows = min(WAVE, a.P - g0);
+            const int nq = (nb * 3 + 3) / 4;      // float4 chunks actually needed per row
+            const int rowq = rowf / 4;
+            const float4 *src = reinterpret_cast<const float4 *>(a.shs + (size_t)g0 * rowf);
+            for (int idx = lane; idx < rows * nq; idx += WAVE) {
+                int r = idx / nq, c = idx - r * nq;
+                float4 v = src[(size_t)r * rowq + c];
+                *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = v;
+            }
+        } else if (vis) {   // generic storage width (M != 16): plain per-lane loads into the lane's row
+            for (int k = 0; k < nb * 3; k++) wl[lane * SH_PITCH + k] = a.shs[(size_t)i * rowf + k];
+        }
+        __syncthreads();
+        if (vis) {
+            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float x = dx * inv, y = dy * inv, z = dz * inv;
+            const float *row = wl + lane * SH_PITCH;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float v = sh_eval_channel(a.D, row, c, x, y, z) + 0.5f;
+                if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
+                rgb[c] = v;
+            }
+        }
+    } else if (vis) {
+        rgb[0] = a.colors[3 * (size_t)i]; rgb[1] = a.colors[3 * (size_t)i + 1]; rgb[2] = a.colors[3 * (size_t)i + 2];
+    }
+
+    if (!valid) return;
+    if (!vis) { a.radii[i] = 0; return; }
+
+    // half extents of the bounding box of {alpha >= 1/255}: |dx| <= sqrt(2 * cov_xx * ln(255 op)).
+    // ln is inflated by 1e-3 so float rounding can never cull a pair the per-pixel test would keep.
+    float tau = __logf(255.f * opp);
+    float ex, ey;
+    if (tau < -1e-3f) { ex = -1e30f; ey = -1e30f; }
+    else { ex = sqrtf(2.f * a_d * (tau + 1e-3f)); ey = sqrtf(2.f * c_d * (tau + 1e-3f)); }
+
+    SplatRec rec;
+    rec.q0 = make_float4(pix, piy, cA, cB);
+    rec.q1 = make_float4(cC, opp, rgb[0], rgb[1]);
+    rec.q2 = make_float4(rgb[2], 1.f / vz, ex, ey);
+    a.geom.rec[i] = rec;
+    a.geom.depth[i] = vz;
+    a.geom.clamped[i] = (uint8_t)clampbits;
+    a.radii[i] = (int)rad;
+    for (int ty = miny; ty < maxy; ty++)
+        for (int tx = minx; tx < maxx; tx++) atomicAdd(&a.tile_count[ty * a.gx + tx], 1u);
+}
+
+// ------------------------------------------------------------------------------------ K2
+// Exclusive scan over the tile counts by one block; offset[T] = N.  Also resets the cursors.
+__global__ void __launch_bounds__(BLOCK) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
+                                                          int T)
+{
+    __shared__ uint32_t part[BLOCK];
+    const int tid = threadIdx.x;
+    const int per = (T + BLOCK - 1) / BLOCK;
+    const int b = tid * per, e = min(T, b + per);
+    uint32_t s = 0;
+    for (int t = b; t < e; t++) s += count[t];
+    part[tid] = s;
+    __syncthreads();
+    for (int d = 1; d < BLOCK; d <<= 1) {
+        uint32_t v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - s;   // exclusive prefix of this thread's chunk
+    for (int t = b; t < e; t++) {
+        offset[t] = run;
+        cursor[t] = 0;
+        run += count[t];
+    }
+    if (tid == BLOCK - 1) offset[T] = part[BLOCK - 1];
+}
+
+// ------------------------------------------------------------------------------------ K3
+__global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, int gy, const int *radii, GeomState geom,
+                                                               const uint32_t *tile_offset, uint32_t *tile_cursor,
+                                                               uint64_t *keys, uint64_t capacity)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float4 q0 = geom.rec[i].q0;
+    int minx, miny, maxx, maxy;
+    tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
+    const uint64_t key = ((uint64_t)__float_as_uint(geom.depth[i]) << 32) | (uint32_t)i;
+    for (int ty = miny; ty < maxy; ty++)
+        for (int tx = minx; tx < maxx; tx++) {
+            const int t = ty * gx + tx;
+            const uint64_t slot = (uint64_t)tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (slot < capacity) keys[slot] = key;
+        }
+}
+
+// ------------------------------------------------------------------------------------ K4
+constexpr int SORT_CHUNK = 4096;   // keys resident in LDS (32 KiB)
+
+__device__ __forceinline__ void ce(uint64_t &x, uint64_t &y)
+{
+    if (x > y) { uint64_t t = x; x = y; y = t; }
+}
+
+// all-ascending bitonic network on m (power of two, <= SORT_CHUNK) keys in LDS.
+// first_k: smallest merge size to run (2 = full sort); mirror_first: run the mirror step of merge
+// size k (false when the caller already did the wide strides in global memory).
+__device__ void lds_sort(uint64_t *s, int m, int tid)
+{
+    for (int k = 2; k <= m; k <<= 1) {
+        const int hk = k >> 1;
+        for (int i = tid; i < (m >> 1); i += BLOCK) {
+            int blk = i / hk, off = i - blk * hk;
+            int lo = blk * k + off, hi = blk * k + k - 1 - off;
+            ce(s[lo], s[hi]);
+        }
+        __syncthreads();
+        for (int j = k >> 2; j >= 1; j >>= 1) {
+            for (int i = tid; i < (m >> 1); i += BLOCK) {
+                int lo = 2 * j * (i / j) + (i % j);
+                ce(s[lo], s[lo + j]);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// half-cleaner strides from j0 down to 1 inside one LDS-resident chunk of m keys
+__device__ void lds_clean(uint64_t *s, int m, int j0, int tid)
+{
+    for (int j = j0; j >= 1; j >>= 1) {
+        for (int i = tid; i < (m >> 1); i += BLOCK) {
+            int lo = 2 * j * (i / j) + (i % j);
+            ce(s[lo], s[lo + j]);
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) tile_sort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+{
+    __shared__ uint64_t s[SORT_CHUNK];
+    const int tid = threadIdx.x;
+    const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
+    if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
+    const long n = (long)(end64 - beg);
+    if (n <= 1) return;
+    uint64_t *g = keys + beg;
+    long np2 = 2;
+    while (np2 < n) np2 <<= 1;
+    const uint64_t INF = ~0ull;
+
+    if (np2 <= SORT_CHUNK) {
+        const int m = (int)np2;
+        for (int i = tid; i < m; i += BLOCK) s[i] = i < n ? g[i] : INF;
+        __syncthreads();
+        lds_sort(s, m, tid);
+        for (int i = tid; i < n; i += BLOCK) g[i] = s[i];
+        return;
+    }
+    // long segment: sort SORT_CHUNK-sized runs in LDS, then merge with wide strides in global memory
+    for (long c = 0; c < n; c += SORT_CHUNK) {
+        for (int i = tid; i < SORT_CHUNK; i += BLOCK) s[i] = (c + i) < n ? g[c + i] : INF;
+        __syncthreads();
+        lds_sort(s, SORT_CHUNK, tid);
+        for (int i = tid; i < SORT_CHUNK; i += BLOCK)
+            if (c + i < n) g[c + i] = s[i];
+        __syncthreads();
+    }
+    for (long k = 2L * SORT_CHUNK; k <= np2; k <<= 1) {
+        const long hk = k >> 1;
+        for (long i = tid; i < (np2 >> 1); i += BLOCK) {        // mirror step
+            long blk = i / hk, off = i - blk * hk;
+            long lo = blk * k + off, hi = blk * k + k - 1 - off;
+            if (hi < n) { uint64_t x = g[lo], y = g[hi]; if (x > y) { g[lo] = y; g[hi] = x; } }
+        }
+        __syncthreads();
+        for (long j = k >> 2; j >= SORT_CHUNK; j >>= 1) {       // strides that cross LDS chunks
+            for (long i = tid; i < (np2 >> 1); i += BLOCK) {
+                long lo = 2 * j * (i / j) + (i % j), hi = lo + j;
+                if (hi < n) { uint64_t x = g[lo], y = g[hi]; if (x > y) { g[lo] = y; g[hi] = x; } }
+            }
+            __syncthreads();
+        }
+        for (long c = 0; c < n; c += SORT_CHUNK) {               // remaining strides inside a chunk
+            for (int i = tid; i < SORT_CHUNK; i += BLOCK) s[i] = (c + i) < n ? g[c + i] : INF;
+            __syncthreads();
+            lds_clean(s, SORT_CHUNK, SORT_CHUNK >> 1, tid);
+            for (int i = tid; i < SORT_CHUNK; i += BLOCK)
+                if (c + i < n) g[c + i] = s[i];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ K6
+struct BlendFwdArgs {
+    int W, H, gx, gy;
+    const uint32_t *tile_offset;
+    const uint64_t *keys;
+    const SplatRec *rec;
+    const float *bg;
+    float *final_T;
+    uint32_t *n_contrib;
+    float *out_color;
+    float *out_invdepth;
+    uint64_t capacity;
+};
+
+// Block -> tile map: the dispatcher places block b on XCD b % 8 (observed, speed only).  Tile
+// rows are dealt round-robin to XCDs so that horizontally adjacent tiles (which share splats)
+// hit the same L2 while the heavy image centre is spread over all eight XCDs.
+__device__ __forceinline__ bool block_to_tile(int b, int gx, int gy, int &tx, int &ty)
+{
+    const int xcd = b & 7, s = b >> 3;
+    ty = xcd + 8 * (s / gx);
+    tx = s % gx;
+    return ty < gy;
+}
+
+__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a)
+{
+    __shared__ SplatRec recs[BLOCK];
+    int tx, ty;
+    if (!block_to_tile(blockIdx.x, a.gx, a.gy, tx, ty)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx = tx * TILE + (wave & 1) * 8, qy = ty * TILE + (wave >> 1) * 8;   // quadrant origin
+    const int pxi = qx + (lane & 7), pyi = qy + (lane >> 3);
+    const bool inside = pxi < a.W && pyi < a.H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const float wx0 = (float)qx, wy0 = (float)qy, wx1 = (float)(qx + 7), wy1 = (float)(qy + 7);
+    const int tile = ty * a.gx + tx;
+    uint32_t beg = a.tile_offset[tile], end = a.tile_offset[tile + 1];
+    if ((uint64_t)end > a.capacity) end = beg;     // overflowed launch (host re-runs it)
+
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (uint32_t base = beg; base < end; base += BLOCK) {
+        if (__syncthreads_and(done)) break;
+        const uint32_t idx = base + tid;
+        if (idx < end) {
+            const uint32_t id = (uint32_t)a.keys[idx];
+            recs[tid] = a.rec[id];
+        }
+        __syncthreads();
+        const int cnt = min((uint32_t)BLOCK, end - base);
+        if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
+        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
+            const int j = chunk + lane;
+            bool hit = false;
+            if (j < cnt) {
+                const float4 q0 = recs[j].q0;
+                const float4 q2 = recs[j].q2;
+                hit = !(q0.x + q2.z < wx0 || q0.x - q2.z > wx1 || q0.y + q2.w < wy0 || q0.y - q2.w > wy1);
+            }
+            uint64_t mask = __ballot(hit);
+            while (mask) {
+                const int bit = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const int k = chunk + bit;         // wave-uniform queue slot
+                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
+                const float dx = r0.x - pxf, dy = r0.y - pyf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
+                bool act = !done && power <= 0.f && alpha >= ALPHA_MIN;
+                const float testT = T * (1.f - alpha);
+                if (act && testT < T_MIN) { done = true; act = false; }
+                if (act) {
+                    const float w = alpha * T;
+                    C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
+                    Dp += r2.y * w;
+                    T = testT;
+                    last = (base - beg) + (uint32_t)k + 1u;
+                }
+                if (__all(done)) break;
+            }
+        }
+    }
+    if (inside) {
+        const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.W * a.H;
+        a.final_T[pid] = T;
+        a.n_contrib[pid] = last;
+        a.out_color[pid] = C0 + T * a.bg[0];
+        a.out_color[HW + pid] = C1 + T * a.bg[1];
+        a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
+        a.out_invdepth[pid] = Dp;
+    }
+}
+
+__global__ void fill_background_kernel(int W, int H, const float *bg, float *out_color, float *out_invdepth)
+{
+    const size_t HW = (size_t)W * H;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HW) return;
+    out_color[i] = bg[0]; out_color[HW + i] = bg[1]; out_color[2 * HW + i] = bg[2];
+    out_invdepth[i] = 0.f;
+}
+
+__global__ void mark_visible_kernel(int P, const float *means3D, const float *view, uint8_t *present)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float vx, vy, vz;
+    view_transform(view, means3D[3 * (size_t)i], means3D[3 * (size_t)i + 1], means3D[3 * (size_t)i + 2], vx, vy, vz);
+    present[i] = vz > NEAR_Z ? 1 : 0;
+}
+
+// pinned read-back slot, one per host thread
+static int32_t *pinned_slot()
+{
+    static thread_local int32_t *slot = nullptr;
+    if (!slot) {
+        if (hipHostMalloc((void **)&slot, 64, hipHostMallocDefault) != hipSuccess) slot = nullptr;
+    }
+    return slot;
+}
+
+}  // namespace gms
+
+using namespace gms;
+
+extern "C" int32_t gms_abi_version(void) { return GMS_ABI_VERSION; }
+extern "C" const char *gms_last_error(void) { return gms::g_err; }
+extern "C" size_t gms_geom_bytes(int32_t P) { return GeomState::bytes((size_t)(P > 0 ? P : 1)); }
+extern "C" size_t gms_image_bytes(int32_t w, int32_t h) { return ImageState::bytes((size_t)w, (size_t)h); }
+extern "C" size_t gms_binning_bytes(int64_t n) { return BinningState::bytes((size_t)(n > 0 ? n : 0)); }
+
+extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    g_err[0] = 0;
+    if (!A || A->P < 0 || A->width <= 0 || A->height <= 0 || !A->out_color || !A->out_invdepth || !A->background) {
+        set_error("gms_rasterize_forward: invalid sizes or null output/background pointer");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    const int P = A->P, W = A->width, H = A->height;
+    const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+    if (P > 0) {
+        if ((A->shs == nullptr) == (A->colors_precomp == nullptr)) {
+            set_error("provide exactly one of shs / colors_precomp");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+        const bool sr = A->scales && A->rotations;
+        if (sr == (A->cov3D_precomp != nullptr) || (!sr && (A->scales || A->rotations))) {
+            set_error("provide exactly one of (scales, rotations) / cov3D_precomp");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+        if (!A->means3D || !A->opacities || !A->viewmatrix || !A->projmatrix || !A->campos || !A->radii ||
+            !A->geom_alloc || !A->binning_alloc || !A->image_alloc) {
+            set_error("gms_rasterize_forward: null input pointer or callback");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+        if (A->shs && (A->D < 0 || A->D > 3 || (A->D + 1) * (A->D + 1) > A->M)) {
+            set_error("SH degree %d needs %d coefficients but M = %d (degrees 0..3 supported)", A->D,
+                      (A->D + 1) * (A->D + 1), A->M);
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+    }
+    const size_t HW = (size_t)W * H;
+    if (P == 0) {   // nothing to draw: background image, no scratch
+        fill_background_kernel<<<(unsigned)((HW + 255) / 256), 256, 0, stream>>>(W, H, A->background, A->out_color,
+                                                                                  A->out_invdepth);
+        GMS_KERNEL_CHECK(A->debug, stream, "fill_background");
+        return 0;
+    }
+
+    void *geom_mem = A->geom_alloc(A->geom_ctx, GeomState::bytes((size_t)P));
+    void *img_mem = A->image_alloc(A->image_ctx, ImageState::bytes((size_t)W, (size_t)H));
+    if (!geom_mem || !img_mem) { set_error("scratch allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+    GeomState geom = GeomState::carve(geom_mem, (size_t)P);
+    ImageState img = ImageState::carve(img_mem, (size_t)W, (size_t)H);
+
+    GMS_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * 4, stream));
+
+    PreArgs pa;
+    pa.P = P; pa.D = A->D; pa.M = A->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
+    pa.means3D = A->means3D; pa.shs = A->shs; pa.colors = A->colors_precomp; pa.opac = A->opacities;
+    pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
+    pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
+    pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.geom = geom; pa.tile_count = img.tile_count;
+    const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
+    preprocess_fwd_kernel<<<pblocks, BLOCK, 0, stream>>>(pa);
+    GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
+    tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor, T);
+    GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
+
+    int32_t *slot = pinned_slot();
+    if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
+    GMS_HIP_CHECK(hipMemcpyAsync(slot, img.tile_offset + T, 4, hipMemcpyDeviceToHost, stream));
+
+    BlendFwdArgs ba;
+    ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.tile_offset = img.tile_offset; ba.rec = geom.rec;
+    ba.bg = A->background; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib; ba.out_color = A->out_color;
+    ba.out_invdepth = A->out_invdepth;
+    const unsigned bblocks = 8u * (unsigned)gx * (unsigned)((gy + 7) / 8);
+
+    auto enqueue_tail = [&](void *bin_mem, uint64_t capacity) -> int32_t {
+        BinningState bin = BinningState::carve(bin_mem, (size_t)capacity);
+        emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset, img.tile_cursor,
+                                                              bin.keys, capacity);
+        GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
+        tile_sort_kernel<<<(unsigned)T, BLOCK, 0, stream>>>(img.tile_offset, bin.keys, capacity);
+        GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
+        ba.keys = bin.keys; ba.capacity = capacity;
+        blend_fwd_kernel<<<bblocks, BLOCK, 0, stream>>>(ba);
+        GMS_KERNEL_CHECK(A->debug, stream, "blend_fwd");
+        return GMS_OK;
+    };
+
+    int64_t N;
+    if (A->binning_capacity_hint > 0) {
+        // optimistic path: enqueue the whole tail before looking at N (no pipeline bubble)
+        const uint64_t cap = (uint64_t)A->binning_capacity_hint;
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap));
+        if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+        hipEvent_t ev;
+        GMS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        GMS_HIP_CHECK(hipEventRecord(ev, stream));       // after the N copy
+        int32_t rc = enqueue_tail(bin_mem, cap);
+        if (rc != GMS_OK) { (void)hipEventDestroy(ev); return rc; }
+        GMS_HIP_CHECK(hipEventSynchronize(ev));
+        (void)hipEventDestroy(ev);
+        N = (int64_t)(uint32_t)*slot;
+        if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
+            bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N));
+            if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+            GMS_HIP_CHECK(hipMemsetAsync(img.tile_cursor, 0, (size_t)T * 4, stream));
+            rc = enqueue_tail(bin_mem, (uint64_t)N);
+            if (rc != GMS_OK) return rc;
+        }
+    } else {
+        GMS_HIP_CHECK(hipStreamSynchronize(stream));
+        N = (int64_t)(uint32_t)*slot;
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N));
+        if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+        int32_t rc = enqueue_tail(bin_mem, (uint64_t)(N > 0 ? N : 1));
+        if (rc != GMS_OK) return rc;
+    }
+    return N;
+}
+
+extern "C" int32_t gms_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                                    uint8_t *present, void *stream_)
+{
+    (void)projmatrix;
+    hipStream_t stream = (hipStream_t)stream_;
+    g_err[0] = 0;
+    if (P < 0 || (P > 0 && (!means3D || !viewmatrix || !present))) {
+        set_error("gms_mark_visible: invalid argument");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    if (P == 0) return GMS_OK;
+    mark_visible_kernel<<<(unsigned)((P + 255) / 256), 256, 0, stream>>>(P, means3D, viewmatrix, present);
+    GMS_KERNEL_CHECK(0, stream, "mark_visible");
+    return GMS_OK;
+}

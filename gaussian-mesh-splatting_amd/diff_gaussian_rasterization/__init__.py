@@ -1,0 +1,250 @@
+"""Drop-in `diff_gaussian_rasterization` for GaMeS on MI355X (gfx950).
+
+Same import surface as the package the reference imports at
+renderer/gaussian_renderer/__init__.py:14 (and the three sibling renderers):
+
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+  * `GaussianRasterizationSettings`: the 13-field NamedTuple built by keyword at
+    renderer/gaussian_renderer/__init__.py:43-57.
+  * `GaussianRasterizer(raster_settings)`: nn.Module whose forward takes
+    (means3D, means2D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp) and returns
+    the 3-tuple (color[3,H,W], radii[P] int32, invdepth[1,H,W]) unpacked at
+    renderer/gaussian_renderer/__init__.py:94-102.
+  * autograd contract: forward inputs (means3D, means2D, sh, colors_precomp, opacities, scales,
+    rotations, cov3Ds_precomp, raster_settings); backward returns nine gradients in that order
+    (train.py:108 drives it through loss.backward()).  `means2D.grad` receives the NDC-scaled
+    screen-space gradient that densification reads (scene/gaussian_model.py:416-418).
+
+All arithmetic runs in hand-written HIP kernels (libgmsplat.so, C ABI in include/gmsplat.h);
+torch only provides device memory, the current stream and autograd plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    antialiasing: bool
+
+
+# (device index, W, H, P) -> instances rendered last time: lets the next call size the binning
+# buffer up-front and enqueue the whole forward without a pipeline bubble.
+_capacity_cache = {}
+_last_stats = {}
+
+
+def last_stats() -> dict:
+    """Counters of the most recent forward call (num_rendered, capacity hint used, ...)."""
+    return dict(_last_stats)
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+class _Scratch:
+    """Holds the three byte tensors the C side asks for through its resize callbacks."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensors = {}
+        self.error = None
+
+        def make(name):
+            def cb(_ctx, nbytes):
+                try:
+                    t = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=self.device)
+                    self.tensors[name] = t
+                    return t.data_ptr()
+                except Exception as e:  # noqa: BLE001 - reported through the error code path
+                    self.error = e
+                    return None
+            return _lib.ALLOC_FN(cb)
+
+        self.geom_cb, self.binning_cb, self.image_cb = make("geom"), make("binning"), make("image")
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        lib = _lib.load()
+        _lib.require_gpu(means3D, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)
+        device = means3D.device
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        P = int(means3D.shape[0])
+        H, W = int(rs.image_height), int(rs.image_width)
+
+        means3D = _f32c(means3D)
+        sh = _f32c(sh) if sh.numel() else sh
+        colors_precomp = _f32c(colors_precomp) if colors_precomp.numel() else colors_precomp
+        opacities = _f32c(opacities)
+        scales = _f32c(scales) if scales.numel() else scales
+        rotations = _f32c(rotations) if rotations.numel() else rotations
+        cov3Ds_precomp = _f32c(cov3Ds_precomp) if cov3Ds_precomp.numel() else cov3Ds_precomp
+        bg, view, proj, campos = (_f32c(t.to(device)) for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
+        if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
+            raise RuntimeError("sh must have dimensions (num_points, num_coeffs, 3)")
+        M = int(sh.shape[1]) if sh.numel() else 0
+
+        color = torch.empty((3, H, W), dtype=torch.float32, device=device)
+        invdepth = torch.empty((1, H, W), dtype=torch.float32, device=device)
+        radii = torch.empty((P,), dtype=torch.int32, device=device)
+
+        scratch = _Scratch(device)
+        key = (device.index, W, H, P)
+        hint = 0
+        if os.environ.get("GMS_SYNC_BINNING", "0") != "1":
+            prev = _capacity_cache.get(key)
+            if prev is not None:
+                hint = int(prev * 1.25) + 4096
+        a = _lib.RasterForwardArgs(
+            P=P, D=int(rs.sh_degree), M=M, width=W, height=H,
+            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh),
+            colors_precomp=_lib.ptr(colors_precomp), opacities=_lib.ptr(opacities), scales=_lib.ptr(scales),
+            rotations=_lib.ptr(rotations), cov3D_precomp=_lib.ptr(cov3Ds_precomp), viewmatrix=_lib.ptr(view),
+            projmatrix=_lib.ptr(proj), campos=_lib.ptr(campos), scale_modifier=float(rs.scale_modifier),
+            tan_fovx=float(rs.tanfovx), tan_fovy=float(rs.tanfovy), prefiltered=int(bool(rs.prefiltered)),
+            antialiasing=int(bool(rs.antialiasing)), debug=int(bool(rs.debug)),
+            out_color=_lib.ptr(color), out_invdepth=_lib.ptr(invdepth), radii=_lib.ptr(radii),
+            geom_alloc=scratch.geom_cb, geom_ctx=None, binning_alloc=scratch.binning_cb, binning_ctx=None,
+            image_alloc=scratch.image_cb, image_ctx=None, binning_capacity_hint=hint)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            num_rendered = lib.gms_rasterize_forward(C.byref(a), C.c_void_p(stream))
+        if num_rendered < 0:
+            if scratch.error is not None:
+                raise scratch.error
+            _lib.check(num_rendered, "gms_rasterize_forward")
+        _capacity_cache[key] = int(num_rendered)
+        _last_stats.update(num_rendered=int(num_rendered), capacity_hint=hint, P=P, width=W, height=H)
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = int(num_rendered)
+        ctx.M = M
+        empty = torch.empty(0, device=device)
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
+                              scratch.tensors.get("geom", empty), scratch.tensors.get("binning", empty),
+                              scratch.tensors.get("image", empty), bg, view, proj, campos)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, _grad_radii, grad_invdepth):
+        lib = _lib.load()
+        rs = ctx.raster_settings
+        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, image,
+         bg, view, proj, campos) = ctx.saved_tensors
+        device = means3D.device
+        P = int(means3D.shape[0])
+        H, W = int(rs.image_height), int(rs.image_width)
+        M = ctx.M
+        use_sh, use_cov = sh.numel() > 0, cov3Ds_precomp.numel() > 0
+
+        grad_color = _f32c(grad_color) if grad_color is not None else torch.zeros((3, H, W), device=device)
+        grad_invdepth = _f32c(grad_invdepth) if grad_invdepth is not None else None
+
+        # atomically accumulated gradients share one zero-filled allocation (one memset), carved into
+        # dense blocks: mean2D [P,3] | conic [P,4] | opacity [P] | colour [P,3] | invdepth [P]
+        flat = torch.zeros(max(P, 1) * 12, dtype=torch.float32, device=device)
+        dL_dmeans2D = flat[0:3 * P].view(P, 3)
+        dL_dconic = flat[3 * P:7 * P].view(P, 4)
+        dL_dopacity = flat[7 * P:8 * P].view(opacities.shape)
+        dL_dcolors = flat[8 * P:11 * P].view(P, 3)
+        dL_dinvdepths = flat[11 * P:12 * P]
+        dL_dmeans3D = torch.empty((P, 3), dtype=torch.float32, device=device)
+        dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device) if use_sh else None
+        dL_dscales = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_cov else None
+        dL_drot = torch.empty((P, 4), dtype=torch.float32, device=device) if not use_cov else None
+        dL_dcov3D = torch.empty((P, 6), dtype=torch.float32, device=device) if use_cov else None
+
+        a = _lib.RasterBackwardArgs(
+            P=P, D=int(rs.sh_degree), M=M, width=W, height=H, num_rendered=ctx.num_rendered,
+            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh), colors_precomp=_lib.ptr(colors_precomp),
+            opacities=_lib.ptr(opacities), scales=_lib.ptr(scales), rotations=_lib.ptr(rotations),
+            cov3D_precomp=_lib.ptr(cov3Ds_precomp), viewmatrix=_lib.ptr(view), projmatrix=_lib.ptr(proj),
+            campos=_lib.ptr(campos), scale_modifier=float(rs.scale_modifier), tan_fovx=float(rs.tanfovx),
+            tan_fovy=float(rs.tanfovy), antialiasing=int(bool(rs.antialiasing)), debug=int(bool(rs.debug)),
+            radii=_lib.ptr(radii), geom_buffer=_lib.ptr(geom), binning_buffer=_lib.ptr(binning),
+            image_buffer=_lib.ptr(image), dL_dout_color=_lib.ptr(grad_color), dL_dout_invdepth=_lib.ptr(grad_invdepth),
+            dL_dmeans2D=_lib.ptr(dL_dmeans2D), dL_dconic=_lib.ptr(dL_dconic), dL_dopacity=_lib.ptr(dL_dopacity),
+            dL_dcolors=_lib.ptr(dL_dcolors), dL_dinvdepths=_lib.ptr(dL_dinvdepths), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
+            dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dscales=_lib.ptr(dL_dscales),
+            dL_drotations=_lib.ptr(dL_drot))
+        if P > 0:
+            with torch.cuda.device(device):
+                stream = torch.cuda.current_stream(device).cuda_stream
+                _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
+        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, None if use_sh else dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
+                dL_dcov3D, None)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
+        """bool[P]: Gaussian centre passes the near-plane test of the current camera."""
+        lib = _lib.load()
+        rs = self.raster_settings
+        _lib.require_gpu(positions)
+        with torch.no_grad():
+            pos = _f32c(positions)
+            present = torch.empty((pos.shape[0],), dtype=torch.uint8, device=pos.device)
+            view, proj = _f32c(rs.viewmatrix.to(pos.device)), _f32c(rs.projmatrix.to(pos.device))
+            with torch.cuda.device(pos.device):
+                stream = torch.cuda.current_stream(pos.device).cuda_stream
+                _lib.check(lib.gms_mark_visible(int(pos.shape[0]), _lib.ptr(pos), _lib.ptr(view), _lib.ptr(proj),
+                                                _lib.ptr(present), C.c_void_p(stream)), "gms_mark_visible")
+        return present.bool()
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.Tensor([]).to(means3D.device)
+        shs = e if shs is None else shs
+        colors_precomp = e if colors_precomp is None else colors_precomp
+        scales = e if scales is None else scales
+        rotations = e if rotations is None else rotations
+        cov3D_precomp = e if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)

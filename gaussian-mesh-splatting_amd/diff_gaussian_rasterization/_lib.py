@@ -1,0 +1,132 @@
+"""ctypes binding of libgmsplat.so (the C ABI declared in include/gmsplat.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or the tensors are not on a
+GPU, calls fail loudly.  Build with `make -C gaussian-mesh-splatting_amd/csrc` (or
+`python __graft_entry__.py build`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "lib", "libgmsplat.so"))
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+GMS_ABI_VERSION = 1
+GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
+ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
+
+
+class RasterForwardArgs(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+        ("prefiltered", C.c_int32), ("antialiasing", C.c_int32), ("debug", C.c_int32),
+        ("out_color", C.c_void_p), ("out_invdepth", C.c_void_p), ("radii", C.c_void_p),
+        ("geom_alloc", ALLOC_FN), ("geom_ctx", C.c_void_p),
+        ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
+        ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
+        ("binning_capacity_hint", C.c_int64),
+    ]
+
+
+class RasterBackwardArgs(C.Structure):
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("num_rendered", C.c_int64),
+        ("background", C.c_void_p),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
+        ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
+        ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+        ("antialiasing", C.c_int32), ("debug", C.c_int32),
+        ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("image_buffer", C.c_void_p),
+        ("dL_dout_color", C.c_void_p), ("dL_dout_invdepth", C.c_void_p),
+        ("dL_dmeans2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
+        ("dL_dinvdepths", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
+    ]
+
+
+class MeshArgs(C.Structure):
+    _fields_ = [
+        ("F", C.c_int32), ("V", C.c_int32), ("P", C.c_int64), ("splats_per_face", C.c_int32), ("alpha_mode", C.c_int32),
+        ("vertices", C.c_void_p), ("faces", C.c_void_p), ("face_splat_offset", C.c_void_p), ("splat_face", C.c_void_p),
+        ("_alpha", C.c_void_p), ("_scale", C.c_void_p),
+    ]
+
+
+# every symbol include/gmsplat.h declares
+EXPORTS = (
+    "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
+    "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
+    "gms_binning_bytes",
+)
+
+_lock = threading.Lock()
+_lib = None
+
+
+def load():
+    """Load libgmsplat.so (once).  Raises RuntimeError with build instructions when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libgmsplat.so not found at {LIB_PATH}: the HIP rasterizer is not built. "
+                "Run `make -C gaussian-mesh-splatting_amd/csrc` (needs hipcc, targets gfx950). "
+                "There is no CPU fallback in the product path.")
+        lib = C.CDLL(LIB_PATH)
+        lib.gms_rasterize_forward.restype = C.c_int64
+        lib.gms_rasterize_forward.argtypes = [C.POINTER(RasterForwardArgs), C.c_void_p]
+        lib.gms_rasterize_backward.restype = C.c_int32
+        lib.gms_rasterize_backward.argtypes = [C.POINTER(RasterBackwardArgs), C.c_void_p]
+        lib.gms_mark_visible.restype = C.c_int32
+        lib.gms_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.gms_mesh_to_gaussians_forward.restype = C.c_int32
+        lib.gms_mesh_to_gaussians_forward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 5
+        lib.gms_mesh_to_gaussians_backward.restype = C.c_int32
+        lib.gms_mesh_to_gaussians_backward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 7
+        lib.gms_abi_version.restype = C.c_int32
+        lib.gms_last_error.restype = C.c_char_p
+        for n in ("gms_geom_bytes", "gms_image_bytes", "gms_binning_bytes"):
+            getattr(lib, n).restype = C.c_size_t
+        lib.gms_geom_bytes.argtypes = [C.c_int32]
+        lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
+        lib.gms_binning_bytes.argtypes = [C.c_int64]
+        if lib.gms_abi_version() != GMS_ABI_VERSION:
+            raise RuntimeError(f"libgmsplat.so ABI {lib.gms_abi_version()} != binding ABI {GMS_ABI_VERSION}; rebuild")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc < 0:
+        msg = load().gms_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed ({ERRORS.get(int(rc), rc)}): {msg}")
+    return rc
+
+
+def ptr(t):
+    """Device pointer of a tensor (None / empty -> NULL)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and t.numel() and not t.is_cuda:
+            raise RuntimeError(
+                "diff_gaussian_rasterization (MI355X/HIP build): tensors must live on a GPU; "
+                "there is no CPU path in the product (the CPU oracle lives under oracle/ for tests only)")

@@ -1,0 +1,178 @@
+/*
+ * gmsplat.h -- C ABI of the MI355X-native differentiable Gaussian rasterizer and the fused
+ * mesh-face -> Gaussian parameterization (libgmsplat.so, built from
+ * gaussian-mesh-splatting_amd/csrc by hipcc --offload-arch=gfx950).
+ *
+ * Plain pointers and sizes only: no torch types, no C++ in the signatures.  Every pointer
+ * marked "device" is an address in the HBM of the GPU that `stream` belongs to.  `stream`
+ * is a hipStream_t passed as void* (NULL = the null stream).  All entry points are
+ * re-entrant and keep no global mutable state besides a per-thread pinned 64-byte
+ * read-back slot.
+ *
+ * What each entry point replaces in the reference (waczjoan/gaussian-mesh-splatting):
+ *
+ *   gms_rasterize_forward   <- diff_gaussian_rasterization._C.rasterize_gaussians, i.e. what
+ *                              `GaussianRasterizer.forward` reaches from
+ *                              renderer/gaussian_renderer/__init__.py:94-102 (and the three
+ *                              sibling renderers: gaussian_animated_renderer/__init__.py:104-112,
+ *                              flame_gaussian_renderer/__init__.py:99-107,
+ *                              gaussian_points_animated_renderer/__init__.py:97-105)
+ *   gms_rasterize_backward  <- diff_gaussian_rasterization._C.rasterize_gaussians_backward,
+ *                              triggered by loss.backward() at train.py:108
+ *   gms_mark_visible        <- diff_gaussian_rasterization._C.mark_visible
+ *                              (GaussianRasterizer.markVisible; no call site in this tree)
+ *   gms_mesh_to_gaussians_forward / _backward
+ *                           <- GaussianMeshModel.update_alpha + _calc_xyz + prepare_scaling_rot
+ *                              (games/mesh_splatting/scene/gaussian_mesh_model.py:86-169), its
+ *                              autograd backward, rot_to_quat_batch (utils/general_utils.py:43-96),
+ *                              the multi-mesh loop (games/multi_mesh_splatting/scene/
+ *                              gaussian_multi_mesh_model.py:99-199) and the softmax variant
+ *                              (games/flame_splatting/scene/gaussian_flame_model.py:195)
+ *
+ * Matrix layout: exactly what scene/cameras.py:54-56 hands over -- the transposed 4x4, so the
+ * mathematical element (row r, col c) is m[4*c + r].  Quaternions are (w,x,y,z) and are used
+ * as given (the reference normalises in python, scene/gaussian_model.py:100-101).
+ */
+#ifndef GMSPLAT_H
+#define GMSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMS_ABI_VERSION 1
+
+/* error codes (negative return values) */
+#define GMS_OK 0
+#define GMS_ERR_INVALID_ARGUMENT (-1)
+#define GMS_ERR_ALLOC (-2)       /* a resize callback returned NULL */
+#define GMS_ERR_HIP (-3)         /* a HIP runtime call failed; see gms_last_error() */
+#define GMS_ERR_CAPACITY (-4)    /* caller-provided capacity too small (retry with the returned need) */
+
+/* Resize callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
+ * that stays valid until the matching backward has run.  Mirrors the three
+ * std::function<char*(size_t)> buffers of the upstream binding (geometry / binning / image
+ * state) so the caller's caching allocator owns all scratch. */
+typedef void *(*gms_alloc_fn)(void *ctx, size_t bytes);
+
+typedef struct GmsRasterForwardArgs {
+    /* sizes */
+    int32_t P;          /* number of Gaussians */
+    int32_t D;          /* active SH degree (0..3) */
+    int32_t M;          /* SH coefficients stored per Gaussian (16 for degree-3 storage); 0 if no SH */
+    int32_t width, height;
+    /* inputs (device) */
+    const float *background;      /* [3] */
+    const float *means3D;         /* [P,3] */
+    const float *shs;             /* [P,M,3] or NULL */
+    const float *colors_precomp;  /* [P,3] or NULL  (exactly one of shs / colors_precomp) */
+    const float *opacities;       /* [P] */
+    const float *scales;          /* [P,3] or NULL */
+    const float *rotations;       /* [P,4] or NULL */
+    const float *cov3D_precomp;   /* [P,6] or NULL  (exactly one of (scales,rotations) / cov3D_precomp) */
+    const float *viewmatrix;      /* [16] */
+    const float *projmatrix;      /* [16] */
+    const float *campos;          /* [3] */
+    float scale_modifier;
+    float tan_fovx, tan_fovy;
+    int32_t prefiltered;          /* accepted for API parity; culled points are simply culled */
+    int32_t antialiasing;
+    int32_t debug;                /* sync + check after every kernel */
+    /* outputs (device) */
+    float *out_color;             /* [3,H,W] */
+    float *out_invdepth;          /* [1,H,W] */
+    int32_t *radii;               /* [P] */
+    /* scratch owned by the caller through resize callbacks */
+    gms_alloc_fn geom_alloc;    void *geom_ctx;
+    gms_alloc_fn binning_alloc; void *binning_ctx;
+    gms_alloc_fn image_alloc;   void *image_ctx;
+    /* Optional: if > 0 the binning buffer is requested up-front for this many (Gaussian,tile)
+     * instances and the whole pipeline is enqueued before the host looks at the real count
+     * (no pipeline bubble); on overflow the tail of the pipeline is re-run after a resize. */
+    int64_t binning_capacity_hint;
+} GmsRasterForwardArgs;
+
+/* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */
+int64_t gms_rasterize_forward(const GmsRasterForwardArgs *args, void *stream);
+
+typedef struct GmsRasterBackwardArgs {
+    int32_t P, D, M, width, height;
+    int64_t num_rendered;             /* value returned by the forward call */
+    const float *background;
+    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *viewmatrix, *projmatrix, *campos;
+    float scale_modifier, tan_fovx, tan_fovy;
+    int32_t antialiasing, debug;
+    const int32_t *radii;             /* [P] from forward */
+    const void *geom_buffer;          /* the three scratch buffers of the forward call */
+    const void *binning_buffer;
+    const void *image_buffer;
+    const float *dL_dout_color;       /* [3,H,W] */
+    const float *dL_dout_invdepth;    /* [1,H,W] or NULL */
+    /* outputs (device).  dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dinvdepths are
+     * accumulated with atomics and MUST be zero-filled by the caller; the others are fully
+     * overwritten (no zero-fill needed). */
+    float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column dead */
+    float *dL_dconic;      /* [P,4] scratch */
+    float *dL_dopacity;    /* [P] */
+    float *dL_dcolors;     /* [P,3] scratch (or the colors_precomp gradient) */
+    float *dL_dinvdepths;  /* [P] scratch */
+    float *dL_dmeans3D;    /* [P,3] */
+    float *dL_dcov3D;      /* [P,6] written only when cov3D_precomp != NULL (else may be NULL) */
+    float *dL_dsh;         /* [P,M,3] written only when shs != NULL */
+    float *dL_dscales;     /* [P,3] written only when scales != NULL */
+    float *dL_drotations;  /* [P,4] written only when rotations != NULL */
+} GmsRasterBackwardArgs;
+
+int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);
+
+/* present[i] = 1 iff Gaussian i passes the near-plane test (view-space z > 0.2). */
+int32_t gms_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                         uint8_t *present, void *stream);
+
+/* ---- mesh-face -> Gaussian parameterization ------------------------------------------- */
+#define GMS_ALPHA_RELU 0      /* alpha = relu(_alpha)+1e-8, L1-normalised  (gaussian_mesh_model.py:166-167) */
+#define GMS_ALPHA_SOFTMAX 1   /* alpha = softmax(_alpha)                   (gaussian_flame_model.py:195) */
+
+typedef struct GmsMeshArgs {
+    int32_t F;                    /* faces (all meshes concatenated) */
+    int32_t V;                    /* vertices */
+    int64_t P;                    /* Gaussians = sum of splats over faces */
+    int32_t splats_per_face;      /* >0: uniform S (P == F*S); 0: use face_splat_offset / splat_face */
+    int32_t alpha_mode;
+    const float *vertices;        /* [V,3] */
+    const int64_t *faces;         /* [F,3] vertex indices (int64, as the reference stores them) */
+    const int32_t *face_splat_offset; /* [F+1] CSR offsets into the splat axis (non-uniform case) or NULL */
+    const int32_t *splat_face;    /* [P] face of each splat (non-uniform case) or NULL */
+    const float *_alpha;          /* [P,3]  (the reference's [F,S,3] flattened) */
+    const float *_scale;          /* [P] */
+} GmsMeshArgs;
+
+/* Outputs: alpha [P,3] (normalised barycentrics, kept because save_ply / the animated renderer
+ * read `pc.alpha`), xyz [P,3], scaling [P,3] = log(relu(_scale*s)+eps), rotation [P,4] quaternion. */
+int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *args, float *alpha, float *xyz, float *scaling,
+                                      float *rotation, void *stream);
+
+/* Gradients of (xyz, scaling, rotation) -> (vertices, _alpha, _scale).  dL_dvertices [V,3] is
+ * accumulated with atomics and MUST be zero-filled by the caller; dL_dalpha [P,3] and
+ * dL_dscale [P] are fully overwritten. */
+int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *args, const float *dL_dxyz, const float *dL_dscaling,
+                                       const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
+                                       float *dL_dscale, void *stream);
+
+/* ---- introspection --------------------------------------------------------------------- */
+int32_t gms_abi_version(void);
+/* Text of the last error on the calling thread ("" if none). */
+const char *gms_last_error(void);
+/* Byte sizes of the scratch buffers for given problem sizes (what the callbacks will be asked for). */
+size_t gms_geom_bytes(int32_t P);
+size_t gms_image_bytes(int32_t width, int32_t height);
+size_t gms_binning_bytes(int64_t num_instances);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMSPLAT_H */
