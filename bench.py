@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd rasterizations/s of the GaMeS render path on MI355X.
+
+One "step" = one training-style pass of the hot path over one camera view of synthetic
+mesh-bound Gaussians (BASELINE.json configs[1]/[2] sizes, SURVEY.md 8(d) "C2"):
+    K0 forward (mesh -> Gaussians)  ->  property getters  ->  render() forward (K1..K6)
+    -> loss.backward() with dL/dcolor = (image-0.5)/(3HW)  (K7..K9, K0 backward)
+    -> [N > 1] RCCL all-reduce of the parameter gradients  -> grads dropped.
+N GPUs = N independent views (one per rank), weak scaling, value = views/s over the whole job.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel, HIP-event timed on the
+launch stream), `kernels` (every kernel), `cpu_baseline` (the C oracle port on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "gaussian-mesh-splatting_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def algorithmic_bytes(P, N, F, W, H):
+    """Algorithmic HBM bytes per launch, SURVEY.md 8(d) per-unit figures (SH degree 3, scale+rotation inputs)."""
+    HW = W * H
+    return {
+        "preprocess_fwd": 308 * P,                 # read 236 + write 72 per Gaussian
+        "tile_scan": 8 * ((W + 15) // 16) * ((H + 15) // 16),
+        "emit_instances": 12 * N,                  # binning lower bound 28*N = emit 12 + sort 16
+        "tile_sort": 16 * N,
+        "blend_fwd": 44 * N + 24 * HW,             # id 4 + gathered record 40 per instance; 24 B per pixel
+        "blend_bwd": 84 * N + 24 * HW,             # 44 + one reduced 40-B gradient record per instance
+        "preprocess_bwd": 569 * P,                 # read 321 + write 248 per Gaussian
+        "mesh_fwd": 36 * F + 56 * P,               # tri 36/face; alpha 12 + scale 4 in, 40 out per splat
+        "mesh_bwd_splat": 56 * P,
+        "mesh_bwd_face": 40 * P + 36 * F,
+    }
+
+
+def cpu_baseline(workload, state, max_seconds=25.0):
+    """The oracle (C restatement of the rasterizer + torch restatement of K0) timed on the host cores."""
+    from games_hip import synthetic as syn
+    from oracle import gs_oracle, mesh_oracle
+    torch.set_num_threads(os.cpu_count() or 1)
+    sc = syn.mesh_scene(workload, state=state)
+    cam = syn.orbit_camera(0, width=sc.meta["image"], height=sc.meta["image"])
+    kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+              bg=torch.ones(3), viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+              campos=cam.camera_center)
+    times, pieces = [], {}
+    t_start = time.time()
+    for it in range(4):
+        t0 = time.time()
+        v = sc.vertices.clone().requires_grad_(True)
+        a = sc._alpha.clone().requires_grad_(True)
+        s = sc._scale.clone().requires_grad_(True)
+        _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(v, sc.faces, a, s)
+        xyz_a, s_a, r_a, op_a, shs = mesh_oracle.activated(xyz, scaling, rot, sc._opacity, sc._features_dc, sc._features_rest)
+        t1 = time.time()
+        o = gs_oracle.rasterize(means3D=xyz_a, opacities=op_a, shs=shs, scales=s_a, rotations=r_a, **kw)
+        t2 = time.time()
+        g = gs_oracle.backward(o, syn.upstream_grad(torch.from_numpy(o.color)))
+        t3 = time.time()
+        loss = ((xyz_a * torch.from_numpy(g["means3D"])).sum() + (s_a * torch.from_numpy(g["scales"])).sum()
+                + (r_a * torch.from_numpy(g["rotations"])).sum())
+        loss.backward()
+        t4 = time.time()
+        if it > 0 or time.time() - t_start > max_seconds / 2:
+            times.append(t4 - t0)
+            pieces = {"k0_fwd_s": t1 - t0, "raster_fwd_s": t2 - t1, "raster_bwd_s": t3 - t2, "k0_bwd_s": t4 - t3}
+        if time.time() - t_start > max_seconds:
+            break
+    t = sorted(times)[len(times) // 2]
+    return {"value": 1.0 / t, "unit": "iters/s", "cores": gs_oracle.max_threads(), "kind": "port",
+            "sample": f"{len(times)} full fwd+bwd iteration(s) of the same workload ({workload}/{state}, "
+                      f"{sc.num_gaussians} Gaussians, {cam.image_width}x{cam.image_height}); C oracle with OpenMP + "
+                      f"torch-CPU K0, median", "host_cpu_count": os.cpu_count(), **{k: round(v, 4) for k, v in pieces.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c2_hotdog_like")
+    ap.add_argument("--state", default="trained", choices=["trained", "init"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from diff_gaussian_rasterization import _lib, last_stats
+    from games_hip import synthetic as syn
+    from games_hip.ddp import allreduce_gradients
+    from games_hip.model import HipGaussianMeshModel
+    from games_hip.render import PipelineParams, render
+
+    scene = syn.mesh_scene(args.workload, state=args.state)
+    size = scene.meta["image"]
+    model = HipGaussianMeshModel.from_scene(scene, device)
+    cam = syn.orbit_camera(rank % 8, width=size, height=size).to(device)
+    bg = torch.ones(3, device=device)
+    pipe = PipelineParams()
+    params = model.parameters()
+    inv_norm = 1.0 / (2.0 * 3 * size * size)
+
+    def step():
+        model.update_alpha()
+        model.prepare_scaling_rot()
+        image = render(cam, model, pipe, bg)["render"]
+        loss = ((image - 0.5) ** 2).sum() * inv_norm     # d loss / d image = (image - 0.5) / (3HW)
+        loss.backward()
+        if world > 1:
+            allreduce_gradients(params, world)
+        for p in params:
+            p.grad = None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1000.0 * elapsed / args.steps
+    value = world * args.steps / elapsed
+    stats = last_stats()
+
+    # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)
+    lib = _lib.load()
+    lib.gms_profile_reset()
+    lib.gms_profile_enable(1)
+    for _ in range(args.profile_steps):
+        step()
+    torch.cuda.synchronize(device)
+    lib.gms_profile_enable(0)
+    ktimes = _lib.kernel_times()
+
+    if rank == 0:
+        P, F = scene.num_gaussians, scene.faces.shape[0]
+        N = int(stats.get("num_rendered", 0))
+        ab = algorithmic_bytes(P, N, F, size, size)
+        traffic = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                traffic = json.load(f).get(f"{args.workload}/{args.state}", {})
+        kernels = {}
+        for name, (ms, n) in ktimes.items():
+            if n == 0:
+                continue
+            avg_us = 1000.0 * ms / n
+            gbs = ab[name] / (avg_us * 1e-6) / 1e9
+            kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / args.profile_steps,
+                             "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
+                             "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": traffic.get(name)}
+        dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches_per_step"])
+        kd = kernels[dom]
+        sum_kernel_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels.values())
+        whole_bytes = 877 * P + 156 * N + 48 * size * size + 152 * P + 72 * F
+        out = {
+            "metric": "train iters/s (fwd+bwd raster) @800x800, 300k Gaussians; HBM GB/s vs roofline",
+            "value": round(value, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}/{args.state}: UV-sphere mesh F={F} x {scene.meta['S']} splats = {P} "
+                                   f"mesh-bound Gaussians, SH degree 3, {size}x{size}, orbit camera k=rank%8, white bg",
+                       "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
+                       "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single view",
+                       "step": "K0 fwd + render fwd + bwd (+ grad all-reduce when N>1)"},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                         "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"], "avg_launch_us": kd["avg_us"],
+                         "note": "blend kernels are VALU/LDS-bound (no dense contraction, no MFMA); HBM-bound kernels "
+                                 "are listed under `kernels`"},
+            "kernels": kernels,
+            "whole_iteration": {"algorithmic_bytes": whole_bytes, "sum_kernel_us": round(sum_kernel_us, 1),
+                                "achieved_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                                "frac_of_8TBps": round(whole_bytes / (ms_per_step * 1e-3) / 8e12, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload, args.state)
+                out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

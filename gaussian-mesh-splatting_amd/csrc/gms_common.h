@@ -141,6 +141,11 @@ __device__ __forceinline__ float dot3p(float a, float b, float c, float d, float
 // thread-local error text for gms_last_error()
 void set_error(const char *fmt, ...);
 
+// optional per-kernel event timing (profile.hip)
+extern bool g_profile_on;
+void profile_begin(int kernel_id, hipStream_t stream);
+void profile_end(int kernel_id, hipStream_t stream);
+
 }  // namespace gms
 
 #define GMS_HIP_CHECK(expr)                                                                    \
@@ -150,6 +155,14 @@ void set_error(const char *fmt, ...);
             gms::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
             return GMS_ERR_HIP;                                                                \
         }                                                                                      \
+    } while (0)
+
+// launch bracket: GMS_LAUNCH(GMS_K_x, stream, kernel<<<grid, block, 0, stream>>>(args));
+#define GMS_LAUNCH(kid, stream, ...)                                  \
+    do {                                                              \
+        if (gms::g_profile_on) gms::profile_begin(kid, stream);       \
+        __VA_ARGS__;                                                  \
+        if (gms::g_profile_on) gms::profile_end(kid, stream);         \
     } while (0)
 
 #define GMS_KERNEL_CHECK(dbg, stream, name)                                                    \

@@ -362,7 +362,7 @@ extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *al
     if (rc != GMS_OK) return rc;
     if (A->P == 0) return GMS_OK;
     if (!xyz || !scaling || !rotation) { set_error("mesh forward: null output"); return GMS_ERR_INVALID_ARGUMENT; }
-    mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation);
+    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation));
     GMS_KERNEL_CHECK(0, stream, "mesh_fwd");
     return GMS_OK;
 }
@@ -380,14 +380,14 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
         set_error("mesh backward: null gradient pointer");
         return GMS_ERR_INVALID_ARGUMENT;
     }
-    mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale);
+    GMS_LAUNCH(GMS_K_MESH_BWD_SPLAT, stream, mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale));
     GMS_KERNEL_CHECK(0, stream, "mesh_bwd_splat");
     const double avg = (double)A->P / (double)(A->F > 0 ? A->F : 1);
     if (avg >= 16.0) {
         const int fpb = BLOCK / WAVE;
-        mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices);
+        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices));
     } else {
-        mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices);
+        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices));
     }
     GMS_KERNEL_CHECK(0, stream, "mesh_bwd_face");
     return GMS_OK;

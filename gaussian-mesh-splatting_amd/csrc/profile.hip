@@ -1,0 +1,91 @@
+// profile.hip -- opt-in per-kernel timing with HIP events recorded on the launch stream.
+// bench.py uses it to report each kernel's average launch duration next to its algorithmic
+// bytes (roofline), inside the same process and on the same stream that does the work.
+#include <mutex>
+#include <vector>
+
+#include "gms_common.h"
+
+namespace gms {
+
+bool g_profile_on = false;
+
+namespace {
+struct Pair { int kid; hipEvent_t e0, e1; };
+std::mutex g_mu;
+std::vector<Pair> g_pending;
+std::vector<hipEvent_t> g_pool;
+double g_total_ms[GMS_K_COUNT] = {0};
+int64_t g_launches[GMS_K_COUNT] = {0};
+thread_local hipEvent_t t_open = nullptr;
+
+hipEvent_t get_event()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void drain_locked()
+{
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            g_total_ms[p.kid] += ms;
+            g_launches[p.kid] += 1;
+        }
+        g_pool.push_back(p.e0);
+        g_pool.push_back(p.e1);
+    }
+    g_pending.clear();
+}
+}  // namespace
+
+void profile_begin(int kid, hipStream_t stream)
+{
+    (void)kid;
+    t_open = get_event();
+    if (t_open) (void)hipEventRecord(t_open, stream);
+}
+
+void profile_end(int kid, hipStream_t stream)
+{
+    hipEvent_t e1 = get_event();
+    if (!t_open || !e1) return;
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_pending.push_back({kid, t_open, e1});
+    t_open = nullptr;
+}
+
+}  // namespace gms
+
+static const char *const k_names[GMS_K_COUNT] = {
+    "preprocess_fwd", "tile_scan", "emit_instances", "tile_sort", "blend_fwd",
+    "blend_bwd", "preprocess_bwd", "mesh_fwd", "mesh_bwd_splat", "mesh_bwd_face"};
+
+extern "C" void gms_profile_enable(int32_t on) { gms::g_profile_on = on != 0; }
+
+extern "C" void gms_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(gms::g_mu);
+    gms::drain_locked();
+    for (int k = 0; k < GMS_K_COUNT; k++) { gms::g_total_ms[k] = 0; gms::g_launches[k] = 0; }
+}
+
+extern "C" int32_t gms_profile_read(int32_t kid, double *total_ms, int64_t *launches)
+{
+    if (kid < 0 || kid >= GMS_K_COUNT) return GMS_ERR_INVALID_ARGUMENT;
+    std::lock_guard<std::mutex> lk(gms::g_mu);
+    gms::drain_locked();
+    if (total_ms) *total_ms = gms::g_total_ms[kid];
+    if (launches) *launches = gms::g_launches[kid];
+    return GMS_OK;
+}
+
+extern "C" const char *gms_profile_kernel_name(int32_t kid)
+{
+    return (kid >= 0 && kid < GMS_K_COUNT) ? k_names[kid] : "";
+}

@@ -443,7 +443,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D; b.dL_dconic = A->dL_dconic;
         b.dL_dopacity = A->dL_dopacity; b.dL_dcolors = A->dL_dcolors; b.dL_dinvdepths = A->dL_dinvdepths;
         const unsigned bblocks = 8u * (unsigned)gx * (unsigned)((gy + 7) / 8);
-        blend_bwd_kernel<<<bblocks, BLOCK, 0, stream>>>(b);
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<bblocks, BLOCK, 0, stream>>>(b));
         GMS_KERNEL_CHECK(A->debug, stream, "blend_bwd");
     }
     PreBwdArgs p;
@@ -454,7 +454,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.clamped = geom.clamped; p.dL_dmean2D = A->dL_dmeans2D; p.dL_dconic = A->dL_dconic; p.dL_dcolors = A->dL_dcolors;
     p.dL_dinvdepths = A->dL_dinvdepths; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
-    preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p);
+    GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
     return GMS_OK;
 }

@@ -529,9 +529,9 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.geom = geom; pa.tile_count = img.tile_count;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
-    preprocess_fwd_kernel<<<pblocks, BLOCK, 0, stream>>>(pa);
+    GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<<<pblocks, BLOCK, 0, stream>>>(pa));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
-    tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor, T);
+    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor, T));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
     int32_t *slot = pinned_slot();
@@ -546,13 +546,13 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
 
     auto enqueue_tail = [&](void *bin_mem, uint64_t capacity) -> int32_t {
         BinningState bin = BinningState::carve(bin_mem, (size_t)capacity);
-        emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset, img.tile_cursor,
-                                                              bin.keys, capacity);
+        GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
+                                                                                             img.tile_cursor, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
-        tile_sort_kernel<<<(unsigned)T, BLOCK, 0, stream>>>(img.tile_offset, bin.keys, capacity);
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_sort_kernel<<<(unsigned)T, BLOCK, 0, stream>>>(img.tile_offset, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         ba.keys = bin.keys; ba.capacity = capacity;
-        blend_fwd_kernel<<<bblocks, BLOCK, 0, stream>>>(ba);
+        GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<bblocks, BLOCK, 0, stream>>>(ba));
         GMS_KERNEL_CHECK(A->debug, stream, "blend_fwd");
         return GMS_OK;
     };

@@ -66,8 +66,9 @@ class MeshArgs(C.Structure):
 EXPORTS = (
     "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
-    "gms_binning_bytes",
+    "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
 )
+K_COUNT = 10
 
 _lock = threading.Lock()
 _lib = None
@@ -104,10 +105,28 @@ def load():
         lib.gms_geom_bytes.argtypes = [C.c_int32]
         lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
         lib.gms_binning_bytes.argtypes = [C.c_int64]
+        lib.gms_profile_enable.argtypes = [C.c_int32]
+        lib.gms_profile_enable.restype = None
+        lib.gms_profile_reset.restype = None
+        lib.gms_profile_read.argtypes = [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.gms_profile_read.restype = C.c_int32
+        lib.gms_profile_kernel_name.argtypes = [C.c_int32]
+        lib.gms_profile_kernel_name.restype = C.c_char_p
         if lib.gms_abi_version() != GMS_ABI_VERSION:
             raise RuntimeError(f"libgmsplat.so ABI {lib.gms_abi_version()} != binding ABI {GMS_ABI_VERSION}; rebuild")
         _lib = lib
     return _lib
+
+
+def kernel_times() -> dict:
+    """{kernel name: (total_ms, launches)} since the last gms_profile_reset()."""
+    lib = load()
+    out = {}
+    for k in range(K_COUNT):
+        ms, n = C.c_double(0), C.c_int64(0)
+        lib.gms_profile_read(k, C.byref(ms), C.byref(n))
+        out[lib.gms_profile_kernel_name(k).decode()] = (ms.value, n.value)
+    return out
 
 
 def check(rc: int, what: str):

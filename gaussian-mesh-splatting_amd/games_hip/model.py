@@ -1,0 +1,121 @@
+"""Mesh-bound Gaussian model on the fused HIP op: the attribute / method surface of the reference's
+GaussianMeshModel that the render path touches, without the reference's dataset / PLY / optimizer code.
+
+Mirrors (same names, same meaning):
+  scene/gaussian_model.py:95-115       get_scaling / get_rotation / get_xyz / get_features / get_opacity
+  games/mesh_splatting/scene/gaussian_mesh_model.py:153-169  update_alpha()
+  games/mesh_splatting/scene/gaussian_mesh_model.py:103-151  prepare_scaling_rot()
+  games/mesh_splatting/scene/gaussian_mesh_model.py:171-183  training_setup() parameter groups
+`HipMeshMixin` can also be mixed into the reference's own classes (see games_hip.install).
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .mesh_op import mesh_to_gaussians, triangles_to_gaussians
+
+
+class HipMeshMixin:
+    """Overrides only update_alpha / prepare_scaling_rot.  Host class must provide: vertices, faces,
+    _alpha [F,S,3], _scale [P,1]; optional `alpha_mode` ("relu" default, "softmax" for FLAME)."""
+
+    alpha_mode = "relu"
+
+    def update_alpha(self):
+        alpha, xyz, scaling, rotation = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale,
+                                                          self.alpha_mode)
+        self.alpha = alpha
+        self._xyz = xyz
+        with torch.no_grad():
+            tri = self.vertices[self.faces]
+        self.triangles = tri
+        self._hip_own_triangles = tri
+        self._hip_cached = (scaling, rotation)
+
+    def prepare_scaling_rot(self, *unused):
+        tri = getattr(self, "triangles", None)
+        own = getattr(self, "_hip_own_triangles", None)
+        cached = getattr(self, "_hip_cached", None)
+        if tri is not None and tri is not own:
+            # a renderer replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72-73):
+            # derive scale / rotation from those triangles
+            _, _, scaling, rotation = triangles_to_gaussians(tri, self._alpha, self._scale, self.alpha_mode)
+        elif cached is not None:
+            scaling, rotation = cached
+        else:
+            _, _, scaling, rotation = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale,
+                                                        self.alpha_mode)
+        self._scaling = scaling
+        self._rotation = rotation
+
+
+class HipGaussianMeshModel(HipMeshMixin):
+    """Stand-alone model (no dependency on the reference tree) used by bench.py / tests."""
+
+    def __init__(self, sh_degree: int = 3):
+        self.active_sh_degree = 0
+        self.max_sh_degree = sh_degree
+        self.optimizer = None
+
+    @classmethod
+    def from_scene(cls, scene, device="cuda"):
+        m = cls(3)
+        m.active_sh_degree = scene.active_sh_degree
+        m.alpha_mode = scene.alpha_mode
+        m.vertices = nn.Parameter(scene.vertices.to(device).float().contiguous())
+        m.faces = scene.faces.to(device)
+        m._alpha = nn.Parameter(scene._alpha.to(device).float().contiguous())
+        m._scale = nn.Parameter(scene._scale.to(device).float().contiguous())
+        m._opacity = nn.Parameter(scene._opacity.to(device).float().contiguous())
+        m._features_dc = nn.Parameter(scene._features_dc.to(device).float().contiguous())
+        m._features_rest = nn.Parameter(scene._features_rest.to(device).float().contiguous())
+        m.update_alpha()
+        m.prepare_scaling_rot()
+        return m
+
+    def parameters(self):
+        return [self.vertices, self._alpha, self._features_dc, self._features_rest, self._opacity, self._scale]
+
+    def training_setup(self, vertices_lr=0.0, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005):
+        groups = [
+            {"params": [self.vertices], "lr": vertices_lr, "name": "vertices"},
+            {"params": [self._alpha], "lr": alpha_lr, "name": "alpha"},
+            {"params": [self._features_dc], "lr": feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
+            {"params": [self._scale], "lr": scaling_lr, "name": "scaling"},
+        ]
+        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        return torch.sigmoid(self._opacity)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+
+def install(games_module=None):
+    """Swap the fused op into the reference's registry (games/__init__.py:35-51): the mesh model keeps
+    its class, dataset reader, optimizer groups and PLY I/O; only update_alpha / prepare_scaling_rot
+    are overridden.  Call after `import games` in an environment that has the reference on sys.path."""
+    if games_module is None:
+        import games as games_module  # type: ignore
+    base = games_module.gaussianModel["gs_mesh"]
+    cls = type("Hip" + base.__name__, (HipMeshMixin, base), {"alpha_mode": "relu"})
+    games_module.gaussianModel["gs_mesh"] = cls
+    return {"gs_mesh": cls}

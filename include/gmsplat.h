@@ -163,6 +163,27 @@ int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *args, const float *dL_
                                        const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
                                        float *dL_dscale, void *stream);
 
+/* ---- per-kernel timing (HIP events on the launch stream; off by default) ------------------
+ * When enabled every kernel launch made by this library is bracketed by two hipEvents on the
+ * caller's stream.  gms_profile_read() synchronises the recorded events and returns the summed
+ * duration and launch count per kernel since the last reset.  Used by bench.py for the live
+ * roofline figure; costs two event records per launch, so keep it off in timed regions. */
+#define GMS_K_PREPROCESS_FWD 0
+#define GMS_K_TILE_SCAN 1
+#define GMS_K_EMIT 2
+#define GMS_K_TILE_SORT 3
+#define GMS_K_BLEND_FWD 4
+#define GMS_K_BLEND_BWD 5
+#define GMS_K_PREPROCESS_BWD 6
+#define GMS_K_MESH_FWD 7
+#define GMS_K_MESH_BWD_SPLAT 8
+#define GMS_K_MESH_BWD_FACE 9
+#define GMS_K_COUNT 10
+void gms_profile_enable(int32_t on);
+void gms_profile_reset(void);
+int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);
+const char *gms_profile_kernel_name(int32_t kernel_id);
+
 /* ---- introspection --------------------------------------------------------------------- */
 int32_t gms_abi_version(void);
 /* Text of the last error on the calling thread ("" if none). */

@@ -1,0 +1,117 @@
+"""GPU parity of the fused mesh->Gaussian op (K0) against fixtures produced by executing the
+reference's own GaussianMeshModel / GaussianMultiMeshModel, and against the torch restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from games_hip import synthetic as syn
+from oracle import mesh_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(golden_dir, name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(golden_dir, name)).items()}
+
+
+def _loss(xyz, scaling, rotation, g, dev):
+    return ((xyz * g["g_xyz"].to(dev)).sum() + (torch.exp(scaling) * g["g_scaling_act"].to(dev)).sum()
+            + (torch.nn.functional.normalize(rotation) * g["g_rotation_act"].to(dev)).sum())
+
+
+def _close(a, b, rtol=2e-4, atol_rel=2e-5):
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    atol = atol_rel * float(b.abs().max()) + 1e-12
+    bad = (a - b).abs() > rtol * b.abs() + atol
+    assert not bad.any(), (float((a - b).abs().max()), float(b.abs().max()), int(bad.sum()))
+
+
+@pytest.mark.parametrize("name", ["k0_mesh.npz", "k0_mesh_s5.npz"])
+def test_single_mesh_matches_reference_fixture(golden_dir, name):
+    from games_hip.mesh_op import mesh_to_gaussians
+    g = _load(golden_dir, name)
+    v = g["vertices"].cuda().requires_grad_(True)
+    a = g["_alpha"].cuda().requires_grad_(True)
+    s = g["_scale"].cuda().requires_grad_(True)
+    alpha, xyz, scaling, rot = mesh_to_gaussians(v, g["faces"].cuda(), a, s, "relu")
+    _close(alpha, g["alpha"], rtol=1e-6)
+    _close(xyz, g["xyz"], rtol=1e-5)
+    # degenerate faces (zero area) give garbage-but-finite frames in the reference: exclude their splats
+    tri = g["triangles"]
+    area = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=1)
+    S = g["_alpha"].shape[1]
+    ok = (area > 1e-9).repeat_interleave(S)
+    _close(scaling[ok.cuda()], g["scaling"][ok], rtol=1e-5)
+    _close(rot[ok.cuda()], g["rotation"][ok], rtol=1e-4)
+    assert torch.isfinite(rot).all() and torch.isfinite(scaling).all()
+    if ok.all():
+        _loss(xyz, scaling, rot, g, "cuda").backward()
+        _close(v.grad, g["d_vertices"])
+        _close(a.grad, g["d_alpha"])
+        _close(s.grad, g["d_scale"])
+
+
+def test_multi_mesh_csr_matches_reference_fixture(golden_dir):
+    from games_hip.mesh_op import mesh_to_gaussians
+    g = _load(golden_dir, "k0_multi_mesh.npz")
+    verts, faces, alphas, scales, offs, sf = [], [], [], [], [0], []
+    voff = foff = 0
+    for i in range(2):
+        v, f, a, s = g[f"vertices{i}"], g[f"faces{i}"], g[f"_alpha{i}"], g[f"_scale{i}"]
+        verts.append(v); faces.append(f + voff); alphas.append(a.reshape(-1, 3)); scales.append(s)
+        S = a.shape[1]
+        for k in range(f.shape[0]):
+            offs.append(offs[-1] + S)
+            sf += [foff + k] * S
+        voff += v.shape[0]; foff += f.shape[0]
+    V = torch.cat(verts).cuda().requires_grad_(True)
+    A = torch.cat(alphas).cuda().requires_grad_(True)
+    Sc = torch.cat(scales).cuda().requires_grad_(True)
+    _, xyz, scaling, rot = mesh_to_gaussians(V, torch.cat(faces).cuda(), A, Sc, "relu",
+                                             face_splat_offset=torch.tensor(offs, dtype=torch.int32).cuda(),
+                                             splat_face=torch.tensor(sf, dtype=torch.int32).cuda())
+    _close(xyz, g["xyz"], rtol=1e-5); _close(scaling, g["scaling"], rtol=1e-5); _close(rot, g["rotation"], rtol=1e-4)
+    _loss(xyz, scaling, rot, g, "cuda").backward()
+    _close(V.grad, torch.cat([g["d_vertices0"], g["d_vertices1"]]))
+    _close(A.grad, torch.cat([g["d_alpha0"].reshape(-1, 3), g["d_alpha1"].reshape(-1, 3)]))
+    _close(Sc.grad, torch.cat([g["d_scale0"], g["d_scale1"]]))
+
+
+@pytest.mark.parametrize("mode,S", [("relu", 3), ("softmax", 4), ("softmax", 50), ("relu", 100)])
+def test_against_torch_restatement(mode, S):
+    """Thread-per-face (S < 16) and wave-per-face (S >= 16) backward paths, both alpha modes."""
+    from games_hip.mesh_op import mesh_to_gaussians
+    v, f = syn.uv_sphere(12, 14)
+    gen = torch.Generator().manual_seed(S)
+    F = f.shape[0]
+    a = torch.randn(F, S, 3, generator=gen) if mode == "softmax" else torch.rand(F, S, 3, generator=gen) - 0.1
+    s = torch.exp(0.3 * torch.randn(F * S, 1, generator=gen))
+    gx, gs, gr = torch.randn(F * S, 3, generator=gen), torch.randn(F * S, 3, generator=gen), torch.randn(F * S, 4, generator=gen)
+    g = dict(g_xyz=gx, g_scaling_act=gs, g_rotation_act=gr)
+    vc, ac, sc = v.clone().requires_grad_(True), a.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vc, f, ac, sc, mode)
+    _loss(xyz, scaling, rot, g, "cpu").backward()
+    vg, ag, sg = v.cuda().requires_grad_(True), a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    alpha_h, xyz_h, scaling_h, rot_h = mesh_to_gaussians(vg, f.cuda(), ag, sg, mode)
+    _loss(xyz_h, scaling_h, rot_h, g, "cuda").backward()
+    _close(xyz_h, xyz, rtol=1e-5); _close(scaling_h, scaling, rtol=1e-5); _close(rot_h, rot, rtol=1e-4)
+    _close(vg.grad, vc.grad); _close(ag.grad, ac.grad); _close(sg.grad, sc.grad)
+
+
+def test_triangles_mode_and_model_surface():
+    """The animated renderer replaces pc.triangles and calls prepare_scaling_rot()
+    (renderer/gaussian_animated_renderer/__init__.py:61-73): scales/rotations must follow the new triangles."""
+    from games_hip.model import HipGaussianMeshModel
+    scene = syn.mesh_scene("tiny")
+    m = HipGaussianMeshModel.from_scene(scene, "cuda")
+    assert m.get_xyz.shape == (scene.num_gaussians, 3) and m.alpha.shape == scene._alpha.shape
+    new_v = scene.vertices * torch.tensor([1.0, 1.3, 0.8])
+    tri = new_v[scene.faces].cuda()
+    with torch.no_grad():
+        m.triangles = tri
+        m.prepare_scaling_rot()
+        xyz = torch.matmul(m.alpha, tri).reshape(-1, 3)
+    _, _, xyz_o, scaling_o, rot_o = mesh_oracle.mesh_to_gaussians(new_v, scene.faces, scene._alpha, scene._scale)
+    _close(xyz, xyz_o, rtol=1e-5); _close(m._scaling, scaling_o, rtol=1e-5); _close(m._rotation, rot_o, rtol=1e-4)
