@@ -40,6 +40,8 @@ def algorithmic_bytes(P, N, F, W, H):
         "mesh_fwd": 36 * F + 56 * P,               # tri 36/face; alpha 12 + scale 4 in, 40 out per splat
         "mesh_bwd_splat": 56 * P,
         "mesh_bwd_face": 40 * P + 36 * F,
+        "blend_tloc": 0,        # implementation passes of the segment-parallel compositing: their traffic is
+        "blend_finalize": 0,    # overhead on top of blend_fwd's algorithmic bytes, not extra algorithmic work
     }
 
 

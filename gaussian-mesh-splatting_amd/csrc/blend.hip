@@ -1,0 +1,368 @@
+// blend.hip -- per-tile alpha compositing (forward and backward) for gfx950, segment-parallel.
+//
+// A tile's depth-sorted splat list is cut into segments of at most L entries (L = seg_len,
+// default 256); one work UNIT = (tile, segment) = one 256-thread block = 4 waves, each wave
+// owning an 8x8 pixel quadrant of the 16x16 tile.  Compositing is associative, so the segments of
+// a heavy tile (thousands of splats around mesh poles / silhouettes) run on different CUs instead
+// of serialising behind one block:
+//
+//   tloc     (multi-segment tiles only) per unit and pixel: T_loc = prod(1 - alpha) over the
+//            segment, no termination.  Not needed for a tile's last segment.
+//   fwd      per unit: T_start = prod_{k<seg} T_loc_k; a pixel whose T_start < 1e-4 is finished
+//            (any further contributing splat fails the T*(1-a) < 1e-4 test).  Exact front-to-back
+//            walk with the reference's skip/stop tests from T_start.  Single-segment tiles write
+//            the final image directly; multi-segment units write (C, D, T_end, last) partials.
+//   finalize (multi-segment tiles) sums the partials in segment order, writes image / final_T /
+//            n_contrib, and replaces each partial by the suffix sum the backward pass needs.
+//   bwd      per unit, back-to-front from (T_end, suffix colour / T_end): the reference's recurrence
+//            restarted at a segment boundary.  Ten partial gradients per (wave, splat) are summed
+//            over the 64 lanes with DPP row operations and leave the wave as ONE hardware float
+//            atomic each.
+//
+// Inside a unit the splat records are gathered 256 at a time into an LDS queue; every wave tests
+// 64 queue entries at once against its quadrant (bounding box of the alpha >= 1/255 ellipse --
+// exact: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors.
+#include "gms_common.h"
+#include "gms_blend.h"
+
+namespace gms {
+
+struct Unit {
+    int tile, seg, nseg, tx, ty;
+    uint32_t tile_beg;     // first entry of the tile in the sorted list
+    uint32_t beg, end;     // this unit's entries [beg, end)
+    uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
+};
+
+// Block -> unit.  The dispatcher places block b on XCD b % 8 (observed; speed only): give each XCD
+// a contiguous run of units (= band of neighbouring tiles, which gather the same splat records).
+__device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
+{
+    const uint32_t nunits = g.unit_first[g.T];
+    const uint32_t chunk = (nunits + 7u) >> 3;
+    const uint32_t s = blockIdx.x >> 3;
+    const uint32_t idx = (blockIdx.x & 7u) * chunk + s;
+    if (s >= chunk || idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
+    u.tile = (int)g.unit_tile[idx];
+    const uint32_t first = g.unit_first[u.tile];
+    u.seg = (int)(idx - first);
+    u.nseg = (int)(g.unit_first[u.tile + 1] - first);
+    u.tx = u.tile % g.gx; u.ty = u.tile / g.gx;
+    u.tile_beg = g.tile_offset[u.tile];
+    const uint32_t tile_end = g.tile_offset[u.tile + 1];
+    u.beg = u.tile_beg + (uint32_t)u.seg * g.seg_len;
+    u.end = min(tile_end, u.beg + g.seg_len);
+    u.slot0 = g.mseg_first[u.tile];
+    return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
+}
+
+struct Pix {
+    int xi, yi; bool inside; float xf, yf; float wx0, wy0, wx1, wy1;
+};
+
+__device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qx = u.tx * TILE + (wave & 1) * 8, qy = u.ty * TILE + (wave >> 1) * 8;
+    Pix p;
+    p.xi = qx + (lane & 7); p.yi = qy + (lane >> 3);
+    p.inside = p.xi < g.W && p.yi < g.H;
+    p.xf = (float)p.xi; p.yf = (float)p.yi;
+    p.wx0 = (float)qx; p.wy0 = (float)qy; p.wx1 = (float)(qx + 7); p.wy1 = (float)(qy + 7);
+    return p;
+}
+
+__device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p)
+{
+    if (j >= cnt) return false;
+    const float4 q0 = recs[j].q0;
+    const float4 q2 = recs[j].q2;
+    return !(q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1);
+}
+
+// ------------------------------------------------------------------------------------ tloc
+__global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const SplatRec *rec)
+{
+    __shared__ SplatRec recs[BLOCK];
+    Unit u;
+    if (!load_unit(g, u)) return;
+    if (u.nseg == 1 || u.seg == u.nseg - 1) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Pix p = pixel_of(g, u);
+    float Tl = 1.f;
+    for (uint32_t base = u.beg; base < u.end; base += BLOCK) {
+        __syncthreads();
+        const uint32_t idx = base + tid;
+        if (idx < u.end) recs[tid] = rec[(uint32_t)g.keys[idx]];
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)BLOCK, u.end - base);
+        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            while (mask) {
+                const int k = chunk + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float4 r0 = recs[k].q0, r1 = recs[k].q1;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
+                if (power <= 0.f && alpha >= ALPHA_MIN) Tl *= (1.f - alpha);
+            }
+        }
+    }
+    g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = Tl;
+}
+
+// ------------------------------------------------------------------------------------ fwd
+__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
+{
+    __shared__ SplatRec recs[BLOCK];
+    Unit u;
+    if (!load_unit(g, u)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const Pix p = pixel_of(g, u);
+
+    float T = 1.f;
+    for (int k = 0; k < u.seg; k++) T *= g.seg_state[(size_t)(u.slot0 + k) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !p.inside || dead_on_entry;
+
+    for (uint32_t base = u.beg; base < u.end; base += BLOCK) {
+        if (__syncthreads_and(done)) break;
+        const uint32_t idx = base + tid;
+        if (idx < u.end) recs[tid] = o.rec[(uint32_t)g.keys[idx]];
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)BLOCK, u.end - base);
+        if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
+        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            while (mask) {
+                const int k = chunk + __builtin_ctzll(mask);     // wave-uniform queue slot
+                mask &= mask - 1;
+                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
+                bool act = !done && power <= 0.f && alpha >= ALPHA_MIN;
+                const float testT = T * (1.f - alpha);
+                if (act && testT < T_MIN) { done = true; act = false; }
+                if (act) {
+                    const float w = alpha * T;
+                    C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
+                    Dp += r2.y * w;
+                    T = testT;
+                    last = (base - u.tile_beg) + (uint32_t)k + 1u;
+                }
+                if (__all(done)) break;
+            }
+        }
+    }
+    if (u.nseg == 1) {
+        if (p.inside) {
+            const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
+            o.final_T[pid] = T;
+            o.n_contrib[pid] = last;
+            o.out_color[pid] = C0 + T * o.bg[0];
+            o.out_color[HW + pid] = C1 + T * o.bg[1];
+            o.out_color[2 * HW + pid] = C2 + T * o.bg[2];
+            o.out_invdepth[pid] = Dp;
+        }
+    } else {
+        float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        st[SEG_C0 * TILE_PIX + tid] = C0; st[SEG_C1 * TILE_PIX + tid] = C1; st[SEG_C2 * TILE_PIX + tid] = C2;
+        st[SEG_D * TILE_PIX + tid] = Dp;
+        st[SEG_TEND * TILE_PIX + tid] = dead_on_entry ? -1.f : T;
+        st[SEG_LAST * TILE_PIX + tid] = __uint_as_float(last);
+    }
+}
+
+// ------------------------------------------------------------------------------------ finalize
+__global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, BlendFwdOut o)
+{
+    const int tile = blockIdx.x;
+    const uint32_t first = g.unit_first[tile];
+    const int nseg = (int)(g.unit_first[tile + 1] - first);
+    if (nseg <= 1) return;
+    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tx = tile % g.gx, ty = tile / g.gx;
+    const int xi = tx * TILE + (wave & 1) * 8 + (lane & 7), yi = ty * TILE + (wave >> 1) * 8 + (lane >> 3);
+    float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
+    uint32_t last = 0;
+    for (int k = 0; k < nseg; k++) {
+        const float *st = st0 + (size_t)k * SEG_FLOATS;
+        const float te = st[SEG_TEND * TILE_PIX + tid];
+        if (te >= 0.f) {
+            C0 += st[SEG_C0 * TILE_PIX + tid]; C1 += st[SEG_C1 * TILE_PIX + tid]; C2 += st[SEG_C2 * TILE_PIX + tid];
+            Dp += st[SEG_D * TILE_PIX + tid];
+            T = te;
+            last = max(last, __float_as_uint(st[SEG_LAST * TILE_PIX + tid]));
+        }
+    }
+    if (xi < g.W && yi < g.H) {
+        const size_t pid = (size_t)yi * g.W + xi, HW = (size_t)g.W * g.H;
+        o.final_T[pid] = T;
+        o.n_contrib[pid] = last;
+        o.out_color[pid] = C0 + T * o.bg[0];
+        o.out_color[HW + pid] = C1 + T * o.bg[1];
+        o.out_color[2 * HW + pid] = C2 + T * o.bg[2];
+        o.out_invdepth[pid] = Dp;
+    }
+    // suffix sums for the backward pass: S_k = sum of the partials of the segments behind k
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
+    for (int k = nseg - 1; k >= 0; k--) {
+        float *st = st0 + (size_t)k * SEG_FLOATS;
+        const bool live = st[SEG_TEND * TILE_PIX + tid] >= 0.f;
+        const float c0 = st[SEG_C0 * TILE_PIX + tid], c1 = st[SEG_C1 * TILE_PIX + tid], c2 = st[SEG_C2 * TILE_PIX + tid];
+        const float d = st[SEG_D * TILE_PIX + tid];
+        st[SEG_C0 * TILE_PIX + tid] = S0; st[SEG_C1 * TILE_PIX + tid] = S1; st[SEG_C2 * TILE_PIX + tid] = S2;
+        st[SEG_D * TILE_PIX + tid] = SD;
+        if (live) { S0 += c0; S1 += c1; S2 += c2; SD += d; }
+    }
+}
+
+// ------------------------------------------------------------------------------------ bwd
+__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
+{
+    __shared__ SplatRec recs[BLOCK];
+    __shared__ uint32_t ids[BLOCK];
+    __shared__ uint32_t wave_max[4];
+    Unit u;
+    if (!load_unit(g, u)) return;
+    if (u.end <= u.beg) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Pix p = pixel_of(g, u);
+    const size_t HW = (size_t)g.W * g.H;
+    const size_t pid = (size_t)p.yi * g.W + p.xi;
+    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
+    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // 1-based position of the last applied splat
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
+    if (p.inside) {
+        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
+        if (a.dL_dinvd) dinvd = a.dL_dinvd[pid];
+    }
+    const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
+    const uint32_t seg_lo = u.beg - u.tile_beg, seg_hi = u.end - u.tile_beg;   // positions covered by this unit
+
+    float T = Tfinal, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
+    if (u.nseg > 1) {
+        const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        const float te = st[SEG_TEND * TILE_PIX + tid];
+        if (te > 0.f) {
+            T = te;
+            const float inv = 1.f / te;
+            acc0 = st[SEG_C0 * TILE_PIX + tid] * inv; acc1 = st[SEG_C1 * TILE_PIX + tid] * inv;
+            acc2 = st[SEG_C2 * TILE_PIX + tid] * inv; accd = st[SEG_D * TILE_PIX + tid] * inv;
+        }
+    }
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lastd = 0.f;
+    const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;
+
+    // entries of this unit that some pixel of the tile actually composited: positions [seg_lo, top)
+    uint32_t m = min(last, seg_hi);
+    m = m > seg_lo ? m : 0u;                       // 0 = this pixel has nothing in this unit
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    if (lane == 0) wave_max[wave] = m;
+    __syncthreads();
+    const uint32_t top = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    if (top == 0) return;
+
+    for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > BLOCK ? hi - BLOCK : seg_lo) {
+        const int cnt = (int)min((uint32_t)BLOCK, hi - seg_lo);
+        __syncthreads();                              // previous queue fully consumed
+        if (tid < cnt) {
+            const uint32_t e = hi - 1 - tid;          // queue slot 0 = backmost entry
+            const uint32_t id = (uint32_t)g.keys[u.tile_beg + e];
+            ids[tid] = id;
+            recs[tid] = a.rec[id];
+        }
+        __syncthreads();
+        if (m == 0) continue;                         // wave-uniform: quadrant has nothing in this unit
+        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            while (mask) {
+                const int k = chunk + __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const uint32_t pos0 = hi - 1 - (uint32_t)k;          // 0-based position in the tile's list
+                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                const float G = __expf(power);
+                const float alpha = fminf(ALPHA_MAX, r1.y * G);
+                const bool act = pos0 < last && power <= 0.f && alpha >= ALPHA_MIN;
+                if (!__any(act)) continue;
+                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
+                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_id = 0.f;
+                if (act) {
+                    T = T / (1.f - alpha);
+                    const float w = alpha * T;
+                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
+                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
+                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
+                    accd = last_alpha * lastd + (1.f - last_alpha) * accd;
+                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x; lastd = r2.y;
+                    float dL_dalpha = (r1.z - acc0) * dp0 + (r1.w - acc1) * dp1 + (r2.x - acc2) * dp2 +
+                                      (r2.y - accd) * dinvd;
+                    g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_id = w * dinvd;
+                    dL_dalpha *= T;
+                    last_alpha = alpha;
+                    dL_dalpha += (-Tfinal / (1.f - alpha)) * bgdot;
+                    const float dL_dG = r1.y * dL_dalpha;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
+                    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
+                    g_mx = dL_dG * dG_ddx * halfW;
+                    g_my = dL_dG * dG_ddy * halfH;
+                    g_ca = -0.5f * gdx * dx * dL_dG;
+                    g_cb = -0.5f * gdx * dy * dL_dG;
+                    g_cc = -0.5f * gdy * dy * dL_dG;
+                    g_op = G * dL_dalpha;
+                }
+                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
+                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
+                g_op = wave_sum_to_lane63(g_op);
+                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
+                g_id = wave_sum_to_lane63(g_id);
+                if (lane == 63) {
+                    const size_t id = ids[k];
+                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id, g_mx);
+                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id + 1, g_my);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id, g_ca);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 1, g_cb);
+                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 3, g_cc);
+                    unsafeAtomicAdd(a.dL_dopacity + id, g_op);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id, g_r);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 1, g_g);
+                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 2, g_b);
+                    if (a.dL_dinvd) unsafeAtomicAdd(a.dL_dinvdepths + id, g_id);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ host
+int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+{
+    const unsigned blocks = 8u * ((max_units + 7u) / 8u);
+    GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
+    GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, o));
+    GMS_KERNEL_CHECK(debug, stream, "blend_fwd");
+    GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, blend_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
+    GMS_KERNEL_CHECK(debug, stream, "blend_finalize");
+    return GMS_OK;
+}
+
+int32_t launch_blend_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+{
+    const unsigned blocks = 8u * ((max_units + 7u) / 8u);
+    GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, a));
+    GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
+    return GMS_OK;
+}
+
+}  // namespace gms

@@ -63,10 +63,12 @@ struct ImageState {
     uint32_t *tile_count;   // [T]     instances per tile (atomically counted in preprocess)
     uint32_t *tile_cursor;  // [T]     emit cursors
     uint32_t *tile_offset;  // [T+1]   exclusive scan of tile_count; tile_offset[T] = N
+    uint32_t *unit_first;   // [T+1]   exclusive scan of segments per tile; unit_first[T] = #units
+    uint32_t *mseg_first;   // [T+1]   exclusive scan of segments of multi-segment tiles only
     static __host__ __device__ size_t bytes(size_t W, size_t H)
     {
         size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-        return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + align_up((T + 1) * 4, 256);
+        return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + 3 * align_up((T + 1) * 4, 256);
     }
     static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
     {
@@ -77,18 +79,33 @@ struct ImageState {
         s.n_contrib = (uint32_t *)p;   p += align_up(W * H * 4, 256);
         s.tile_count = (uint32_t *)p;  p += align_up(T * 4, 256);
         s.tile_cursor = (uint32_t *)p; p += align_up(T * 4, 256);
-        s.tile_offset = (uint32_t *)p;
+        s.tile_offset = (uint32_t *)p; p += align_up((T + 1) * 4, 256);
+        s.unit_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
+        s.mseg_first = (uint32_t *)p;
         return s;
     }
 };
 
+// Binning buffer: sorted keys, unit table and per-(unit, pixel) segment state.  Sized from the
+// instance capacity N, the tile count T and the segment length L.
 struct BinningState {
-    uint64_t *keys;   // [N]  (depth_bits << 32) | gaussian id ; sorted in place per tile segment
-    static __host__ __device__ size_t bytes(size_t N) { return align_up((N > 0 ? N : 1) * 8, 256); }
-    static __host__ __device__ BinningState carve(void *base, size_t)
+    uint64_t *keys;        // [N]  (depth_bits << 32) | gaussian id ; sorted in place per tile segment
+    uint32_t *unit_tile;   // [T + N/L + 1]
+    float *seg_state;      // [2N/L + 2][7][256]
+    static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
+    static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
+    static __host__ __device__ size_t bytes(size_t N, size_t T, size_t L)
+    {
+        return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 4, 256) +
+               align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
+    }
+    static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
     {
         BinningState b;
-        b.keys = (uint64_t *)base;
+        char *p = (char *)base;
+        b.keys = (uint64_t *)p;      p += align_up((N > 0 ? N : 1) * 8, 256);
+        b.unit_tile = (uint32_t *)p; p += align_up(n_units(N, T, L) * 4, 256);
+        b.seg_state = (float *)p;
         return b;
     }
 };
@@ -127,6 +144,36 @@ __device__ __forceinline__ void tile_rect(float px, float py, float radius, int 
     maxy = (int)fminf(big, fmaxf(-big, q3));
     minx = min(gx, max(0, minx)); maxx = min(gx, max(0, maxx));
     miny = min(gy, max(0, miny)); maxy = min(gy, max(0, maxy));
+}
+
+// Wave-aggregated counter increment.  Neighbouring Gaussians (consecutive ids on a mesh face) land
+// in the same tile, so per-lane atomics hammer a handful of addresses and serialise in L2.  Here
+// the lanes that target the same counter elect a leader, the leader issues ONE atomic for the
+// group and every lane derives its own rank from the ballot.  Must be called by all 64 lanes.
+template <bool RETURNING>
+__device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t *counters, int key, bool active)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t rank = 0;
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int k = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = active && key == k;
+        const uint64_t same = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == leader) {
+            const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
+            if (RETURNING) base = atomicAdd(&counters[k], cnt);
+            else atomicAdd(&counters[k], cnt);
+        }
+        if (RETURNING) {
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+            if (mine) rank = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return rank;
 }
 
 // a*b + c*d + e*f + g in the documented order ((a*b (+) c*d) (+) e*f) + g, each (+) fused.

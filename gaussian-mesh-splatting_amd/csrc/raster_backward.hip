@@ -14,157 +14,11 @@
 //
 // Gradient conventions: SURVEY.md appendix A.4/A.5 (straight-through alpha clamp, constant
 // skip tests, clamp masks, 1/(det^2+1e-7), NDC-scaled mean2D gradient).
+#include "gms_blend.h"
 #include "gms_common.h"
 #include "gms_project.h"
 
 namespace gms {
-
-struct BlendBwdArgs {
-    int W, H, gx, gy;
-    const uint32_t *tile_offset;
-    const uint64_t *keys;
-    const SplatRec *rec;
-    const float *bg;
-    const float *final_T;
-    const uint32_t *n_contrib;
-    const float *dL_dpix;       // [3,H,W]
-    const float *dL_dinvd;      // [H,W] or NULL
-    float *dL_dmean2D;          // [P,3]
-    float *dL_dconic;           // [P,4]
-    float *dL_dopacity;         // [P]
-    float *dL_dcolors;          // [P,3]
-    float *dL_dinvdepths;       // [P]
-};
-
-__device__ __forceinline__ bool block_to_tile_b(int b, int gx, int gy, int &tx, int &ty)
-{
-    const int xcd = b & 7, s = b >> 3;
-    ty = xcd + 8 * (s / gx);
-    tx = s % gx;
-    return ty < gy;
-}
-
-__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendBwdArgs a)
-{
-    __shared__ SplatRec recs[BLOCK];
-    __shared__ uint32_t ids[BLOCK];
-    __shared__ uint32_t wave_max[4];
-    int tx, ty;
-    if (!block_to_tile_b(blockIdx.x, a.gx, a.gy, tx, ty)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qx = tx * TILE + (wave & 1) * 8, qy = ty * TILE + (wave >> 1) * 8;
-    const int pxi = qx + (lane & 7), pyi = qy + (lane >> 3);
-    const bool inside = pxi < a.W && pyi < a.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const float wx0 = (float)qx, wy0 = (float)qy, wx1 = (float)(qx + 7), wy1 = (float)(qy + 7);
-    const int tile = ty * a.gx + tx;
-    const uint32_t beg = a.tile_offset[tile], end = a.tile_offset[tile + 1];
-    if (end <= beg) return;
-
-    const size_t HW = (size_t)a.W * a.H;
-    const size_t pid = (size_t)pyi * a.W + pxi;
-    const float Tfinal = inside ? a.final_T[pid] : 0.f;
-    float T = Tfinal;
-    const uint32_t last = inside ? a.n_contrib[pid] : 0u;
-    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
-    if (inside) {
-        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
-        if (a.dL_dinvd) dinvd = a.dL_dinvd[pid];
-    }
-    const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lastd = 0.f;
-    const float halfW = 0.5f * a.W, halfH = 0.5f * a.H;
-
-    // the tile only needs the prefix of its segment that some pixel actually composited
-    uint32_t m = last;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) wave_max[wave] = m;
-    __syncthreads();
-    const uint32_t total = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
-
-    for (uint32_t hi = total; hi > 0; hi = hi > BLOCK ? hi - BLOCK : 0) {
-        const int cnt = (int)min((uint32_t)BLOCK, hi);
-        __syncthreads();                              // previous queue fully consumed
-        if (tid < cnt) {
-            const uint32_t e = hi - 1 - tid;          // queue slot 0 = backmost entry
-            const uint32_t id = (uint32_t)a.keys[beg + e];
-            ids[tid] = id;
-            recs[tid] = a.rec[id];
-        }
-        __syncthreads();
-        if (m == 0) continue;                         // wave-uniform: quadrant composited nothing
-        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
-            const int j = chunk + lane;
-            bool hit = false;
-            if (j < cnt) {
-                const float4 q0 = recs[j].q0;
-                const float4 q2 = recs[j].q2;
-                hit = !(q0.x + q2.z < wx0 || q0.x - q2.z > wx1 || q0.y + q2.w < wy0 || q0.y - q2.w > wy1);
-            }
-            uint64_t mask = __ballot(hit);
-            while (mask) {
-                const int bit = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int k = chunk + bit;
-                const uint32_t pos0 = hi - 1 - (uint32_t)k;          // 0-based position in the tile segment
-                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
-                const float dx = r0.x - pxf, dy = r0.y - pyf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, r1.y * G);
-                const bool act = pos0 < last && power <= 0.f && alpha >= ALPHA_MIN;
-                if (!__any(act)) continue;
-                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
-                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_id = 0.f;
-                if (act) {
-                    T = T / (1.f - alpha);
-                    const float w = alpha * T;
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    accd = last_alpha * lastd + (1.f - last_alpha) * accd;
-                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x; lastd = r2.y;
-                    float dL_dalpha = (r1.z - acc0) * dp0 + (r1.w - acc1) * dp1 + (r2.x - acc2) * dp2 +
-                                      (r2.y - accd) * dinvd;
-                    g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_id = w * dinvd;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-Tfinal / (1.f - alpha)) * bgdot;
-                    const float dL_dG = r1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
-                    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
-                    g_mx = dL_dG * dG_ddx * halfW;
-                    g_my = dL_dG * dG_ddy * halfH;
-                    g_ca = -0.5f * gdx * dx * dL_dG;
-                    g_cb = -0.5f * gdx * dy * dL_dG;
-                    g_cc = -0.5f * gdy * dy * dL_dG;
-                    g_op = G * dL_dalpha;
-                }
-                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-                g_op = wave_sum_to_lane63(g_op);
-                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-                g_id = wave_sum_to_lane63(g_id);
-                if (lane == 63) {
-                    const size_t id = ids[k];
-                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id, g_mx);
-                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id + 1, g_my);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id, g_ca);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 1, g_cb);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 3, g_cc);
-                    unsafeAtomicAdd(a.dL_dopacity + id, g_op);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id, g_r);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 1, g_g);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 2, g_b);
-                    if (a.dL_dinvd) unsafeAtomicAdd(a.dL_dinvdepths + id, g_id);
-                }
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------ K8 + K9
 constexpr int SH_PITCH_B = 52;
@@ -434,17 +288,25 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
     GeomState geom = GeomState::carve(const_cast<void *>(A->geom_buffer), (size_t)P);
     ImageState img = ImageState::carve(const_cast<void *>(A->image_buffer), (size_t)W, (size_t)H);
-    BinningState bin = BinningState::carve(const_cast<void *>(A->binning_buffer), (size_t)A->num_rendered);
+    const int T = gx * gy;
+    const uint32_t L = seg_len();
+    const uint64_t cap = (uint64_t)(A->binning_capacity > 0 ? A->binning_capacity : (A->num_rendered > 0 ? A->num_rendered : 1));
+    BinningState bin = BinningState::carve(const_cast<void *>(A->binning_buffer), (size_t)cap, (size_t)T, L);
 
     if (A->num_rendered > 0) {
+        BlendGrid g;
+        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
+        g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
+        g.seg_state = bin.seg_state; g.capacity = cap;
+        g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
         BlendBwdArgs b;
-        b.W = W; b.H = H; b.gx = gx; b.gy = gy; b.tile_offset = img.tile_offset; b.keys = bin.keys; b.rec = geom.rec;
-        b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib; b.dL_dpix = A->dL_dout_color;
-        b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D; b.dL_dconic = A->dL_dconic;
-        b.dL_dopacity = A->dL_dopacity; b.dL_dcolors = A->dL_dcolors; b.dL_dinvdepths = A->dL_dinvdepths;
-        const unsigned bblocks = 8u * (unsigned)gx * (unsigned)((gy + 7) / 8);
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<bblocks, BLOCK, 0, stream>>>(b));
-        GMS_KERNEL_CHECK(A->debug, stream, "blend_bwd");
+        b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
+        b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D;
+        b.dL_dconic = A->dL_dconic; b.dL_dopacity = A->dL_dopacity; b.dL_dcolors = A->dL_dcolors;
+        b.dL_dinvdepths = A->dL_dinvdepths;
+        const uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
+        int32_t rc = launch_blend_backward(g, b, mu, A->debug != 0, stream);
+        if (rc != GMS_OK) return rc;
     }
     PreBwdArgs p;
     p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;

@@ -23,6 +23,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <stdlib.h>
+
+#include "gms_blend.h"
 #include "gms_common.h"
 #include "gms_project.h"
 
@@ -171,54 +174,87 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         rgb[0] = a.colors[3 * (size_t)i]; rgb[1] = a.colors[3 * (size_t)i + 1]; rgb[2] = a.colors[3 * (size_t)i + 2];
     }
 
-    if (!valid) return;
-    if (!vis) { a.radii[i] = 0; return; }
-
-    // half extents of the bounding box of {alpha >= 1/255}: |dx| <= sqrt(2 * cov_xx * ln(255 op)).
-    // ln is inflated by 1e-3 so float rounding can never cull a pair the per-pixel test would keep.
-    float tau = __logf(255.f * opp);
-    float ex, ey;
-    if (tau < -1e-3f) { ex = -1e30f; ey = -1e30f; }
-    else { ex = sqrtf(2.f * a_d * (tau + 1e-3f)); ey = sqrtf(2.f * c_d * (tau + 1e-3f)); }
-
-    SplatRec rec;
-    rec.q0 = make_float4(pix, piy, cA, cB);
-    rec.q1 = make_float4(cC, opp, rgb[0], rgb[1]);
-    rec.q2 = make_float4(rgb[2], 1.f / vz, ex, ey);
-    a.geom.rec[i] = rec;
-    a.geom.depth[i] = vz;
-    a.geom.clamped[i] = (uint8_t)clampbits;
-    a.radii[i] = (int)rad;
-    for (int ty = miny; ty < maxy; ty++)
-        for (int tx = minx; tx < maxx; tx++) atomicAdd(&a.tile_count[ty * a.gx + tx], 1u);
+    if (valid && !vis) a.radii[i] = 0;
+    if (vis) {
+        // half extents of the bounding box of {alpha >= 1/255}: |dx| <= sqrt(2 * cov_xx * ln(255 op)).
+        // ln is inflated by 1e-3 so float rounding can never cull a pair the per-pixel test would keep.
+        float tau = __logf(255.f * opp);
+        float ex, ey;
+        if (tau < -1e-3f) { ex = -1e30f; ey = -1e30f; }
+        else { ex = sqrtf(2.f * a_d * (tau + 1e-3f)); ey = sqrtf(2.f * c_d * (tau + 1e-3f)); }
+        SplatRec rec;
+        rec.q0 = make_float4(pix, piy, cA, cB);
+        rec.q1 = make_float4(cC, opp, rgb[0], rgb[1]);
+        rec.q2 = make_float4(rgb[2], 1.f / vz, ex, ey);
+        a.geom.rec[i] = rec;
+        a.geom.depth[i] = vz;
+        a.geom.clamped[i] = (uint8_t)clampbits;
+        a.radii[i] = (int)rad;
+    }
+    // tile coverage counts: all 64 lanes walk their rectangles in lock-step, one aggregated atomic
+    // per distinct tile per step
+    const int rw = maxx - minx;
+    const int area = vis ? rw * (maxy - miny) : 0;
+    int cx = minx, cy = miny;
+    for (int k = 0; __any(k < area); k++) {
+        const bool act = k < area;
+        wave_aggregated_inc<false>(a.tile_count, act ? cy * a.gx + cx : -1, act);
+        if (++cx == maxx) { cx = minx; cy++; }
+    }
 }
 
 // ------------------------------------------------------------------------------------ K2
-// Exclusive scan over the tile counts by one block; offset[T] = N.  Also resets the cursors.
+// One block: exclusive scans over the tiles of (a) instance counts -> tile_offset (offset[T] = N),
+// (b) segments per tile -> unit_first, (c) segments of multi-segment tiles -> mseg_first (slots of
+// the per-unit pixel state).  Also resets the emit cursors.
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t *part, int tid, uint32_t &total)
+{
+    __syncthreads();
+    part[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < BLOCK; d <<= 1) {
+        uint32_t x = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    total = part[BLOCK - 1];
+    return part[tid] - v;
+}
+
 __global__ void __launch_bounds__(BLOCK) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
-                                                          int T)
+                                                          uint32_t *unit_first, uint32_t *mseg_first, int T, uint32_t L)
 {
     __shared__ uint32_t part[BLOCK];
     const int tid = threadIdx.x;
     const int per = (T + BLOCK - 1) / BLOCK;
     const int b = tid * per, e = min(T, b + per);
-    uint32_t s = 0;
-    for (int t = b; t < e; t++) s += count[t];
-    part[tid] = s;
-    __syncthreads();
-    for (int d = 1; d < BLOCK; d <<= 1) {
-        uint32_t v = tid >= d ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - s;   // exclusive prefix of this thread's chunk
+    uint32_t s0 = 0, s1 = 0, s2 = 0;
     for (int t = b; t < e; t++) {
-        offset[t] = run;
-        cursor[t] = 0;
-        run += count[t];
+        const uint32_t c = count[t], ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
+        s0 += c; s1 += ns; s2 += ns > 1 ? ns : 0;
     }
-    if (tid == BLOCK - 1) offset[T] = part[BLOCK - 1];
+    uint32_t tot0, tot1, tot2;
+    uint32_t r0 = block_exclusive(s0, part, tid, tot0);
+    uint32_t r1 = block_exclusive(s1, part, tid, tot1);
+    uint32_t r2 = block_exclusive(s2, part, tid, tot2);
+    for (int t = b; t < e; t++) {
+        const uint32_t c = count[t], ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
+        offset[t] = r0; unit_first[t] = r1; mseg_first[t] = r2;
+        cursor[t] = 0;
+        r0 += c; r1 += ns; r2 += ns > 1 ? ns : 0;
+    }
+    if (tid == 0) { offset[T] = tot0; unit_first[T] = tot1; mseg_first[T] = tot2; }
+}
+
+// unit table: unit_tile[unit_first[t] + s] = t
+__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *unit_first, uint32_t *unit_tile, int T,
+                                                           uint32_t max_units)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t b = unit_first[t], e = unit_first[t + 1];
+    for (uint32_t u = b; u < e && u < max_units; u++) unit_tile[u] = (uint32_t)t;
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -227,19 +263,26 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
                                                                uint64_t *keys, uint64_t capacity)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= P) return;
-    const int r = radii[i];
-    if (r <= 0) return;
-    const float4 q0 = geom.rec[i].q0;
-    int minx, miny, maxx, maxy;
-    tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
-    const uint64_t key = ((uint64_t)__float_as_uint(geom.depth[i]) << 32) | (uint32_t)i;
-    for (int ty = miny; ty < maxy; ty++)
-        for (int tx = minx; tx < maxx; tx++) {
-            const int t = ty * gx + tx;
-            const uint64_t slot = (uint64_t)tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
+    const int r = i < P ? radii[i] : 0;
+    int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    uint64_t key = 0;
+    if (r > 0) {
+        const float4 q0 = geom.rec[i].q0;
+        tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
+        key = ((uint64_t)__float_as_uint(geom.depth[i]) << 32) | (uint32_t)i;
+    }
+    const int area = r > 0 ? (maxx - minx) * (maxy - miny) : 0;
+    int cx = minx, cy = miny;
+    for (int k = 0; __any(k < area); k++) {
+        const bool act = k < area;
+        const int t = act ? cy * gx + cx : -1;
+        const uint32_t rank = wave_aggregated_inc<true>(tile_cursor, t, act);
+        if (act) {
+            const uint64_t slot = (uint64_t)tile_offset[t] + rank;
             if (slot < capacity) keys[slot] = key;
         }
+        if (++cx == maxx) { cx = minx; cy++; }
+    }
 }
 
 // ------------------------------------------------------------------------------------ K4
@@ -341,102 +384,6 @@ __global__ void __launch_bounds__(BLOCK) tile_sort_kernel(const uint32_t *tile_o
     }
 }
 
-// ------------------------------------------------------------------------------------ K6
-struct BlendFwdArgs {
-    int W, H, gx, gy;
-    const uint32_t *tile_offset;
-    const uint64_t *keys;
-    const SplatRec *rec;
-    const float *bg;
-    float *final_T;
-    uint32_t *n_contrib;
-    float *out_color;
-    float *out_invdepth;
-    uint64_t capacity;
-};
-
-// Block -> tile map: the dispatcher places block b on XCD b % 8 (observed, speed only).  Tile
-// rows are dealt round-robin to XCDs so that horizontally adjacent tiles (which share splats)
-// hit the same L2 while the heavy image centre is spread over all eight XCDs.
-__device__ __forceinline__ bool block_to_tile(int b, int gx, int gy, int &tx, int &ty)
-{
-    const int xcd = b & 7, s = b >> 3;
-    ty = xcd + 8 * (s / gx);
-    tx = s % gx;
-    return ty < gy;
-}
-
-__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendFwdArgs a)
-{
-    __shared__ SplatRec recs[BLOCK];
-    int tx, ty;
-    if (!block_to_tile(blockIdx.x, a.gx, a.gy, tx, ty)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qx = tx * TILE + (wave & 1) * 8, qy = ty * TILE + (wave >> 1) * 8;   // quadrant origin
-    const int pxi = qx + (lane & 7), pyi = qy + (lane >> 3);
-    const bool inside = pxi < a.W && pyi < a.H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
-    const float wx0 = (float)qx, wy0 = (float)qy, wx1 = (float)(qx + 7), wy1 = (float)(qy + 7);
-    const int tile = ty * a.gx + tx;
-    uint32_t beg = a.tile_offset[tile], end = a.tile_offset[tile + 1];
-    if ((uint64_t)end > a.capacity) end = beg;     // overflowed launch (host re-runs it)
-
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    bool done = !inside;
-
-    for (uint32_t base = beg; base < end; base += BLOCK) {
-        if (__syncthreads_and(done)) break;
-        const uint32_t idx = base + tid;
-        if (idx < end) {
-            const uint32_t id = (uint32_t)a.keys[idx];
-            recs[tid] = a.rec[id];
-        }
-        __syncthreads();
-        const int cnt = min((uint32_t)BLOCK, end - base);
-        if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
-        for (int chunk = 0; chunk < cnt; chunk += WAVE) {
-            const int j = chunk + lane;
-            bool hit = false;
-            if (j < cnt) {
-                const float4 q0 = recs[j].q0;
-                const float4 q2 = recs[j].q2;
-                hit = !(q0.x + q2.z < wx0 || q0.x - q2.z > wx1 || q0.y + q2.w < wy0 || q0.y - q2.w > wy1);
-            }
-            uint64_t mask = __ballot(hit);
-            while (mask) {
-                const int bit = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const int k = chunk + bit;         // wave-uniform queue slot
-                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
-                const float dx = r0.x - pxf, dy = r0.y - pyf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
-                bool act = !done && power <= 0.f && alpha >= ALPHA_MIN;
-                const float testT = T * (1.f - alpha);
-                if (act && testT < T_MIN) { done = true; act = false; }
-                if (act) {
-                    const float w = alpha * T;
-                    C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
-                    Dp += r2.y * w;
-                    T = testT;
-                    last = (base - beg) + (uint32_t)k + 1u;
-                }
-                if (__all(done)) break;
-            }
-        }
-    }
-    if (inside) {
-        const size_t pid = (size_t)pyi * a.W + pxi, HW = (size_t)a.W * a.H;
-        a.final_T[pid] = T;
-        a.n_contrib[pid] = last;
-        a.out_color[pid] = C0 + T * a.bg[0];
-        a.out_color[HW + pid] = C1 + T * a.bg[1];
-        a.out_color[2 * HW + pid] = C2 + T * a.bg[2];
-        a.out_invdepth[pid] = Dp;
-    }
-}
-
 __global__ void fill_background_kernel(int W, int H, const float *bg, float *out_color, float *out_invdepth)
 {
     const size_t HW = (size_t)W * H;
@@ -465,6 +412,18 @@ static int32_t *pinned_slot()
     return slot;
 }
 
+uint32_t seg_len()
+{
+    static uint32_t L = 0;
+    if (L == 0) {
+        uint32_t v = 256;
+        if (const char *e = getenv("GMS_SEG_LEN")) v = (uint32_t)atoi(e);
+        if (v < 256) v = 256;
+        L = (v + 255u) / 256u * 256u;
+    }
+    return L;
+}
+
 }  // namespace gms
 
 using namespace gms;
@@ -473,7 +432,11 @@ extern "C" int32_t gms_abi_version(void) { return GMS_ABI_VERSION; }
 extern "C" const char *gms_last_error(void) { return gms::g_err; }
 extern "C" size_t gms_geom_bytes(int32_t P) { return GeomState::bytes((size_t)(P > 0 ? P : 1)); }
 extern "C" size_t gms_image_bytes(int32_t w, int32_t h) { return ImageState::bytes((size_t)w, (size_t)h); }
-extern "C" size_t gms_binning_bytes(int64_t n) { return BinningState::bytes((size_t)(n > 0 ? n : 0)); }
+extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
+{
+    const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
+    return BinningState::bytes((size_t)(n > 0 ? n : 0), T, seg_len());
+}
 
 extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *stream_)
 {
@@ -531,37 +494,41 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
     GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<<<pblocks, BLOCK, 0, stream>>>(pa));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
-    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor, T));
+    const uint32_t L = seg_len();
+    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
+                                                                                   img.unit_first, img.mseg_first, T, L));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
     int32_t *slot = pinned_slot();
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
     GMS_HIP_CHECK(hipMemcpyAsync(slot, img.tile_offset + T, 4, hipMemcpyDeviceToHost, stream));
 
-    BlendFwdArgs ba;
-    ba.W = W; ba.H = H; ba.gx = gx; ba.gy = gy; ba.tile_offset = img.tile_offset; ba.rec = geom.rec;
-    ba.bg = A->background; ba.final_T = img.final_T; ba.n_contrib = img.n_contrib; ba.out_color = A->out_color;
-    ba.out_invdepth = A->out_invdepth;
-    const unsigned bblocks = 8u * (unsigned)gx * (unsigned)((gy + 7) / 8);
+    BlendFwdOut bo;
+    bo.rec = geom.rec; bo.bg = A->background; bo.final_T = img.final_T; bo.n_contrib = img.n_contrib;
+    bo.out_color = A->out_color; bo.out_invdepth = A->out_invdepth;
 
     auto enqueue_tail = [&](void *bin_mem, uint64_t capacity) -> int32_t {
-        BinningState bin = BinningState::carve(bin_mem, (size_t)capacity);
+        BinningState bin = BinningState::carve(bin_mem, (size_t)capacity, (size_t)T, L);
+        const uint32_t mu = (uint32_t)BinningState::n_units((size_t)capacity, (size_t)T, L);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                              img.tile_cursor, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
+        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.unit_first, bin.unit_tile, T, mu);
+        GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_sort_kernel<<<(unsigned)T, BLOCK, 0, stream>>>(img.tile_offset, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
-        ba.keys = bin.keys; ba.capacity = capacity;
-        GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<bblocks, BLOCK, 0, stream>>>(ba));
-        GMS_KERNEL_CHECK(A->debug, stream, "blend_fwd");
-        return GMS_OK;
+        BlendGrid g;
+        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
+        g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
+        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu;
+        return launch_blend_forward(g, bo, mu, A->debug != 0, stream);
     };
 
     int64_t N;
     if (A->binning_capacity_hint > 0) {
         // optimistic path: enqueue the whole tail before looking at N (no pipeline bubble)
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
-        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap));
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
         hipEvent_t ev;
         GMS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -572,7 +539,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         (void)hipEventDestroy(ev);
         N = (int64_t)(uint32_t)*slot;
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
-            bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N));
+            bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
             GMS_HIP_CHECK(hipMemsetAsync(img.tile_cursor, 0, (size_t)T * 4, stream));
             rc = enqueue_tail(bin_mem, (uint64_t)N);
@@ -581,9 +548,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     } else {
         GMS_HIP_CHECK(hipStreamSynchronize(stream));
         N = (int64_t)(uint32_t)*slot;
-        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N));
+        const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
-        int32_t rc = enqueue_tail(bin_mem, (uint64_t)(N > 0 ? N : 1));
+        int32_t rc = enqueue_tail(bin_mem, cap);
         if (rc != GMS_OK) return rc;
     }
     return N;

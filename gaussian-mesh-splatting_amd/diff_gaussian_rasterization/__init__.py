@@ -155,6 +155,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)
+        ctx.binning_capacity = hint if (hint > 0 and num_rendered <= hint) else max(int(num_rendered), 1)
         ctx.M = M
         empty = torch.empty(0, device=device)
         ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
@@ -194,6 +195,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         a = _lib.RasterBackwardArgs(
             P=P, D=int(rs.sh_degree), M=M, width=W, height=H, num_rendered=ctx.num_rendered,
+            binning_capacity=ctx.binning_capacity,
             background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh), colors_precomp=_lib.ptr(colors_precomp),
             opacities=_lib.ptr(opacities), scales=_lib.ptr(scales), rotations=_lib.ptr(rotations),
             cov3D_precomp=_lib.ptr(cov3Ds_precomp), viewmatrix=_lib.ptr(view), projmatrix=_lib.ptr(proj),

@@ -39,7 +39,7 @@ class RasterForwardArgs(C.Structure):
 class RasterBackwardArgs(C.Structure):
     _fields_ = [
         ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
-        ("num_rendered", C.c_int64),
+        ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64),
         ("background", C.c_void_p),
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
@@ -68,7 +68,7 @@ EXPORTS = (
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
 )
-K_COUNT = 10
+K_COUNT = 12
 
 _lock = threading.Lock()
 _lib = None
@@ -104,7 +104,7 @@ def load():
             getattr(lib, n).restype = C.c_size_t
         lib.gms_geom_bytes.argtypes = [C.c_int32]
         lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
-        lib.gms_binning_bytes.argtypes = [C.c_int64]
+        lib.gms_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.gms_profile_enable.argtypes = [C.c_int32]
         lib.gms_profile_enable.restype = None
         lib.gms_profile_reset.restype = None

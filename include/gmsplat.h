@@ -101,6 +101,9 @@ int64_t gms_rasterize_forward(const GmsRasterForwardArgs *args, void *stream);
 typedef struct GmsRasterBackwardArgs {
     int32_t P, D, M, width, height;
     int64_t num_rendered;             /* value returned by the forward call */
+    int64_t binning_capacity;         /* instance capacity the forward's binning buffer was laid out for:
+                                         the capacity hint when one was given and was sufficient, else
+                                         max(num_rendered, 1) */
     const float *background;
     const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *viewmatrix, *projmatrix, *campos;
@@ -178,7 +181,9 @@ int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *args, const float *dL_
 #define GMS_K_MESH_FWD 7
 #define GMS_K_MESH_BWD_SPLAT 8
 #define GMS_K_MESH_BWD_FACE 9
-#define GMS_K_COUNT 10
+#define GMS_K_BLEND_TLOC 10
+#define GMS_K_BLEND_FINALIZE 11
+#define GMS_K_COUNT 12
 void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);
@@ -191,7 +196,7 @@ const char *gms_last_error(void);
 /* Byte sizes of the scratch buffers for given problem sizes (what the callbacks will be asked for). */
 size_t gms_geom_bytes(int32_t P);
 size_t gms_image_bytes(int32_t width, int32_t height);
-size_t gms_binning_bytes(int64_t num_instances);
+size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
 #ifdef __cplusplus
 }

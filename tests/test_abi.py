@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert loaded.gms_abi_version() == _lib.GMS_ABI_VERSION
     assert loaded.gms_geom_bytes(1000) >= 1000 * 53
     assert loaded.gms_image_bytes(800, 800) >= 800 * 800 * 8
-    assert loaded.gms_binning_bytes(1000) >= 8000
+    assert loaded.gms_binning_bytes(1000, 800, 800) >= 8000
     assert loaded.gms_profile_kernel_name(5) == b"blend_bwd"
 
 
