@@ -34,15 +34,18 @@ struct Unit {
     uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
 };
 
-// Block -> unit.  The dispatcher places block b on XCD b % 8 (observed; speed only): give each XCD
-// a contiguous run of units (= band of neighbouring tiles, which gather the same splat records).
+// Block -> unit.  The dispatcher places block b on XCD b % 8 (observed; speed only).  Units are dealt
+// to the XCDs in runs of UNIT_RUN consecutive units: a run is a stretch of neighbouring tiles that
+// gather the same splat records (L2 locality), while successive runs rotate over the eight XCDs so the
+// heavy image centre and the empty border are spread over all of them (units are far from equal work).
+constexpr uint32_t UNIT_RUN = 16;
+
 __device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
 {
     const uint32_t nunits = g.unit_first[g.T];
-    const uint32_t chunk = (nunits + 7u) >> 3;
-    const uint32_t s = blockIdx.x >> 3;
-    const uint32_t idx = (blockIdx.x & 7u) * chunk + s;
-    if (s >= chunk || idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
+    const uint32_t s = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t idx = ((s / UNIT_RUN) * 8u + xcd) * UNIT_RUN + (s % UNIT_RUN);
+    if (idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
     u.tile = (int)g.unit_tile[idx];
     const uint32_t first = g.unit_first[u.tile];
     u.seg = (int)(idx - first);
@@ -260,6 +263,22 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lastd = 0.f;
     const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;
 
+    // lane-constant atomic targets matching wave_reduce10's output layout
+    float *abase0; size_t astride0;
+    switch (lane >> 3) {
+    case 0: abase0 = a.dL_dmean2D; astride0 = 3; break;          // v0 = mean2D.x
+    case 1: abase0 = a.dL_dconic + 3; astride0 = 4; break;       // v4 = conic C
+    case 2: abase0 = a.dL_dconic; astride0 = 4; break;           // v2 = conic A
+    case 3: abase0 = a.dL_dcolors; astride0 = 3; break;          // v6 = r
+    case 4: abase0 = a.dL_dmean2D + 1; astride0 = 3; break;      // v1 = mean2D.y
+    case 5: abase0 = a.dL_dopacity; astride0 = 1; break;         // v5 = opacity
+    case 6: abase0 = a.dL_dconic + 1; astride0 = 4; break;       // v3 = conic B
+    default: abase0 = a.dL_dcolors + 1; astride0 = 3; break;     // v7 = g
+    }
+    float *abase1 = lane == 0 ? a.dL_dcolors + 2 : a.dL_dinvdepths;   // v8 = b (lane 0), v9 = inverse depth (lane 32)
+    const size_t astride1 = lane == 0 ? 3 : 1;
+    const bool alane1 = lane == 0 || (lane == 32 && a.dL_dinvd != nullptr);
+
     // entries of this unit that some pixel of the tile actually composited: positions [seg_lo, top)
     uint32_t m = min(last, seg_hi);
     m = m > seg_lo ? m : 0u;                       // 0 = this pixel has nothing in this unit
@@ -321,24 +340,11 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                     g_cc = -0.5f * gdy * dy * dL_dG;
                     g_op = G * dL_dalpha;
                 }
-                g_mx = wave_sum_to_lane63(g_mx); g_my = wave_sum_to_lane63(g_my);
-                g_ca = wave_sum_to_lane63(g_ca); g_cb = wave_sum_to_lane63(g_cb); g_cc = wave_sum_to_lane63(g_cc);
-                g_op = wave_sum_to_lane63(g_op);
-                g_r = wave_sum_to_lane63(g_r); g_g = wave_sum_to_lane63(g_g); g_b = wave_sum_to_lane63(g_b);
-                g_id = wave_sum_to_lane63(g_id);
-                if (lane == 63) {
-                    const size_t id = ids[k];
-                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id, g_mx);
-                    unsafeAtomicAdd(a.dL_dmean2D + 3 * id + 1, g_my);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id, g_ca);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 1, g_cb);
-                    unsafeAtomicAdd(a.dL_dconic + 4 * id + 3, g_cc);
-                    unsafeAtomicAdd(a.dL_dopacity + id, g_op);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id, g_r);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 1, g_g);
-                    unsafeAtomicAdd(a.dL_dcolors + 3 * id + 2, g_b);
-                    if (a.dL_dinvd) unsafeAtomicAdd(a.dL_dinvdepths + id, g_id);
-                }
+                float y0, y1;
+                wave_reduce10(g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g, g_b, g_id, y0, y1);
+                const size_t id = ids[k];
+                if ((lane & 7) == 0) unsafeAtomicAdd(abase0 + id * astride0, y0);       // 8 lanes, 8 different targets
+                if (alane1) unsafeAtomicAdd(abase1 + id * astride1, y1);
             }
         }
     }
@@ -347,7 +353,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
 // ------------------------------------------------------------------------------------ host
 int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    const unsigned blocks = 8u * ((max_units + 7u) / 8u);
+    const unsigned blocks = 8u * UNIT_RUN * ((max_units + 8u * UNIT_RUN - 1u) / (8u * UNIT_RUN));
     GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
     GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
     GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, o));
@@ -359,7 +365,7 @@ int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
 
 int32_t launch_blend_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    const unsigned blocks = 8u * ((max_units + 7u) / 8u);
+    const unsigned blocks = 8u * UNIT_RUN * ((max_units + 8u * UNIT_RUN - 1u) / (8u * UNIT_RUN));
     GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, a));
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
     return GMS_OK;

@@ -129,6 +129,45 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     return v;
 }
 
+// gfx950 lane-swap instructions (the clang builtins mis-model the second result in ROCm 7.2, so
+// they are issued as inline asm; `s_nop 1` covers the VALU-write -> permlane-swap-read hazard that
+// hipcc does not track for asm operands).  All 64 lanes must be active.
+//   swap32(a, b): a <- [a.lo32lanes, b.lo32lanes],  b <- [a.hi32lanes, b.hi32lanes]
+//   swap16(a, b): rows (16 lanes) a=(r0,r1,r2,r3), b=(s0,s1,s2,s3) -> a=(r0,s0,r2,s2), b=(r1,s1,r3,s3)
+__device__ __forceinline__ void swap32(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float &a, float &b)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// Transposing wave reduction of ten values: every stage adds partner lanes AND halves the number
+// of live registers (the two halves / rows / half-rows end up holding different values), ~26 VALU
+// instead of 80 for ten independent butterflies.  Result layout:
+//   y0, lane group (lane>>3) = 0..7 holds the wave total of v0, v4, v2, v6, v1, v5, v3, v7
+//   y1, lanes 0..15 hold the total of v8, lanes 32..47 the total of v9
+__device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                              float v7, float v8, float v9, float &y0, float &y1)
+{
+    swap32(v0, v1); float w0 = v0 + v1;
+    swap32(v2, v3); float w1 = v2 + v3;
+    swap32(v4, v5); float w2 = v4 + v5;
+    swap32(v6, v7); float w3 = v6 + v7;
+    swap32(v8, v9); float w4 = v8 + v9;
+    swap16(w0, w1); float x0 = w0 + w1;          // rows (v0, v2, v1, v3)
+    swap16(w2, w3); float x1 = w2 + w3;          // rows (v4, v6, v5, v7)
+    float z = 0.f;
+    swap16(w4, z);  float x2 = w4 + z;           // rows (v8, 0, v9, 0)
+    const float a = dpp_add<0x128>(x0);          // row_ror:8 : lane l += lane l^8 (within the row)
+    const float b = dpp_add<0x128>(x1);
+    y0 = (threadIdx.x & 8) ? b : a;
+    y1 = dpp_add<0x128>(x2);
+    y0 = dpp_add<0x141>(y0); y0 = dpp_add<0xB1>(y0); y0 = dpp_add<0x4E>(y0);   // sum the 8 lanes of each group
+    y1 = dpp_add<0x141>(y1); y1 = dpp_add<0xB1>(y1); y1 = dpp_add<0x4E>(y1);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // Tile rectangle of a splat: identical code in preprocess (count) and emit, so both agree.

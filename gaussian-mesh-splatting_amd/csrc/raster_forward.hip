@@ -286,98 +286,116 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
 }
 
 // ------------------------------------------------------------------------------------ K4
-constexpr int SORT_CHUNK = 4096;   // keys resident in LDS (32 KiB)
-
+// Per-tile sort of (depth bits << 32 | id) keys: an all-ascending bitonic network (mirror step +
+// half-cleaners), so virtual +inf padding works for any length.  Compare-exchange index i always
+// touches the 128-key block i/64, and thread t owns indices t, t+THREADS, ...: every sub-stage
+// whose span is <= 128 keys stays inside one wave's blocks and needs only wave-level ordering
+// (LDS operations of a wave execute in order) -- block barriers are paid only for the wide
+// sub-stages (6 instead of 55 for 1024 keys).
 __device__ __forceinline__ void ce(uint64_t &x, uint64_t &y)
 {
     if (x > y) { uint64_t t = x; x = y; y = t; }
 }
 
-// all-ascending bitonic network on m (power of two, <= SORT_CHUNK) keys in LDS.
-// first_k: smallest merge size to run (2 = full sort); mirror_first: run the mirror step of merge
-// size k (false when the caller already did the wide strides in global memory).
-__device__ void lds_sort(uint64_t *s, int m, int tid)
+__device__ __forceinline__ void wave_sync()
 {
-    for (int k = 2; k <= m; k <<= 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int WAVE_SPAN = 128;   // keys covered by one wave's 64 compare-exchanges
+
+template <int THREADS>
+__device__ __forceinline__ void stage_sync(int span, int &prev_span)
+{
+    if (span > WAVE_SPAN || prev_span > WAVE_SPAN) __syncthreads();
+    else wave_sync();
+    prev_span = span;
+}
+
+// sort m (power of two) keys in LDS: merges k = k0 .. m; with mirror=false the mirror step of the
+// first merge is skipped (the caller did it and the wide strides in global memory).
+template <int THREADS>
+__device__ void lds_bitonic(uint64_t *s, int m, int k0, int j0, bool first_mirror, int tid)
+{
+    int prev = 1 << 30;
+    for (int k = k0; k <= m; k <<= 1) {
         const int hk = k >> 1;
-        for (int i = tid; i < (m >> 1); i += BLOCK) {
-            int blk = i / hk, off = i - blk * hk;
-            int lo = blk * k + off, hi = blk * k + k - 1 - off;
-            ce(s[lo], s[hi]);
+        if (k > k0 || first_mirror) {
+            stage_sync<THREADS>(k, prev);
+            for (int i = tid; i < (m >> 1); i += THREADS) {
+                int blk = i / hk, off = i - blk * hk;
+                int lo = blk * k + off, hi = blk * k + k - 1 - off;
+                ce(s[lo], s[hi]);
+            }
         }
-        __syncthreads();
-        for (int j = k >> 2; j >= 1; j >>= 1) {
-            for (int i = tid; i < (m >> 1); i += BLOCK) {
+        for (int j = (k > k0 || first_mirror) ? (k >> 2) : j0; j >= 1; j >>= 1) {
+            stage_sync<THREADS>(2 * j, prev);
+            for (int i = tid; i < (m >> 1); i += THREADS) {
                 int lo = 2 * j * (i / j) + (i % j);
                 ce(s[lo], s[lo + j]);
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
 }
 
-// half-cleaner strides from j0 down to 1 inside one LDS-resident chunk of m keys
-__device__ void lds_clean(uint64_t *s, int m, int j0, int tid)
-{
-    for (int j = j0; j >= 1; j >>= 1) {
-        for (int i = tid; i < (m >> 1); i += BLOCK) {
-            int lo = 2 * j * (i / j) + (i % j);
-            ce(s[lo], s[lo + j]);
-        }
-        __syncthreads();
-    }
-}
+// CLASS 0: tiles with n <= SMALL_MAX (256 threads, 16 KiB LDS); CLASS 1: larger tiles (1024 threads,
+// 64 KiB LDS, global-memory merge steps beyond 8192 keys).  Both kernels are launched over all
+// tiles; a block returns at once when its tile belongs to the other class.
+constexpr int SORT_SMALL_MAX = 2048;
+constexpr int SORT_BIG_CHUNK = 8192;
 
-__global__ void __launch_bounds__(BLOCK) tile_sort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+template <int THREADS, int CHUNK, bool BIG>
+__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
 {
-    __shared__ uint64_t s[SORT_CHUNK];
+    __shared__ uint64_t s[CHUNK];
     const int tid = threadIdx.x;
     const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
     if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
     const long n = (long)(end64 - beg);
     if (n <= 1) return;
+    if (BIG ? (n <= SORT_SMALL_MAX) : (n > SORT_SMALL_MAX)) return;
     uint64_t *g = keys + beg;
     long np2 = 2;
     while (np2 < n) np2 <<= 1;
     const uint64_t INF = ~0ull;
 
-    if (np2 <= SORT_CHUNK) {
+    if (np2 <= CHUNK) {
         const int m = (int)np2;
-        for (int i = tid; i < m; i += BLOCK) s[i] = i < n ? g[i] : INF;
-        __syncthreads();
-        lds_sort(s, m, tid);
-        for (int i = tid; i < n; i += BLOCK) g[i] = s[i];
+        for (int i = tid; i < m; i += THREADS) s[i] = i < n ? g[i] : INF;
+        lds_bitonic<THREADS>(s, m, 2, 0, true, tid);
+        for (int i = tid; i < n; i += THREADS) g[i] = s[i];
         return;
     }
-    // long segment: sort SORT_CHUNK-sized runs in LDS, then merge with wide strides in global memory
-    for (long c = 0; c < n; c += SORT_CHUNK) {
-        for (int i = tid; i < SORT_CHUNK; i += BLOCK) s[i] = (c + i) < n ? g[c + i] : INF;
-        __syncthreads();
-        lds_sort(s, SORT_CHUNK, tid);
-        for (int i = tid; i < SORT_CHUNK; i += BLOCK)
+    // very long segment: sort CHUNK-sized runs in LDS, then merge with wide strides in global memory
+    for (long c = 0; c < n; c += CHUNK) {
+        for (int i = tid; i < CHUNK; i += THREADS) s[i] = (c + i) < n ? g[c + i] : INF;
+        lds_bitonic<THREADS>(s, CHUNK, 2, 0, true, tid);
+        for (int i = tid; i < CHUNK; i += THREADS)
             if (c + i < n) g[c + i] = s[i];
         __syncthreads();
     }
-    for (long k = 2L * SORT_CHUNK; k <= np2; k <<= 1) {
+    for (long k = 2L * CHUNK; k <= np2; k <<= 1) {
         const long hk = k >> 1;
-        for (long i = tid; i < (np2 >> 1); i += BLOCK) {        // mirror step
+        for (long i = tid; i < (np2 >> 1); i += THREADS) {        // mirror step
             long blk = i / hk, off = i - blk * hk;
             long lo = blk * k + off, hi = blk * k + k - 1 - off;
             if (hi < n) { uint64_t x = g[lo], y = g[hi]; if (x > y) { g[lo] = y; g[hi] = x; } }
         }
         __syncthreads();
-        for (long j = k >> 2; j >= SORT_CHUNK; j >>= 1) {       // strides that cross LDS chunks
-            for (long i = tid; i < (np2 >> 1); i += BLOCK) {
+        for (long j = k >> 2; j >= CHUNK; j >>= 1) {              // strides that cross LDS chunks
+            for (long i = tid; i < (np2 >> 1); i += THREADS) {
                 long lo = 2 * j * (i / j) + (i % j), hi = lo + j;
                 if (hi < n) { uint64_t x = g[lo], y = g[hi]; if (x > y) { g[lo] = y; g[hi] = x; } }
             }
             __syncthreads();
         }
-        for (long c = 0; c < n; c += SORT_CHUNK) {               // remaining strides inside a chunk
-            for (int i = tid; i < SORT_CHUNK; i += BLOCK) s[i] = (c + i) < n ? g[c + i] : INF;
-            __syncthreads();
-            lds_clean(s, SORT_CHUNK, SORT_CHUNK >> 1, tid);
-            for (int i = tid; i < SORT_CHUNK; i += BLOCK)
+        for (long c = 0; c < n; c += CHUNK) {                      // remaining strides inside a chunk
+            for (int i = tid; i < CHUNK; i += THREADS) s[i] = (c + i) < n ? g[c + i] : INF;
+            lds_bitonic<THREADS>(s, CHUNK, CHUNK, CHUNK >> 1, false, tid);
+            for (int i = tid; i < CHUNK; i += THREADS)
                 if (c + i < n) g[c + i] = s[i];
             __syncthreads();
         }
@@ -515,7 +533,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.unit_first, bin.unit_tile, T, mu);
         GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_sort_kernel<<<(unsigned)T, BLOCK, 0, stream>>>(img.tile_offset, bin.keys, capacity));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, (tile_sort_kernel<1024, SORT_BIG_CHUNK, true><<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity)));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, (tile_sort_kernel<256, SORT_SMALL_MAX, false><<<(unsigned)T, 256, 0, stream>>>(img.tile_offset, bin.keys, capacity)));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
