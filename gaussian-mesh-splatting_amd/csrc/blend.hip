@@ -22,6 +22,8 @@
 // Inside a unit the splat records are gathered 256 at a time into an LDS queue; every wave tests
 // 64 queue entries at once against its quadrant (bounding box of the alpha >= 1/255 ellipse --
 // exact: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors.
+#include <stdlib.h>
+
 #include "gms_common.h"
 #include "gms_blend.h"
 
@@ -288,6 +290,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     __syncthreads();
     const uint32_t top = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
     if (top == 0) return;
+    if (g.dbg & 2u) return;                              // experiment: prologue only
 
     for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > BLOCK ? hi - BLOCK : seg_lo) {
         const int cnt = (int)min((uint32_t)BLOCK, hi - seg_lo);
@@ -301,7 +304,9 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
         __syncthreads();
         if (m == 0) continue;                         // wave-uniform: quadrant has nothing in this unit
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
-            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
+            if (g.dbg & 4u) { if (mask == 0x123456789ull) a.dL_dopacity[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
                 const int k = chunk + __builtin_ctzll(mask);
                 mask &= mask - 1;
@@ -316,7 +321,8 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
                 float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_id = 0.f;
                 if (act) {
-                    T = T / (1.f - alpha);
+                    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01
+                    T = T * rcp1ma;
                     const float w = alpha * T;
                     acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
                     acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
@@ -328,7 +334,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                     g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_id = w * dinvd;
                     dL_dalpha *= T;
                     last_alpha = alpha;
-                    dL_dalpha += (-Tfinal / (1.f - alpha)) * bgdot;
+                    dL_dalpha -= Tfinal * rcp1ma * bgdot;
                     const float dL_dG = r1.y * dL_dalpha;
                     const float gdx = G * dx, gdy = G * dy;
                     const float dG_ddx = -gdx * r0.z - gdy * r0.w;
@@ -343,6 +349,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 float y0, y1;
                 wave_reduce10(g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g, g_b, g_id, y0, y1);
                 const size_t id = ids[k];
+                if (g.dbg & 1u) { if (y0 == 123.456f) a.dL_dopacity[0] = y1; continue; }   // experiment: no atomics
                 if ((lane & 7) == 0) unsafeAtomicAdd(abase0 + id * astride0, y0);       // 8 lanes, 8 different targets
                 if (alane1) unsafeAtomicAdd(abase1 + id * astride1, y1);
             }
@@ -363,8 +370,12 @@ int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     return GMS_OK;
 }
 
-int32_t launch_blend_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    BlendGrid g = g_in;
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = e ? atoi(e) : 0; }
+    g.dbg = (uint32_t)dbg;
     const unsigned blocks = 8u * UNIT_RUN * ((max_units + 8u * UNIT_RUN - 1u) / (8u * UNIT_RUN));
     GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, a));
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");

@@ -19,6 +19,7 @@ struct BlendGrid {
     float *seg_state;              // [slots][SEG_FIELDS][256]
     uint64_t capacity;             // instances the binning buffer can hold
     uint32_t max_units;            // entries of unit_tile
+    uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)
 };
 
 struct BlendFwdOut {

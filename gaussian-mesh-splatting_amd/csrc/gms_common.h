@@ -193,26 +193,29 @@ template <bool RETURNING>
 __device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t *counters, int key, bool active)
 {
     const int lane = (int)(threadIdx.x & 63);
-    uint32_t rank = 0;
+    // group discovery: registers only
+    uint32_t rank = 0, cnt = 0;
+    int my_leader = lane;
+    bool is_leader = false;
     uint64_t todo = __ballot(active);
     while (todo) {
         const int leader = __builtin_ctzll(todo);
         const int k = __builtin_amdgcn_readlane(key, leader);
         const bool mine = active && key == k;
         const uint64_t same = __ballot(mine);
-        uint32_t base = 0;
-        if (lane == leader) {
-            const uint32_t cnt = (uint32_t)__builtin_popcountll(same);
-            if (RETURNING) base = atomicAdd(&counters[k], cnt);
-            else atomicAdd(&counters[k], cnt);
-        }
-        if (RETURNING) {
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-            if (mine) rank = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
-        }
+        if (mine) { rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)); my_leader = leader; }
+        if (lane == leader) { is_leader = true; cnt = (uint32_t)__builtin_popcountll(same); }
         todo &= ~same;
     }
-    return rank;
+    // every group's leader issues its atomic in the same instruction: one memory round trip per call
+    uint32_t base = 0;
+    if (is_leader) {
+        if (RETURNING) base = atomicAdd(&counters[key], cnt);
+        else atomicAdd(&counters[key], cnt);
+    }
+    if (!RETURNING) return 0;
+    base = (uint32_t)__shfl((int)base, my_leader);
+    return base + rank;
 }
 
 // a*b + c*d + e*f + g in the documented order ((a*b (+) c*d) (+) e*f) + g, each (+) fused.

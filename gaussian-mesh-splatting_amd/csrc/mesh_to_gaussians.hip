@@ -69,7 +69,7 @@ __device__ __forceinline__ void face_frame(V3 t0, V3 t1, V3 t2, Frame &f)
 }
 
 // rotation matrix with columns (v0,v1,v2) -> quaternion; also reports the selected candidate
-struct QuatSel { int sel; float a; float sign; float cand[4]; float x[4]; };
+struct QuatSel { int sel; float a; float sign; float cand[4]; float xsel; };   // xsel = argument of the selected sqrt
 
 __device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel *qs)
 {
@@ -85,7 +85,9 @@ __device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel 
 #pragma unroll
     for (int k = 1; k < 4; k++)
         if (qa[k] > qa[sel]) sel = k;          // first maximum wins, as torch.argmax
-    const float a = qa[sel];
+    // select without dynamic register-array indexing (that would be demoted to LDS/scratch)
+    const float a = sel == 0 ? qa[0] : sel == 1 ? qa[1] : sel == 2 ? qa[2] : qa[3];
+    const float xsel = sel == 0 ? x[0] : sel == 1 ? x[1] : sel == 2 ? x[2] : x[3];
     float c[4];
     const float a2 = a * a;
     if (sel == 0) { c[0] = a2; c[1] = m21 - m12; c[2] = m02 - m20; c[3] = m10 - m01; }
@@ -100,7 +102,8 @@ __device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel 
     if (qs) {
         qs->sel = sel; qs->a = a; qs->sign = sign;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { qs->cand[k] = c[k]; qs->x[k] = x[k]; }
+        for (int k = 0; k < 4; k++) qs->cand[k] = c[k];
+        qs->xsel = xsel;
     }
 }
 
@@ -131,7 +134,7 @@ __device__ __forceinline__ void barycentric(int mode, const float *raw, float al
 }
 
 __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *alpha_out, float *xyz, float *scaling,
-                                                         float *rotation)
+                                                         float *rotation, float *scaling_act, float *rotation_unit)
 {
 #pragma clang fp contract(off)
     const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -149,12 +152,18 @@ __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *a
     Frame fr;
     face_frame(t0, t1, t2, fr);
     const float sc = a._scale[p];
-    scaling[3 * p] = logf(fmaxf(sc * EPS, 0.f) + EPS);
-    scaling[3 * p + 1] = logf(fmaxf(sc * fr.s1, 0.f) + EPS);
-    scaling[3 * p + 2] = logf(fmaxf(sc * fr.s2, 0.f) + EPS);
+    const float act0 = fmaxf(sc * EPS, 0.f) + EPS, act1 = fmaxf(sc * fr.s1, 0.f) + EPS, act2 = fmaxf(sc * fr.s2, 0.f) + EPS;
+    scaling[3 * p] = logf(act0);
+    scaling[3 * p + 1] = logf(act1);
+    scaling[3 * p + 2] = logf(act2);
     float q[4];
     rot_to_quat(fr, q, nullptr);
     *reinterpret_cast<float4 *>(rotation + 4 * p) = make_float4(q[0], q[1], q[2], q[3]);
+    if (scaling_act) { scaling_act[3 * p] = act0; scaling_act[3 * p + 1] = act1; scaling_act[3 * p + 2] = act2; }
+    if (rotation_unit) {   // torch.nn.functional.normalize: q / max(|q|, 1e-12)
+        const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        *reinterpret_cast<float4 *>(rotation_unit + 4 * p) = make_float4(q[0] / n, q[1] / n, q[2] / n, q[3] / n);
+    }
 }
 
 // ------------------------------------------------------------------ backward, per splat
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, co
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const float u = sc * sj[j];
-        if (u > 0.f) acc += dL_dscaling[3 * p + j] * sj[j] / (u + EPS);
+        if (u > 0.f) acc += dL_dscaling[3 * p + j] * sj[j] * (a.fused_activations ? 1.f : 1.f / (u + EPS));
     }
     dL_dscale[p] = acc;
 }
@@ -207,8 +216,8 @@ __device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, c
     G.dq[0] += gq.x; G.dq[1] += gq.y; G.dq[2] += gq.z; G.dq[3] += gq.w;
     const float sc = a._scale[p];
     const float u1 = sc * fr.s1, u2 = sc * fr.s2;
-    if (u1 > 0.f) G.ds1 += dL_dscaling[3 * p + 1] * sc / (u1 + EPS);
-    if (u2 > 0.f) G.ds2 += dL_dscaling[3 * p + 2] * sc / (u2 + EPS);
+    if (u1 > 0.f) G.ds1 += dL_dscaling[3 * p + 1] * sc * (a.fused_activations ? 1.f : 1.f / (u1 + EPS));
+    if (u2 > 0.f) G.ds2 += dL_dscaling[3 * p + 2] * sc * (a.fused_activations ? 1.f : 1.f / (u2 + EPS));
 }
 
 // differentiate quaternion + frame once per face and scatter into the three vertices
@@ -218,6 +227,13 @@ __device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, Face
     float q[4];
     QuatSel qs;
     rot_to_quat(fr, q, &qs);
+    if (a.fused_activations) {   // gradient arrived w.r.t. q / |q|: project out the radial part, scale by 1/|q|
+        const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        const float u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+        const float d = u[0] * G.dq[0] + u[1] * G.dq[1] + u[2] * G.dq[2] + u[3] * G.dq[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) G.dq[k] = (G.dq[k] - u[k] * d) / n;
+    }
     const float den = 2.0f * fmaxf(qs.a, 0.1f);
     float gc[4];
     float dden = 0.f;
@@ -228,8 +244,9 @@ __device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, Face
         dden -= gk * qs.cand[k] / (den * den);
     }
     // a enters through den (if a > 0.1) and through cand[sel] = a^2
-    float da = (qs.a > 0.1f ? 2.f * dden : 0.f) + 2.f * qs.a * gc[qs.sel];
-    const float dx = (qs.x[qs.sel] > 0.f) ? da / (2.f * qs.a) : 0.f;   // a = sqrt(x), zero subgradient at x <= 0
+    const float gsel = qs.sel == 0 ? gc[0] : qs.sel == 1 ? gc[1] : qs.sel == 2 ? gc[2] : gc[3];
+    float da = (qs.a > 0.1f ? 2.f * dden : 0.f) + 2.f * qs.a * gsel;
+    const float dx = (qs.xsel > 0.f) ? da / (2.f * qs.a) : 0.f;   // a = sqrt(x), zero subgradient at x <= 0
     float d00 = 0, d01 = 0, d02 = 0, d10 = 0, d11 = 0, d12 = 0, d20 = 0, d21 = 0, d22 = 0;
     switch (qs.sel) {
     case 0:
@@ -354,7 +371,7 @@ static int32_t check_mesh_args(const GmsMeshArgs *A)
 }
 
 extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *alpha, float *xyz, float *scaling,
-                                                 float *rotation, void *stream_)
+                                                 float *rotation, float *scaling_act, float *rotation_unit, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
@@ -362,7 +379,7 @@ extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *al
     if (rc != GMS_OK) return rc;
     if (A->P == 0) return GMS_OK;
     if (!xyz || !scaling || !rotation) { set_error("mesh forward: null output"); return GMS_ERR_INVALID_ARGUMENT; }
-    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation));
+    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation, scaling_act, rotation_unit));
     GMS_KERNEL_CHECK(0, stream, "mesh_fwd");
     return GMS_OK;
 }

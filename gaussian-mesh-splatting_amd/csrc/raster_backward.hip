@@ -35,6 +35,71 @@ struct PreBwdArgs {
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 
+// SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
+// (ds_read_b128, conflict-free at the 52-dword pitch), d loss / d sh is written back in place, the
+// direction gradient is accumulated.  r[k*3+c] lives in registers (all indices are constants).
+template <int DEG>
+__device__ __forceinline__ void sh_backward(float *row_lds, float x, float y, float z, const float dRGB[3], float gdir[3])
+{
+    constexpr int NQ = ((DEG + 1) * (DEG + 1) * 3 + 3) / 4;
+    float r[NQ * 4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(row_lds + q * 4);
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+#define GMS_SH_TERM(K, BV, BDX, BDY, BDZ)                                          \
+    {                                                                              \
+        const float bv = (BV), bx = (BDX), by = (BDY), bz = (BDZ);                 \
+        _Pragma("unroll") for (int c = 0; c < 3; c++) {                            \
+            const float w = r[(K) * 3 + c] * dRGB[c];                              \
+            gdir[0] += bx * w; gdir[1] += by * w; gdir[2] += bz * w;               \
+            r[(K) * 3 + c] = bv * dRGB[c];                                         \
+        }                                                                          \
+    }
+    GMS_SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
+    if (DEG > 0) {
+        GMS_SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
+        GMS_SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
+        GMS_SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
+    }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        GMS_SH_TERM(4, SH_C2[0] * x * y, SH_C2[0] * y, SH_C2[0] * x, 0.f)
+        GMS_SH_TERM(5, SH_C2[1] * y * z, 0.f, SH_C2[1] * z, SH_C2[1] * y)
+        GMS_SH_TERM(6, SH_C2[2] * (2.f * zz - xx - yy), -2.f * SH_C2[2] * x, -2.f * SH_C2[2] * y, 4.f * SH_C2[2] * z)
+        GMS_SH_TERM(7, SH_C2[3] * x * z, SH_C2[3] * z, 0.f, SH_C2[3] * x)
+        GMS_SH_TERM(8, SH_C2[4] * (xx - yy), 2.f * SH_C2[4] * x, -2.f * SH_C2[4] * y, 0.f)
+    }
+    if (DEG > 2) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        GMS_SH_TERM(9, SH_C3[0] * y * (3.f * xx - yy), SH_C3[0] * 6.f * x * y, SH_C3[0] * (3.f * xx - 3.f * yy), 0.f)
+        GMS_SH_TERM(10, SH_C3[1] * x * y * z, SH_C3[1] * y * z, SH_C3[1] * x * z, SH_C3[1] * x * y)
+        GMS_SH_TERM(11, SH_C3[2] * y * (4.f * zz - xx - yy), SH_C3[2] * (-2.f * x * y), SH_C3[2] * (4.f * zz - xx - 3.f * yy), SH_C3[2] * 8.f * y * z)
+        GMS_SH_TERM(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), SH_C3[3] * (-6.f * x * z), SH_C3[3] * (-6.f * y * z), SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
+        GMS_SH_TERM(13, SH_C3[4] * x * (4.f * zz - xx - yy), SH_C3[4] * (4.f * zz - 3.f * xx - yy), SH_C3[4] * (-2.f * x * y), SH_C3[4] * 8.f * x * z)
+        GMS_SH_TERM(14, SH_C3[5] * z * (xx - yy), SH_C3[5] * 2.f * x * z, SH_C3[5] * (-2.f * y * z), SH_C3[5] * (xx - yy))
+        GMS_SH_TERM(15, SH_C3[6] * x * (xx - 3.f * yy), SH_C3[6] * (3.f * xx - 3.f * yy), SH_C3[6] * (-6.f * x * y), 0.f)
+    }
+#undef GMS_SH_TERM
+    // coefficients beyond the active degree inside the last chunk get zero gradient
+#pragma unroll
+    for (int k = (DEG + 1) * (DEG + 1) * 3; k < NQ * 4; k++) r[k] = 0.f;
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+        *reinterpret_cast<float4 *>(row_lds + q * 4) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+}
+
+template <int NQ>
+__device__ __forceinline__ void stage_sh_rows_b(const float *shs, int g0, int rows, int rowq, float *wl, int lane)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(shs) + (size_t)g0 * rowq;
+    for (int idx = lane; idx < rows * NQ; idx += WAVE) {
+        const int r = idx / NQ, c = idx - r * NQ;
+        *reinterpret_cast<float4 *>(wl + r * 52 + c * 4) = src[(size_t)r * rowq + c];
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH_B];
@@ -54,11 +119,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     if (use_sh) {
         if (vec_ok) {
             if (__any(vis)) {
-                const int nq = (nb * 3 + 3) / 4, rowq = rowf / 4;
-                const float4 *src = reinterpret_cast<const float4 *>(a.shs + (size_t)g0 * rowf);
-                for (int idx = lane; idx < rows * nq; idx += WAVE) {
-                    int r = idx / nq, c = idx - r * nq;
-                    *reinterpret_cast<float4 *>(wl + r * SH_PITCH_B + c * 4) = src[(size_t)r * rowq + c];
+                const int rowq = rowf / 4;
+                switch (a.D) {
+                case 0: stage_sh_rows_b<1>(a.shs, g0, rows, rowq, wl, lane); break;
+                case 1: stage_sh_rows_b<3>(a.shs, g0, rows, rowq, wl, lane); break;
+                case 2: stage_sh_rows_b<7>(a.shs, g0, rows, rowq, wl, lane); break;
+                default: stage_sh_rows_b<12>(a.shs, g0, rows, rowq, wl, lane); break;
                 }
             }
         } else if (vis) {
@@ -156,41 +222,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
 #pragma unroll
             for (int c = 0; c < 3; c++) dRGB[c] = ((cl >> c) & 1u) ? 0.f : a.dL_dcolors[3 * (size_t)i + c];
             float gdir[3] = {0.f, 0.f, 0.f};
-            // basis value and its direction derivative per coefficient; row[k*3+c] is read (sh) then
-            // overwritten in place with d loss / d sh.
-#define GMS_SH_TERM(K, BV, BDX, BDY, BDZ)                                          \
-            {                                                                      \
-                const float bv = (BV), bx = (BDX), by = (BDY), bz = (BDZ);         \
-                _Pragma("unroll") for (int c = 0; c < 3; c++) {                    \
-                    const float w = row[(K) * 3 + c] * dRGB[c];                    \
-                    gdir[0] += bx * w; gdir[1] += by * w; gdir[2] += bz * w;       \
-                    row[(K) * 3 + c] = bv * dRGB[c];                               \
-                }                                                                  \
+            switch (a.D) {
+            case 0: sh_backward<0>(row, x, y, z, dRGB, gdir); break;
+            case 1: sh_backward<1>(row, x, y, z, dRGB, gdir); break;
+            case 2: sh_backward<2>(row, x, y, z, dRGB, gdir); break;
+            default: sh_backward<3>(row, x, y, z, dRGB, gdir); break;
             }
-            GMS_SH_TERM(0, SH_C0, 0.f, 0.f, 0.f)
-            if (a.D > 0) {
-                GMS_SH_TERM(1, -SH_C1 * y, 0.f, -SH_C1, 0.f)
-                GMS_SH_TERM(2, SH_C1 * z, 0.f, 0.f, SH_C1)
-                GMS_SH_TERM(3, -SH_C1 * x, -SH_C1, 0.f, 0.f)
-                if (a.D > 1) {
-                    const float xx = x * x, yy = y * y, zz = z * z;
-                    GMS_SH_TERM(4, SH_C2[0] * x * y, SH_C2[0] * y, SH_C2[0] * x, 0.f)
-                    GMS_SH_TERM(5, SH_C2[1] * y * z, 0.f, SH_C2[1] * z, SH_C2[1] * y)
-                    GMS_SH_TERM(6, SH_C2[2] * (2.f * zz - xx - yy), -2.f * SH_C2[2] * x, -2.f * SH_C2[2] * y, 4.f * SH_C2[2] * z)
-                    GMS_SH_TERM(7, SH_C2[3] * x * z, SH_C2[3] * z, 0.f, SH_C2[3] * x)
-                    GMS_SH_TERM(8, SH_C2[4] * (xx - yy), 2.f * SH_C2[4] * x, -2.f * SH_C2[4] * y, 0.f)
-                    if (a.D > 2) {
-                        GMS_SH_TERM(9, SH_C3[0] * y * (3.f * xx - yy), SH_C3[0] * 6.f * x * y, SH_C3[0] * (3.f * xx - 3.f * yy), 0.f)
-                        GMS_SH_TERM(10, SH_C3[1] * x * y * z, SH_C3[1] * y * z, SH_C3[1] * x * z, SH_C3[1] * x * y)
-                        GMS_SH_TERM(11, SH_C3[2] * y * (4.f * zz - xx - yy), SH_C3[2] * (-2.f * x * y), SH_C3[2] * (4.f * zz - xx - 3.f * yy), SH_C3[2] * 8.f * y * z)
-                        GMS_SH_TERM(12, SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), SH_C3[3] * (-6.f * x * z), SH_C3[3] * (-6.f * y * z), SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
-                        GMS_SH_TERM(13, SH_C3[4] * x * (4.f * zz - xx - yy), SH_C3[4] * (4.f * zz - 3.f * xx - yy), SH_C3[4] * (-2.f * x * y), SH_C3[4] * 8.f * x * z)
-                        GMS_SH_TERM(14, SH_C3[5] * z * (xx - yy), SH_C3[5] * 2.f * x * z, SH_C3[5] * (-2.f * y * z), SH_C3[5] * (xx - yy))
-                        GMS_SH_TERM(15, SH_C3[6] * x * (xx - 3.f * yy), SH_C3[6] * (3.f * xx - 3.f * yy), SH_C3[6] * (-6.f * x * y), 0.f)
-                    }
-                }
-            }
-#undef GMS_SH_TERM
             const float dd = x * gdir[0] + y * gdir[1] + z * gdir[2];
             dmean[0] += (gdir[0] - x * dd) * inv;
             dmean[1] += (gdir[1] - y * dd) * inv;
@@ -235,10 +272,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     if (use_sh) {
         const int used = vis ? nb * 3 : 0;
         if (vec_ok) {
-            for (int k = used; k < rowf; k++) row[k] = 0.f;
+            // chunks the SH backward did not write (culled Gaussian, or coefficients above the active degree)
+            const int rowq = rowf / 4;
+            for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < rowq; q++)
+                *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
             __syncthreads();
             if (rows > 0) {
-                const int rowq = rowf / 4;
                 float4 *dst = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)g0 * rowf);
                 for (int idx = lane; idx < rows * rowq; idx += WAVE) {
                     int r = idx / rowq, c = idx - r * rowq;
@@ -298,7 +337,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = cap;
-        g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
+        g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0;
         BlendBwdArgs b;
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
         b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D;

@@ -53,20 +53,21 @@ struct PreArgs {
     uint32_t *tile_count;
 };
 
-// SH -> RGB (before +0.5/clamp) from an LDS row laid out [k][c]; same operation order as
-// utils/sh_utils.py:57-112 evaluated per channel.
-__device__ __forceinline__ float sh_eval_channel(int deg, const float *row, int c, float x, float y, float z)
+// SH -> RGB (before +0.5/clamp) for one channel from the coefficient row r[k*3+c] held in registers;
+// same operation order as utils/sh_utils.py:57-112 evaluated per channel.
+template <int DEG>
+__device__ __forceinline__ float sh_eval_channel(const float *row, int c, float x, float y, float z)
 {
 #pragma clang fp contract(off)
     float res = SH_C0 * row[0 * 3 + c];
-    if (deg > 0) {
+    if (DEG > 0) {
         res = res - SH_C1 * y * row[1 * 3 + c] + SH_C1 * z * row[2 * 3 + c] - SH_C1 * x * row[3 * 3 + c];
-        if (deg > 1) {
+        if (DEG > 1) {
             float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
             res = res + SH_C2[0] * xy * row[4 * 3 + c] + SH_C2[1] * yz * row[5 * 3 + c] +
                   SH_C2[2] * (2.f * zz - xx - yy) * row[6 * 3 + c] + SH_C2[3] * xz * row[7 * 3 + c] +
                   SH_C2[4] * (xx - yy) * row[8 * 3 + c];
-            if (deg > 2) {
+            if (DEG > 2) {
                 res = res + SH_C3[0] * y * (3.f * xx - yy) * row[9 * 3 + c] + SH_C3[1] * xy * z * row[10 * 3 + c] +
                       SH_C3[2] * y * (4.f * zz - xx - yy) * row[11 * 3 + c] +
                       SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy) * row[12 * 3 + c] +
@@ -76,6 +77,37 @@ __device__ __forceinline__ float sh_eval_channel(int deg, const float *row, int 
         }
     }
     return res;
+}
+
+// Stage the first NQ float4 chunks of `rows` consecutive SH rows into the wave's LDS region with
+// coalesced loads (each wave instruction moves 1 KiB), pitch SH_PITCH dwords per row.
+template <int NQ>
+__device__ __forceinline__ void stage_sh_rows(const float *shs, int g0, int rows, int rowq, float *wl, int lane)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(shs) + (size_t)g0 * rowq;
+    for (int idx = lane; idx < rows * NQ; idx += WAVE) {
+        const int r = idx / NQ, c = idx - r * NQ;
+        *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = src[(size_t)r * rowq + c];
+    }
+}
+
+// Read the lane's row back as float4 (ds_read_b128, conflict-free at a 52-dword pitch) and evaluate.
+template <int DEG>
+__device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y, float z, float rgb[3], unsigned &clampbits)
+{
+    constexpr int NQ = ((DEG + 1) * (DEG + 1) * 3 + 3) / 4;
+    float r[NQ * 4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(row_lds + q * 4);
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float v = sh_eval_channel<DEG>(r, c, x, y, z) + 0.5f;
+        if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
+        rgb[c] = v;
+    }
 }
 
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
@@ -146,13 +178,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         if (any_vis && vec_ok) {
             const int g0 = blockIdx.x * BLOCK + wave * WAVE;
             const int rows = min(WAVE, a.P - g0);
-            const int nq = (nb * 3 + 3) / 4;      // float4 chunks actually needed per row
             const int rowq = rowf / 4;
-            const float4 *src = reinterpret_cast<const float4 *>(a.shs + (size_t)g0 * rowf);
-            for (int idx = lane; idx < rows * nq; idx += WAVE) {
-                int r = idx / nq, c = idx - r * nq;
-                float4 v = src[(size_t)r * rowq + c];
-                *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = v;
+            switch (a.D) {
+            case 0: stage_sh_rows<1>(a.shs, g0, rows, rowq, wl, lane); break;
+            case 1: stage_sh_rows<3>(a.shs, g0, rows, rowq, wl, lane); break;
+            case 2: stage_sh_rows<7>(a.shs, g0, rows, rowq, wl, lane); break;
+            default: stage_sh_rows<12>(a.shs, g0, rows, rowq, wl, lane); break;
             }
         } else if (vis) {   // generic storage width (M != 16): plain per-lane loads into the lane's row
             for (int k = 0; k < nb * 3; k++) wl[lane * SH_PITCH + k] = a.shs[(size_t)i * rowf + k];
@@ -163,11 +194,11 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
             float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
             float x = dx * inv, y = dy * inv, z = dz * inv;
             const float *row = wl + lane * SH_PITCH;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float v = sh_eval_channel(a.D, row, c, x, y, z) + 0.5f;
-                if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
-                rgb[c] = v;
+            switch (a.D) {
+            case 0: sh_colour<0>(row, x, y, z, rgb, clampbits); break;
+            case 1: sh_colour<1>(row, x, y, z, rgb, clampbits); break;
+            case 2: sh_colour<2>(row, x, y, z, rgb, clampbits); break;
+            default: sh_colour<3>(row, x, y, z, rgb, clampbits); break;
             }
         }
     } else if (vis) {
@@ -436,8 +467,8 @@ uint32_t seg_len()
     if (L == 0) {
         uint32_t v = 256;
         if (const char *e = getenv("GMS_SEG_LEN")) v = (uint32_t)atoi(e);
-        if (v < 256) v = 256;
-        L = (v + 255u) / 256u * 256u;
+        if (v < 64) v = 64;
+        L = (v + 63u) / 64u * 64u;
     }
     return L;
 }
@@ -539,7 +570,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
-        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu;
+        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0;
         return launch_blend_forward(g, bo, mu, A->debug != 0, stream);
     };
 

@@ -58,7 +58,7 @@ class MeshArgs(C.Structure):
     _fields_ = [
         ("F", C.c_int32), ("V", C.c_int32), ("P", C.c_int64), ("splats_per_face", C.c_int32), ("alpha_mode", C.c_int32),
         ("vertices", C.c_void_p), ("faces", C.c_void_p), ("face_splat_offset", C.c_void_p), ("splat_face", C.c_void_p),
-        ("_alpha", C.c_void_p), ("_scale", C.c_void_p),
+        ("_alpha", C.c_void_p), ("_scale", C.c_void_p), ("fused_activations", C.c_int32),
     ]
 
 
@@ -95,7 +95,7 @@ def load():
         lib.gms_mark_visible.restype = C.c_int32
         lib.gms_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gms_mesh_to_gaussians_forward.restype = C.c_int32
-        lib.gms_mesh_to_gaussians_forward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 5
+        lib.gms_mesh_to_gaussians_forward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 7
         lib.gms_mesh_to_gaussians_backward.restype = C.c_int32
         lib.gms_mesh_to_gaussians_backward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 7
         lib.gms_abi_version.restype = C.c_int32

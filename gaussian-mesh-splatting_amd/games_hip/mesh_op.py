@@ -26,17 +26,21 @@ def _c(t, dtype):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face):
+def _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused=False):
     P = _alpha.shape[0] if _alpha.dim() == 2 else _alpha.shape[0] * _alpha.shape[1]
     return _lib.MeshArgs(F=int(faces.shape[0]), V=int(vertices.shape[0]), P=int(P), splats_per_face=int(splats_per_face),
                          alpha_mode=int(mode), vertices=_lib.ptr(vertices), faces=_lib.ptr(faces),
                          face_splat_offset=_lib.ptr(face_splat_offset), splat_face=_lib.ptr(splat_face),
-                         _alpha=_lib.ptr(_alpha), _scale=_lib.ptr(_scale))
+                         _alpha=_lib.ptr(_alpha), _scale=_lib.ptr(_scale), fused_activations=int(bool(fused)))
 
 
 class _MeshToGaussians(torch.autograd.Function):
+    """outputs: alpha, xyz, scaling (log), rotation, and -- when `fused` -- exp(scaling), normalize(rotation).
+    With `fused` the gradient enters through the activated outputs (the log / raw ones are then
+    attribute-parity outputs only and carry no gradient)."""
+
     @staticmethod
-    def forward(ctx, vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face):
+    def forward(ctx, vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused):
         lib = _lib.load()
         _lib.require_gpu(vertices, faces, _alpha, _scale)
         device = vertices.device
@@ -49,26 +53,34 @@ class _MeshToGaussians(torch.autograd.Function):
         xyz = torch.empty((P, 3), dtype=torch.float32, device=device)
         scaling = torch.empty((P, 3), dtype=torch.float32, device=device)
         rotation = torch.empty((P, 4), dtype=torch.float32, device=device)
-        a = _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face)
+        scaling_act = torch.empty((P, 3), dtype=torch.float32, device=device) if fused else None
+        rotation_unit = torch.empty((P, 4), dtype=torch.float32, device=device) if fused else None
+        a = _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.gms_mesh_to_gaussians_forward(C.byref(a), _lib.ptr(alpha), _lib.ptr(xyz), _lib.ptr(scaling),
-                                                         _lib.ptr(rotation), C.c_void_p(stream)), "gms_mesh_to_gaussians_forward")
+                                                         _lib.ptr(rotation), _lib.ptr(scaling_act), _lib.ptr(rotation_unit),
+                                                         C.c_void_p(stream)), "gms_mesh_to_gaussians_forward")
         ctx.save_for_backward(vertices, faces, _alpha, _scale,
                               face_splat_offset if face_splat_offset is not None else torch.empty(0, device=device),
                               splat_face if splat_face is not None else torch.empty(0, device=device))
-        ctx.mode, ctx.spf = mode, splats_per_face
+        ctx.mode, ctx.spf, ctx.fused = mode, splats_per_face, fused
+        if fused:
+            ctx.mark_non_differentiable(alpha, scaling, rotation)
+            return alpha, xyz, scaling, rotation, scaling_act, rotation_unit
         ctx.mark_non_differentiable(alpha)
         return alpha, xyz, scaling, rotation
 
     @staticmethod
-    def backward(ctx, _g_alpha, g_xyz, g_scaling, g_rotation):
+    def backward(ctx, _g_alpha, g_xyz, g_scaling, g_rotation, g_scaling_act=None, g_rotation_unit=None):
         lib = _lib.load()
         vertices, faces, _alpha, _scale, fso, sf = ctx.saved_tensors
         device = vertices.device
         P = _scale.numel()
         fso = fso if fso.numel() else None
         sf = sf if sf.numel() else None
+        if ctx.fused:
+            g_scaling, g_rotation = g_scaling_act, g_rotation_unit
 
         def grad_or_zero(g, shape):
             return torch.zeros(shape, dtype=torch.float32, device=device) if g is None else _c(g, torch.float32)
@@ -77,23 +89,24 @@ class _MeshToGaussians(torch.autograd.Function):
         d_vertices = torch.zeros_like(vertices)
         d_alpha = torch.empty_like(_alpha)
         d_scale = torch.empty_like(_scale)
-        a = _mesh_args(vertices, faces, _alpha, _scale, ctx.mode, ctx.spf, fso, sf)
+        a = _mesh_args(vertices, faces, _alpha, _scale, ctx.mode, ctx.spf, fso, sf, ctx.fused)
         with torch.cuda.device(device):
             stream = torch.cuda.current_stream(device).cuda_stream
             _lib.check(lib.gms_mesh_to_gaussians_backward(C.byref(a), _lib.ptr(g_xyz), _lib.ptr(g_scaling), _lib.ptr(g_rotation),
                                                           _lib.ptr(d_vertices), _lib.ptr(d_alpha), _lib.ptr(d_scale),
                                                           C.c_void_p(stream)), "gms_mesh_to_gaussians_backward")
-        return d_vertices, None, d_alpha, d_scale, None, None, None, None
+        return d_vertices, None, d_alpha, d_scale, None, None, None, None, None
 
 
 def mesh_to_gaussians(vertices: torch.Tensor, faces: torch.Tensor, _alpha: torch.Tensor, _scale: torch.Tensor,
                       alpha_mode: str = "relu", face_splat_offset: Optional[torch.Tensor] = None,
-                      splat_face: Optional[torch.Tensor] = None
-                      ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                      splat_face: Optional[torch.Tensor] = None, fused_activations: bool = False):
     """(alpha, _xyz[P,3], _scaling[P,3] (log), _rotation[P,4]) for mesh-bound Gaussians.
 
     `_alpha` is [F,S,3] (uniform S splats per face, the single-mesh models) or [P,3] together with
-    CSR `face_splat_offset` [F+1] / `splat_face` [P] (concatenated meshes with different S)."""
+    CSR `face_splat_offset` [F+1] / `splat_face` [P] (concatenated meshes with different S).
+    `fused_activations=True` appends (exp(_scaling), normalize(_rotation)) -- the property getters of
+    scene/gaussian_model.py:95-101 -- computed in the same kernel and differentiated in the same backward."""
     mode = ALPHA_MODES[alpha_mode]
     if face_splat_offset is None:
         if _alpha.dim() != 3:
@@ -101,17 +114,20 @@ def mesh_to_gaussians(vertices: torch.Tensor, faces: torch.Tensor, _alpha: torch
         spf = int(_alpha.shape[1])
     else:
         spf = 0
-    return _MeshToGaussians.apply(vertices, faces, _alpha, _scale, mode, spf, face_splat_offset, splat_face)
+    return _MeshToGaussians.apply(vertices, faces, _alpha, _scale, mode, spf, face_splat_offset, splat_face,
+                                  bool(fused_activations))
 
 
 _identity_faces = {}
 
 
-def triangles_to_gaussians(triangles: torch.Tensor, _alpha: torch.Tensor, _scale: torch.Tensor, alpha_mode: str = "relu"):
+def triangles_to_gaussians(triangles: torch.Tensor, _alpha: torch.Tensor, _scale: torch.Tensor, alpha_mode: str = "relu",
+                           fused_activations: bool = False):
     """Same op driven by explicit triangles [F,3,3] (the animated renderers replace `pc.triangles`
     per frame: renderer/gaussian_animated_renderer/__init__.py:61-73)."""
     F_ = int(triangles.shape[0])
     key = (triangles.device, F_)
     if key not in _identity_faces:
         _identity_faces[key] = torch.arange(3 * F_, device=triangles.device, dtype=torch.int64).reshape(F_, 3)
-    return mesh_to_gaussians(triangles.reshape(3 * F_, 3), _identity_faces[key], _alpha, _scale, alpha_mode)
+    return mesh_to_gaussians(triangles.reshape(3 * F_, 3), _identity_faces[key], _alpha, _scale, alpha_mode,
+                             fused_activations=fused_activations)

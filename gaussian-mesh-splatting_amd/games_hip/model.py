@@ -23,15 +23,15 @@ class HipMeshMixin:
     alpha_mode = "relu"
 
     def update_alpha(self):
-        alpha, xyz, scaling, rotation = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale,
-                                                          self.alpha_mode)
+        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
+            self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
         self.alpha = alpha
         self._xyz = xyz
         with torch.no_grad():
             tri = self.vertices[self.faces]
         self.triangles = tri
         self._hip_own_triangles = tri
-        self._hip_cached = (scaling, rotation)
+        self._hip_cached = (scaling, rotation, scaling_act, rotation_unit)
 
     def prepare_scaling_rot(self, *unused):
         tri = getattr(self, "triangles", None)
@@ -40,14 +40,32 @@ class HipMeshMixin:
         if tri is not None and tri is not own:
             # a renderer replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72-73):
             # derive scale / rotation from those triangles
-            _, _, scaling, rotation = triangles_to_gaussians(tri, self._alpha, self._scale, self.alpha_mode)
+            _, _, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
+                tri, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
         elif cached is not None:
-            scaling, rotation = cached
+            scaling, rotation, scaling_act, rotation_unit = cached
         else:
-            _, _, scaling, rotation = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale,
-                                                        self.alpha_mode)
+            _, _, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
+                self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
         self._scaling = scaling
         self._rotation = rotation
+        self._hip_activated = (scaling, rotation, scaling_act, rotation_unit)
+
+    # Property getters (scene/gaussian_model.py:95-101): exp / normalize were computed by the fused
+    # kernel; fall back to the reference's formula if somebody replaced _scaling / _rotation.
+    @property
+    def get_scaling(self):
+        act = getattr(self, "_hip_activated", None)
+        if act is not None and act[0] is self._scaling:
+            return act[2]
+        return torch.exp(self._scaling)
+
+    @property
+    def get_rotation(self):
+        act = getattr(self, "_hip_activated", None)
+        if act is not None and act[1] is self._rotation:
+            return act[3]
+        return torch.nn.functional.normalize(self._rotation)
 
 
 class HipGaussianMeshModel(HipMeshMixin):
@@ -91,14 +109,6 @@ class HipGaussianMeshModel(HipMeshMixin):
     @property
     def get_xyz(self):
         return self._xyz
-
-    @property
-    def get_scaling(self):
-        return torch.exp(self._scaling)
-
-    @property
-    def get_rotation(self):
-        return torch.nn.functional.normalize(self._rotation)
 
     @property
     def get_opacity(self):

@@ -152,12 +152,16 @@ typedef struct GmsMeshArgs {
     const int32_t *splat_face;    /* [P] face of each splat (non-uniform case) or NULL */
     const float *_alpha;          /* [P,3]  (the reference's [F,S,3] flattened) */
     const float *_scale;          /* [P] */
+    int32_t fused_activations;    /* 1: the property getters of scene/gaussian_model.py:95-101 are fused in:
+                                     forward also writes exp(scaling) and normalize(rotation); backward takes
+                                     the gradients w.r.t. THOSE instead of (scaling, rotation) */
 } GmsMeshArgs;
 
 /* Outputs: alpha [P,3] (normalised barycentrics, kept because save_ply / the animated renderer
  * read `pc.alpha`), xyz [P,3], scaling [P,3] = log(relu(_scale*s)+eps), rotation [P,4] quaternion. */
 int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *args, float *alpha, float *xyz, float *scaling,
-                                      float *rotation, void *stream);
+                                      float *rotation, float *scaling_activated /* [P,3] or NULL */,
+                                      float *rotation_unit /* [P,4] or NULL */, void *stream);
 
 /* Gradients of (xyz, scaling, rotation) -> (vertices, _alpha, _scale).  dL_dvertices [V,3] is
  * accumulated with atomics and MUST be zero-filled by the caller; dL_dalpha [P,3] and

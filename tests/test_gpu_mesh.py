@@ -115,3 +115,27 @@ def test_triangles_mode_and_model_surface():
         xyz = torch.matmul(m.alpha, tri).reshape(-1, 3)
     _, _, xyz_o, scaling_o, rot_o = mesh_oracle.mesh_to_gaussians(new_v, scene.faces, scene._alpha, scene._scale)
     _close(xyz, xyz_o, rtol=1e-5); _close(m._scaling, scaling_o, rtol=1e-5); _close(m._rotation, rot_o, rtol=1e-4)
+
+
+@pytest.mark.parametrize("S", [3, 40])
+def test_fused_activations_match_unfused_chain(S):
+    """fused_activations=True returns exp(_scaling) / normalize(_rotation) and differentiates through them
+    exactly like the reference's property getters (scene/gaussian_model.py:95-101) applied afterwards."""
+    from games_hip.mesh_op import mesh_to_gaussians
+    v, f = syn.uv_sphere(10, 12)
+    gen = torch.Generator().manual_seed(S)
+    F = f.shape[0]
+    a = torch.rand(F, S, 3, generator=gen) - 0.05
+    s = torch.exp(0.3 * torch.randn(F * S, 1, generator=gen))
+    g = dict(g_xyz=torch.randn(F * S, 3, generator=gen), g_scaling_act=torch.randn(F * S, 3, generator=gen),
+             g_rotation_act=torch.randn(F * S, 4, generator=gen))
+    vc, ac, sc = v.clone().requires_grad_(True), a.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vc, f, ac, sc, "relu")
+    _loss(xyz, scaling, rot, g, "cpu").backward()
+    vg, ag, sg = v.cuda().requires_grad_(True), a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+    _, xyz_h, scaling_h, rot_h, sact, runit = mesh_to_gaussians(vg, f.cuda(), ag, sg, "relu", fused_activations=True)
+    _close(sact, torch.exp(scaling), rtol=1e-5)
+    _close(runit, torch.nn.functional.normalize(rot), rtol=1e-4)
+    _close(scaling_h, scaling, rtol=1e-5)
+    ((xyz_h * g["g_xyz"].cuda()).sum() + (sact * g["g_scaling_act"].cuda()).sum() + (runit * g["g_rotation_act"].cuda()).sum()).backward()
+    _close(vg.grad, vc.grad); _close(ag.grad, ac.grad); _close(sg.grad, sc.grad)
