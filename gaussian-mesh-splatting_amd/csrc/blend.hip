@@ -104,13 +104,21 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const Sp
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
             while (mask) {
-                const int k = chunk + __builtin_ctzll(mask);
+                // two queue entries per trip: their alpha evaluations are independent (ILP hides the
+                // LDS and exp latency); only the transmittance product is sequential
+                const int ka = chunk + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const float4 r0 = recs[k].q0, r1 = recs[k].q1;
-                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
-                if (power <= 0.f && alpha >= ALPHA_MIN) Tl *= (1.f - alpha);
+                const bool two = mask != 0;
+                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
+                mask &= mask - 1;                                   // no-op when mask is already 0
+                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, b0 = recs[kb].q0, b1 = recs[kb].q1;
+                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
+                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
+                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
+                const float ala = fminf(ALPHA_MAX, a1.y * __expf(pa));
+                const float alb = fminf(ALPHA_MAX, b1.y * __expf(pb));
+                if (pa <= 0.f && ala >= ALPHA_MIN) Tl *= (1.f - ala);
+                if (two && pb <= 0.f && alb >= ALPHA_MIN) Tl *= (1.f - alb);
             }
         }
     }
@@ -143,21 +151,42 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdO
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
             while (mask) {
-                const int k = chunk + __builtin_ctzll(mask);     // wave-uniform queue slot
+                // two queue entries per trip (independent alpha evaluation, sequential compositing)
+                const int ka = chunk + __builtin_ctzll(mask);       // wave-uniform queue slots
                 mask &= mask - 1;
-                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
-                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float alpha = fminf(ALPHA_MAX, r1.y * __expf(power));
-                bool act = !done && power <= 0.f && alpha >= ALPHA_MIN;
-                const float testT = T * (1.f - alpha);
-                if (act && testT < T_MIN) { done = true; act = false; }
-                if (act) {
-                    const float w = alpha * T;
-                    C0 += r1.z * w; C1 += r1.w * w; C2 += r2.x * w;
-                    Dp += r2.y * w;
-                    T = testT;
-                    last = (base - u.tile_beg) + (uint32_t)k + 1u;
+                const bool two = mask != 0;
+                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
+                mask &= mask - 1;
+                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, a2 = recs[ka].q2;
+                const float4 b0 = recs[kb].q0, b1 = recs[kb].q1, b2 = recs[kb].q2;
+                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
+                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
+                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
+                const float ala = fminf(ALPHA_MAX, a1.y * __expf(pa));
+                const float alb = fminf(ALPHA_MAX, b1.y * __expf(pb));
+                {
+                    bool act = !done && pa <= 0.f && ala >= ALPHA_MIN;
+                    const float testT = T * (1.f - ala);
+                    if (act && testT < T_MIN) { done = true; act = false; }
+                    if (act) {
+                        const float w = ala * T;
+                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
+                        Dp += a2.y * w;
+                        T = testT;
+                        last = (base - u.tile_beg) + (uint32_t)ka + 1u;
+                    }
+                }
+                if (two) {
+                    bool act = !done && pb <= 0.f && alb >= ALPHA_MIN;
+                    const float testT = T * (1.f - alb);
+                    if (act && testT < T_MIN) { done = true; act = false; }
+                    if (act) {
+                        const float w = alb * T;
+                        C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w;
+                        Dp += b2.y * w;
+                        T = testT;
+                        last = (base - u.tile_beg) + (uint32_t)kb + 1u;
+                    }
                 }
                 if (__all(done)) break;
             }
@@ -229,6 +258,42 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
 }
 
 // ------------------------------------------------------------------------------------ bwd
+// per-pixel state of the back-to-front recurrence
+struct BwdState {
+    float T, acc0, acc1, acc2, accd, last_alpha, lc0, lc1, lc2, lastd;
+};
+
+// One splat against one pixel: updates the recurrence and returns the ten partial gradients
+// v = (mean2D.x, mean2D.y, conic A, conic B, conic C, opacity, r, g, b, inverse depth).
+__device__ __forceinline__ void bwd_step(BwdState &s, const float4 &r0, const float4 &r1, const float4 &r2, float dx,
+                                         float dy, float G, float alpha, float dp0, float dp1, float dp2, float dinvd,
+                                         float Tfinal, float bgdot, float halfW, float halfH, float *v)
+{
+    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01
+    s.T = s.T * rcp1ma;
+    const float w = alpha * s.T;
+    s.acc0 = s.last_alpha * s.lc0 + (1.f - s.last_alpha) * s.acc0;
+    s.acc1 = s.last_alpha * s.lc1 + (1.f - s.last_alpha) * s.acc1;
+    s.acc2 = s.last_alpha * s.lc2 + (1.f - s.last_alpha) * s.acc2;
+    s.accd = s.last_alpha * s.lastd + (1.f - s.last_alpha) * s.accd;
+    s.lc0 = r1.z; s.lc1 = r1.w; s.lc2 = r2.x; s.lastd = r2.y;
+    float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2 + (r2.y - s.accd) * dinvd;
+    v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = w * dinvd;
+    dL_dalpha *= s.T;
+    s.last_alpha = alpha;
+    dL_dalpha -= Tfinal * rcp1ma * bgdot;
+    const float dL_dG = r1.y * dL_dalpha;                      // alpha = min(0.99, op*G) is straight-through
+    const float gdx = G * dx, gdy = G * dy;
+    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
+    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
+    v[0] = dL_dG * dG_ddx * halfW;
+    v[1] = dL_dG * dG_ddy * halfH;
+    v[2] = -0.5f * gdx * dx * dL_dG;
+    v[3] = -0.5f * gdx * dy * dL_dG;
+    v[4] = -0.5f * gdy * dy * dL_dG;
+    v[5] = G * dL_dalpha;
+}
+
 __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     __shared__ SplatRec recs[BLOCK];
@@ -251,18 +316,17 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
     const uint32_t seg_lo = u.beg - u.tile_beg, seg_hi = u.end - u.tile_beg;   // positions covered by this unit
 
-    float T = Tfinal, acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
+    BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (u.nseg > 1) {
         const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
         const float te = st[SEG_TEND * TILE_PIX + tid];
         if (te > 0.f) {
-            T = te;
+            st8.T = te;
             const float inv = 1.f / te;
-            acc0 = st[SEG_C0 * TILE_PIX + tid] * inv; acc1 = st[SEG_C1 * TILE_PIX + tid] * inv;
-            acc2 = st[SEG_C2 * TILE_PIX + tid] * inv; accd = st[SEG_D * TILE_PIX + tid] * inv;
+            st8.acc0 = st[SEG_C0 * TILE_PIX + tid] * inv; st8.acc1 = st[SEG_C1 * TILE_PIX + tid] * inv;
+            st8.acc2 = st[SEG_C2 * TILE_PIX + tid] * inv; st8.accd = st[SEG_D * TILE_PIX + tid] * inv;
         }
     }
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, lastd = 0.f;
     const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;
 
     // lane-constant atomic targets matching wave_reduce10's output layout
@@ -308,50 +372,52 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
             if (g.dbg & 4u) { if (mask == 0x123456789ull) a.dL_dopacity[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
-                const int k = chunk + __builtin_ctzll(mask);
+                // two queue entries per trip: loads, exp and the two wave reductions are independent and
+                // interleave; only the per-pixel recurrence is sequential (entry a is behind entry b)
+                const int ka = chunk + __builtin_ctzll(mask);
                 mask &= mask - 1;
-                const uint32_t pos0 = hi - 1 - (uint32_t)k;          // 0-based position in the tile's list
-                const float4 r0 = recs[k].q0, r1 = recs[k].q1, r2 = recs[k].q2;
-                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-                const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-                const float G = __expf(power);
-                const float alpha = fminf(ALPHA_MAX, r1.y * G);
-                const bool act = pos0 < last && power <= 0.f && alpha >= ALPHA_MIN;
-                if (!__any(act)) continue;
-                float g_mx = 0.f, g_my = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f, g_op = 0.f;
-                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_id = 0.f;
-                if (act) {
-                    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01
-                    T = T * rcp1ma;
-                    const float w = alpha * T;
-                    acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                    acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                    acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                    accd = last_alpha * lastd + (1.f - last_alpha) * accd;
-                    lc0 = r1.z; lc1 = r1.w; lc2 = r2.x; lastd = r2.y;
-                    float dL_dalpha = (r1.z - acc0) * dp0 + (r1.w - acc1) * dp1 + (r2.x - acc2) * dp2 +
-                                      (r2.y - accd) * dinvd;
-                    g_r = w * dp0; g_g = w * dp1; g_b = w * dp2; g_id = w * dinvd;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha -= Tfinal * rcp1ma * bgdot;
-                    const float dL_dG = r1.y * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
-                    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
-                    g_mx = dL_dG * dG_ddx * halfW;
-                    g_my = dL_dG * dG_ddy * halfH;
-                    g_ca = -0.5f * gdx * dx * dL_dG;
-                    g_cb = -0.5f * gdx * dy * dL_dG;
-                    g_cc = -0.5f * gdy * dy * dL_dG;
-                    g_op = G * dL_dalpha;
+                const bool two = mask != 0;
+                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
+                mask &= mask - 1;
+                const uint32_t posa = hi - 1 - (uint32_t)ka, posb = hi - 1 - (uint32_t)kb;   // 0-based tile positions
+                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, a2 = recs[ka].q2;
+                const float4 b0 = recs[kb].q0, b1 = recs[kb].q1, b2 = recs[kb].q2;
+                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
+                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
+                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
+                const float Ga = __expf(pa), Gb = __expf(pb);
+                const float ala = fminf(ALPHA_MAX, a1.y * Ga), alb = fminf(ALPHA_MAX, b1.y * Gb);
+                const bool acta = posa < last && pa <= 0.f && ala >= ALPHA_MIN;
+                const bool actb = two && posb < last && pb <= 0.f && alb >= ALPHA_MIN;
+                const bool anya = __any(acta), anyb = __any(actb);
+                if (!(anya || anyb)) continue;
+                float va[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                float vb[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (acta) bwd_step(st8, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
+                if (actb) bwd_step(st8, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                const bool noatomics = (g.dbg & 1u) != 0;                 // experiment switch
+                if (anya && anyb) {
+                    float y0a, y1a, y0b, y1b;
+                    wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
+                    if (noatomics) { if (y0a == 123.456f) a.dL_dopacity[0] = y1a + y0b + y1b; continue; }
+                    const size_t ida = ids[ka], idb = ids[kb];
+                    if ((lane & 7) == 0) {
+                        unsafeAtomicAdd(abase0 + ida * astride0, y0a);       // 8 lanes, 8 different targets
+                        unsafeAtomicAdd(abase0 + idb * astride0, y0b);
+                    }
+                    if (alane1) {
+                        unsafeAtomicAdd(abase1 + ida * astride1, y1a);
+                        unsafeAtomicAdd(abase1 + idb * astride1, y1b);
+                    }
+                } else {
+                    float y0, y1;
+                    float *v = anya ? va : vb;
+                    wave_reduce10(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], y0, y1);
+                    if (noatomics) { if (y0 == 123.456f) a.dL_dopacity[0] = y1; continue; }
+                    const size_t id = ids[anya ? ka : kb];
+                    if ((lane & 7) == 0) unsafeAtomicAdd(abase0 + id * astride0, y0);
+                    if (alane1) unsafeAtomicAdd(abase1 + id * astride1, y1);
                 }
-                float y0, y1;
-                wave_reduce10(g_mx, g_my, g_ca, g_cb, g_cc, g_op, g_r, g_g, g_b, g_id, y0, y1);
-                const size_t id = ids[k];
-                if (g.dbg & 1u) { if (y0 == 123.456f) a.dL_dopacity[0] = y1; continue; }   // experiment: no atomics
-                if ((lane & 7) == 0) unsafeAtomicAdd(abase0 + id * astride0, y0);       // 8 lanes, 8 different targets
-                if (alane1) unsafeAtomicAdd(abase1 + id * astride1, y1);
             }
         }
     }

@@ -168,6 +168,26 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
     y1 = dpp_add<0x141>(y1); y1 = dpp_add<0xB1>(y1); y1 = dpp_add<0x4E>(y1);
 }
 
+// Two independent ten-value reductions with their stages interleaved (same layout as wave_reduce10
+// for each): the second chain fills the issue slots the first one leaves while waiting.
+__device__ __forceinline__ void wave_reduce10x2(float *a, float *b, float &y0a, float &y1a, float &y0b, float &y1b)
+{
+    swap32(a[0], a[1]); swap32(b[0], b[1]); swap32(a[2], a[3]); swap32(b[2], b[3]); swap32(a[4], a[5]);
+    swap32(b[4], b[5]); swap32(a[6], a[7]); swap32(b[6], b[7]); swap32(a[8], a[9]); swap32(b[8], b[9]);
+    float wa0 = a[0] + a[1], wb0 = b[0] + b[1], wa1 = a[2] + a[3], wb1 = b[2] + b[3], wa2 = a[4] + a[5];
+    float wb2 = b[4] + b[5], wa3 = a[6] + a[7], wb3 = b[6] + b[7], wa4 = a[8] + a[9], wb4 = b[8] + b[9];
+    float za = 0.f, zb = 0.f;
+    swap16(wa0, wa1); swap16(wb0, wb1); swap16(wa2, wa3); swap16(wb2, wb3); swap16(wa4, za); swap16(wb4, zb);
+    const float xa0 = wa0 + wa1, xb0 = wb0 + wb1, xa1 = wa2 + wa3, xb1 = wb2 + wb3, xa2 = wa4 + za, xb2 = wb4 + zb;
+    const bool hi8 = (threadIdx.x & 8) != 0;
+    const float pa = dpp_add<0x128>(xa0), pb = dpp_add<0x128>(xb0), qa = dpp_add<0x128>(xa1), qb = dpp_add<0x128>(xb1);
+    y0a = hi8 ? qa : pa; y0b = hi8 ? qb : pb;
+    y1a = dpp_add<0x128>(xa2); y1b = dpp_add<0x128>(xb2);
+    y0a = dpp_add<0x141>(y0a); y0b = dpp_add<0x141>(y0b); y1a = dpp_add<0x141>(y1a); y1b = dpp_add<0x141>(y1b);
+    y0a = dpp_add<0xB1>(y0a); y0b = dpp_add<0xB1>(y0b); y1a = dpp_add<0xB1>(y1a); y1b = dpp_add<0xB1>(y1b);
+    y0a = dpp_add<0x4E>(y0a); y0b = dpp_add<0x4E>(y0b); y1a = dpp_add<0x4E>(y1a); y1b = dpp_add<0x4E>(y1b);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // Tile rectangle of a splat: identical code in preprocess (count) and emit, so both agree.

@@ -156,7 +156,7 @@ def test_full_size_mesh_scene_properties():
         white = render(cam, model, PipelineParams(), torch.ones(3, device="cuda"), override_color=ones)["render"]
         black = render(cam, model, PipelineParams(), torch.zeros(3, device="cuda"), override_color=ones)
         # colour 1 everywhere: sum of weights + T_final = 1  =>  white-background image is exactly 1
-        assert (white - 1).abs().max().item() <= 2e-5
+        assert (white - 1).abs().max().item() <= 1e-4      # float32 sum of up to ~7000 weights per pixel
         cover = black["render"][0]
         assert 0.15 < (cover > 0.5).float().mean().item() < 0.6          # the sphere covers the image centre
         assert (black["radii"] > 0).all()
