@@ -329,21 +329,24 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     }
     const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;
 
-    // lane-constant atomic targets matching wave_reduce10's output layout
-    float *abase0; size_t astride0;
+    // wave_reduce10 leaves the ten totals in lanes 0,8,...,56 (y0) and 4, 36 (y1): those ten lanes add
+    // into the ten fields of the splat's 64-byte gradient record with ONE atomic instruction.
+    int afield;
     switch (lane >> 3) {
-    case 0: abase0 = a.dL_dmean2D; astride0 = 3; break;          // v0 = mean2D.x
-    case 1: abase0 = a.dL_dconic + 3; astride0 = 4; break;       // v4 = conic C
-    case 2: abase0 = a.dL_dconic; astride0 = 4; break;           // v2 = conic A
-    case 3: abase0 = a.dL_dcolors; astride0 = 3; break;          // v6 = r
-    case 4: abase0 = a.dL_dmean2D + 1; astride0 = 3; break;      // v1 = mean2D.y
-    case 5: abase0 = a.dL_dopacity; astride0 = 1; break;         // v5 = opacity
-    case 6: abase0 = a.dL_dconic + 1; astride0 = 4; break;       // v3 = conic B
-    default: abase0 = a.dL_dcolors + 1; astride0 = 3; break;     // v7 = g
+    case 0: afield = GRAD_MX; break;
+    case 1: afield = GRAD_CC; break;
+    case 2: afield = GRAD_CA; break;
+    case 3: afield = GRAD_R; break;
+    case 4: afield = GRAD_MY; break;
+    case 5: afield = GRAD_OP; break;
+    case 6: afield = GRAD_CB; break;
+    default: afield = GRAD_G; break;
     }
-    float *abase1 = lane == 0 ? a.dL_dcolors + 2 : a.dL_dinvdepths;   // v8 = b (lane 0), v9 = inverse depth (lane 32)
-    const size_t astride1 = lane == 0 ? 3 : 1;
-    const bool alane1 = lane == 0 || (lane == 32 && a.dL_dinvd != nullptr);
+    if (lane == 4) afield = GRAD_B;
+    if (lane == 36) afield = GRAD_ID;
+    const bool alane = (lane & 7) == 0 || lane == 4 || (lane == 36 && a.has_invd);
+    float *const abase = a.accum + afield;
+    const bool use_y1 = (lane & 7) != 0;
 
     // entries of this unit that some pixel of the tile actually composited: positions [seg_lo, top)
     uint32_t m = min(last, seg_hi);
@@ -370,7 +373,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
-            if (g.dbg & 4u) { if (mask == 0x123456789ull) a.dL_dopacity[1] = 1.f; continue; }   // experiment: queue fill + cull only
+            if (g.dbg & 4u) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
                 // two queue entries per trip: loads, exp and the two wave reductions are independent and
                 // interleave; only the per-pixel recurrence is sequential (entry a is behind entry b)
@@ -396,27 +399,23 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 if (acta) bwd_step(st8, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
                 if (actb) bwd_step(st8, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
                 const bool noatomics = (g.dbg & 1u) != 0;                 // experiment switch
+                if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }   // experiment: no reduction
                 if (anya && anyb) {
                     float y0a, y1a, y0b, y1b;
                     wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
-                    if (noatomics) { if (y0a == 123.456f) a.dL_dopacity[0] = y1a + y0b + y1b; continue; }
+                    if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
                     const size_t ida = ids[ka], idb = ids[kb];
-                    if ((lane & 7) == 0) {
-                        unsafeAtomicAdd(abase0 + ida * astride0, y0a);       // 8 lanes, 8 different targets
-                        unsafeAtomicAdd(abase0 + idb * astride0, y0b);
-                    }
-                    if (alane1) {
-                        unsafeAtomicAdd(abase1 + ida * astride1, y1a);
-                        unsafeAtomicAdd(abase1 + idb * astride1, y1b);
+                    if (alane) {
+                        unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
+                        unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
                     }
                 } else {
                     float y0, y1;
                     float *v = anya ? va : vb;
                     wave_reduce10(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], y0, y1);
-                    if (noatomics) { if (y0 == 123.456f) a.dL_dopacity[0] = y1; continue; }
+                    if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
                     const size_t id = ids[anya ? ka : kb];
-                    if ((lane & 7) == 0) unsafeAtomicAdd(abase0 + id * astride0, y0);
-                    if (alane1) unsafeAtomicAdd(abase1 + id * astride1, y1);
+                    if (alane) unsafeAtomicAdd(abase + id * GRAD_STRIDE, use_y1 ? y1 : y0);
                 }
             }
         }

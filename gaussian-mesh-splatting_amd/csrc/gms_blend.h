@@ -4,6 +4,9 @@
 
 namespace gms {
 
+// fields of the per-Gaussian 64-byte gradient record
+enum { GRAD_MX = 0, GRAD_MY, GRAD_CA, GRAD_CB, GRAD_CC, GRAD_OP, GRAD_R, GRAD_G, GRAD_B, GRAD_ID, GRAD_STRIDE = 16 };
+
 // per (multi-segment unit, pixel) state, SoA over the 256 pixels of the tile
 enum { SEG_TLOC = 0, SEG_C0, SEG_C1, SEG_C2, SEG_D, SEG_TEND, SEG_LAST, SEG_FIELDS };
 constexpr size_t SEG_FLOATS = (size_t)SEG_FIELDS * TILE_PIX;     // 7 KiB per unit
@@ -38,11 +41,8 @@ struct BlendBwdArgs {
     const uint32_t *n_contrib;
     const float *dL_dpix;       // [3,H,W]
     const float *dL_dinvd;      // [H,W] or NULL
-    float *dL_dmean2D;          // [P,3]
-    float *dL_dconic;           // [P,4]
-    float *dL_dopacity;         // [P]
-    float *dL_dcolors;          // [P,3]
-    float *dL_dinvdepths;       // [P]
+    float *accum;               // [P,16] zero-filled 64-B gradient records (see GRAD_* below)
+    int has_invd;
 };
 
 // segment length used by this process (env GMS_SEG_LEN, default 256; multiple of 256)

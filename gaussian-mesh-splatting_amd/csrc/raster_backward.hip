@@ -30,8 +30,8 @@ struct PreBwdArgs {
     int aa;
     const int *radii;
     const uint8_t *clamped;
-    const float *dL_dmean2D, *dL_dconic, *dL_dcolors, *dL_dinvdepths;
-    float *dL_dopacity;     // in/out (antialiasing rescales it)
+    const float *accum;     // [P,16] gradient records filled by blend_bwd
+    float *dL_dmean2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
 };
 
@@ -137,7 +137,16 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
-    float dop = valid ? a.dL_dopacity[i] : 0.f;
+    // the Gaussian's 64-byte gradient record (three coalesced float4 loads)
+    float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga, gc4 = ga;
+    if (valid) {
+        const float4 *rec = reinterpret_cast<const float4 *>(a.accum + (size_t)i * GRAD_STRIDE);
+        ga = rec[0]; gb = rec[1]; gc4 = rec[2];
+    }
+    const float acc_mx = ga.x, acc_my = ga.y, acc_ca = ga.z, acc_cb = ga.w, acc_cc = gb.x;
+    const float acc_col[3] = {gb.z, gb.w, gc4.x};
+    const float acc_id = gc4.y;
+    float dop = gb.y;
     float *row = wl + lane * SH_PITCH_B;
 
     if (vis) {
@@ -161,8 +170,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         ewa_project(V, vx, vy, vz, cv, fx, fy, 1.3f * a.tanx, 1.3f * a.tany, e);
         const float b = e.b, aD = e.a0 + DILATE, cD = e.c0 + DILATE;
         const float det = aD * cD - b * b;
-        const float4 gcon = *reinterpret_cast<const float4 *>(a.dL_dconic + 4 * (size_t)i);
-        const float gA = gcon.x, gB = gcon.y, gC = gcon.w;
+        const float gA = acc_ca, gB = acc_cb, gC = acc_cc;
         const float d2inv = 1.f / (det * det + 0.0000001f);
         float dL_da = d2inv * (-cD * cD * gA + 2.f * b * cD * gB + (det - aD * cD) * gC);
         float dL_dc = d2inv * (-aD * aD * gC + 2.f * aD * b * gB + (det - aD * cD) * gA);
@@ -197,7 +205,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         const float dtx = e.xmul * -fx * tz2 * dJ02;
         const float dty = e.ymul * -fy * tz2 * dJ12;
         float dtz = -fx * tz2 * dJ00 - fy * tz2 * dJ11 + (2.f * fx * e.tx) * tz3 * dJ02 + (2.f * fy * e.ty) * tz3 * dJ12;
-        dtz -= a.dL_dinvdepths[i] * tz2;
+        dtz -= acc_id * tz2;
 #pragma unroll
         for (int r = 0; r < 3; r++) dmean[r] += V[4 * r + 0] * dtx + V[4 * r + 1] * dty + V[4 * r + 2] * dtz;
 
@@ -206,7 +214,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         const float hy = dot3p(Mx[1], px, Mx[5], py, Mx[9], pz, Mx[13]);
         const float hw = dot3p(Mx[3], px, Mx[7], py, Mx[11], pz, Mx[15]);
         const float mw = 1.f / (hw + 0.0000001f);
-        const float gmx = a.dL_dmean2D[3 * (size_t)i], gmy = a.dL_dmean2D[3 * (size_t)i + 1];
+        const float gmx = acc_mx, gmy = acc_my;
         const float mul1 = hx * mw * mw, mul2 = hy * mw * mw;
 #pragma unroll
         for (int r = 0; r < 3; r++)
@@ -220,7 +228,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
             const unsigned cl = a.clamped[i];
             float dRGB[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) dRGB[c] = ((cl >> c) & 1u) ? 0.f : a.dL_dcolors[3 * (size_t)i + c];
+            for (int c = 0; c < 3; c++) dRGB[c] = ((cl >> c) & 1u) ? 0.f : acc_col[c];
             float gdir[3] = {0.f, 0.f, 0.f};
             switch (a.D) {
             case 0: sh_backward<0>(row, x, y, z, dRGB, gdir); break;
@@ -290,6 +298,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     }
     if (!valid) return;
     a.dL_dopacity[i] = dop;
+    a.dL_dmean2D[3 * (size_t)i] = acc_mx; a.dL_dmean2D[3 * (size_t)i + 1] = acc_my; a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
+    if (a.dL_dcolors) { a.dL_dcolors[3 * (size_t)i] = acc_col[0]; a.dL_dcolors[3 * (size_t)i + 1] = acc_col[1]; a.dL_dcolors[3 * (size_t)i + 2] = acc_col[2]; }
     a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1]; a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     if (a.cov3Dp) {
         if (a.dL_dcov3D)
@@ -317,8 +327,8 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     if (P == 0) return GMS_OK;
     const bool sr = A->scales && A->rotations;
     if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
-        !A->dL_dout_color || !A->dL_dmeans2D || !A->dL_dconic || !A->dL_dopacity || !A->dL_dcolors ||
-        !A->dL_dinvdepths || !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
+        !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || !A->dL_dopacity || (A->colors_precomp && !A->dL_dcolors) ||
+        !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
         (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
         (A->cov3D_precomp && !A->dL_dcov3D)) {
         set_error("gms_rasterize_backward: null or inconsistent pointer arguments");
@@ -340,9 +350,8 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0;
         BlendBwdArgs b;
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
-        b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.dL_dmean2D = A->dL_dmeans2D;
-        b.dL_dconic = A->dL_dconic; b.dL_dopacity = A->dL_dopacity; b.dL_dcolors = A->dL_dcolors;
-        b.dL_dinvdepths = A->dL_dinvdepths;
+        b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.accum = A->grad_accum;
+        b.has_invd = A->dL_dout_invdepth != nullptr;
         const uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
         int32_t rc = launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
@@ -352,8 +361,8 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.means3D = A->means3D; p.shs = A->shs; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
-    p.clamped = geom.clamped; p.dL_dmean2D = A->dL_dmeans2D; p.dL_dconic = A->dL_dconic; p.dL_dcolors = A->dL_dcolors;
-    p.dL_dinvdepths = A->dL_dinvdepths; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
+    p.clamped = geom.clamped; p.accum = A->grad_accum; p.dL_dmean2D = A->dL_dmeans2D;
+    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");

@@ -179,14 +179,11 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = _f32c(grad_color) if grad_color is not None else torch.zeros((3, H, W), device=device)
         grad_invdepth = _f32c(grad_invdepth) if grad_invdepth is not None else None
 
-        # atomically accumulated gradients share one zero-filled allocation (one memset), carved into
-        # dense blocks: mean2D [P,3] | conic [P,4] | opacity [P] | colour [P,3] | invdepth [P]
-        flat = torch.zeros(max(P, 1) * 12, dtype=torch.float32, device=device)
-        dL_dmeans2D = flat[0:3 * P].view(P, 3)
-        dL_dconic = flat[3 * P:7 * P].view(P, 4)
-        dL_dopacity = flat[7 * P:8 * P].view(opacities.shape)
-        dL_dcolors = flat[8 * P:11 * P].view(P, 3)
-        dL_dinvdepths = flat[11 * P:12 * P]
+        # one zero-filled 64-byte gradient record per Gaussian for the blend kernel's atomics
+        grad_accum = torch.zeros((max(P, 1), 16), dtype=torch.float32, device=device)
+        dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=device)
+        dL_dopacity = torch.empty(opacities.shape, dtype=torch.float32, device=device)
+        dL_dcolors = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_sh else None
         dL_dmeans3D = torch.empty((P, 3), dtype=torch.float32, device=device)
         dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device) if use_sh else None
         dL_dscales = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_cov else None
@@ -203,15 +200,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             tan_fovy=float(rs.tanfovy), antialiasing=int(bool(rs.antialiasing)), debug=int(bool(rs.debug)),
             radii=_lib.ptr(radii), geom_buffer=_lib.ptr(geom), binning_buffer=_lib.ptr(binning),
             image_buffer=_lib.ptr(image), dL_dout_color=_lib.ptr(grad_color), dL_dout_invdepth=_lib.ptr(grad_invdepth),
-            dL_dmeans2D=_lib.ptr(dL_dmeans2D), dL_dconic=_lib.ptr(dL_dconic), dL_dopacity=_lib.ptr(dL_dopacity),
-            dL_dcolors=_lib.ptr(dL_dcolors), dL_dinvdepths=_lib.ptr(dL_dinvdepths), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
+            grad_accum=_lib.ptr(grad_accum), dL_dmeans2D=_lib.ptr(dL_dmeans2D), dL_dopacity=_lib.ptr(dL_dopacity),
+            dL_dcolors=_lib.ptr(dL_dcolors), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
             dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dscales=_lib.ptr(dL_dscales),
             dL_drotations=_lib.ptr(dL_drot))
         if P > 0:
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
                 _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
-        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, None if use_sh else dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
+        return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
                 dL_dcov3D, None)
 
 

@@ -48,8 +48,9 @@ class RasterBackwardArgs(C.Structure):
         ("antialiasing", C.c_int32), ("debug", C.c_int32),
         ("radii", C.c_void_p), ("geom_buffer", C.c_void_p), ("binning_buffer", C.c_void_p), ("image_buffer", C.c_void_p),
         ("dL_dout_color", C.c_void_p), ("dL_dout_invdepth", C.c_void_p),
-        ("dL_dmeans2D", C.c_void_p), ("dL_dconic", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
-        ("dL_dinvdepths", C.c_void_p), ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p),
+        ("grad_accum", C.c_void_p),
+        ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
+        ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
     ]
 

@@ -115,14 +115,15 @@ typedef struct GmsRasterBackwardArgs {
     const void *image_buffer;
     const float *dL_dout_color;       /* [3,H,W] */
     const float *dL_dout_invdepth;    /* [1,H,W] or NULL */
-    /* outputs (device).  dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors, dL_dinvdepths are
-     * accumulated with atomics and MUST be zero-filled by the caller; the others are fully
-     * overwritten (no zero-fill needed). */
-    float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column dead */
-    float *dL_dconic;      /* [P,4] scratch */
+    /* scratch (device): [P,16] floats, 64-byte aligned, MUST be zero-filled by the caller.  One 64-byte
+     * record per Gaussian {mean2D.x, mean2D.y, conic A, B, C, opacity, r, g, b, inverse depth, pad x6}:
+     * the blend kernel's ten partial sums of a (wave, splat) pair leave as ONE atomic instruction whose
+     * lanes all hit the same cache line. */
+    float *grad_accum;
+    /* outputs (device), all fully overwritten (no zero-fill needed) */
+    float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column = 0 */
     float *dL_dopacity;    /* [P] */
-    float *dL_dcolors;     /* [P,3] scratch (or the colors_precomp gradient) */
-    float *dL_dinvdepths;  /* [P] scratch */
+    float *dL_dcolors;     /* [P,3] written only when colors_precomp != NULL (else may be NULL) */
     float *dL_dmeans3D;    /* [P,3] */
     float *dL_dcov3D;      /* [P,6] written only when cov3D_precomp != NULL (else may be NULL) */
     float *dL_dsh;         /* [P,M,3] written only when shs != NULL */
