@@ -120,14 +120,15 @@ def main():
     bg = torch.ones(3, device=device)
     pipe = PipelineParams()
     params = model.parameters()
-    inv_norm = 1.0 / (2.0 * 3 * size * size)
+    inv_norm = 1.0 / (3.0 * size * size)
 
     def step():
         model.update_alpha()
         model.prepare_scaling_rot()
         image = render(cam, model, pipe, bg)["render"]
-        loss = ((image - 0.5) ** 2).sum() * inv_norm     # d loss / d image = (image - 0.5) / (3HW)
-        loss.backward()
+        with torch.no_grad():
+            grad = (image - 0.5) * inv_norm              # dL/dcolor = (image - 0.5) / (3HW), dense
+        image.backward(grad)
         if world > 1:
             allreduce_gradients(params, world)
         for p in params:

@@ -1,0 +1,92 @@
+"""World-size-2 gloo tests of the view-parallel data-parallel helpers (CPU, no GPU needed).
+Parity statement: all-reduced gradient == sum of the ranks' single-view gradients
+(divided by world size for mean-loss semantics)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from games_hip.ddp import allreduce_gradients, shard_views
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1234)          # identical "parameters" on every rank
+        shapes = [(50, 3), (40, 2, 3), (80, 1, 3), (80, 15, 3), (80, 1), (80, 1)]   # vertices,_alpha,f_dc,f_rest,opacity,scale
+        params = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+        # rank-specific "single-view" gradients
+        gr = torch.Generator().manual_seed(100 + rank)
+        local = [torch.randn(s, generator=gr) for s in shapes]
+        for p, l in zip(params, local):
+            p.grad = l.clone()
+        params[3].grad = None                              # a parameter without gradient is skipped
+        allreduce_gradients(params, world, average=True)
+        out = [None if p.grad is None else p.grad.clone() for p in params]
+        # camera sharding: same permutation everywhere, disjoint cover of the views within an epoch
+        views = [shard_views(8, step, rank, world, seed=7) for step in range(4)]
+        q.put((rank, local, out, views))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_world(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res
+
+
+def test_allreduce_equals_mean_of_single_view_gradients():
+    world = 2
+    try:
+        res = _run_world(world)
+    except Exception:          # e.g. the probed rendezvous port was taken in between: one retry
+        res = _run_world(world)
+    (_, l0, o0, v0), (_, l1, o1, v1) = res
+    for k in range(len(l0)):
+        if k == 3:
+            assert o0[k] is None and o1[k] is None
+            continue
+        expect = (l0[k] + l1[k]) / 2
+        torch.testing.assert_close(o0[k], expect, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(o1[k], expect, rtol=1e-6, atol=1e-7)
+    # 4 steps x 2 ranks = one epoch over 8 views, every view exactly once
+    assert sorted(v0 + v1) == list(range(8))
+
+
+def test_shard_views_is_deterministic_and_epoch_reshuffles():
+    a = [shard_views(8, s, r, 4, seed=3) for s in range(4) for r in range(4)]
+    b = [shard_views(8, s, r, 4, seed=3) for s in range(4) for r in range(4)]
+    assert a == b
+    assert sorted(a[:8]) == list(range(8)) and sorted(a[8:]) == list(range(8))
+    assert a[:8] != a[8:]          # a new permutation every epoch
+
+
+def test_single_process_is_a_no_op():
+    p = torch.zeros(3, requires_grad=True)
+    p.grad = torch.ones(3)
+    allreduce_gradients([p], 1)
+    assert torch.equal(p.grad, torch.ones(3))
