@@ -76,3 +76,27 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(dirpath, fn)
                 assert "gs_oracle" not in text, os.path.join(dirpath, fn)
+
+
+def test_install_patches_the_reference_registry():
+    """games_hip.model.install() keeps the reference's GaussianMeshModel (dataset reader, optimizer groups, PLY I/O)
+    and overrides only the two K0 methods + the fused getters.  Needs the reference tree: skipped on the GPU box."""
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref = ref_import.import_reference()
+    import games
+    from games_hip.model import HipMeshMixin, install
+    base = games.gaussianModel["gs_mesh"]
+    try:
+        out = install(games)
+        cls = games.gaussianModel["gs_mesh"]
+        assert out["gs_mesh"] is cls and issubclass(cls, HipMeshMixin) and issubclass(cls, ref.mesh_model.GaussianMeshModel)
+        assert cls.update_alpha is HipMeshMixin.update_alpha and cls.prepare_scaling_rot is HipMeshMixin.prepare_scaling_rot
+        assert cls.training_setup is ref.mesh_model.GaussianMeshModel.training_setup       # untouched
+        m = cls(3)
+        m._scaling, m._rotation = torch.zeros(4, 3), torch.tensor([[2.0, 0, 0, 0]] * 4)
+        assert torch.equal(m.get_scaling, torch.ones(4, 3)) and torch.allclose(m.get_rotation.norm(dim=1), torch.ones(4))
+    finally:
+        games.gaussianModel["gs_mesh"] = base
+        ref_import.drop_reference_stubs()
