@@ -372,31 +372,53 @@ __device__ void lds_bitonic(uint64_t *s, int m, int k0, int j0, bool first_mirro
     __syncthreads();
 }
 
-// CLASS 0: tiles with n <= SMALL_MAX (256 threads, 16 KiB LDS); CLASS 1: larger tiles (1024 threads,
-// 64 KiB LDS, global-memory merge steps beyond 8192 keys).  Both kernels are launched over all
-// tiles; a block returns at once when its tile belongs to the other class.
-constexpr int SORT_SMALL_MAX = 2048;
-constexpr int SORT_BIG_CHUNK = 8192;
+// Two launches.  (1) presort: grid (T, 8), 256 threads: block (t, c) sorts the c-th run of SORT_RUN keys of
+// tile t in LDS (runs of one tile sort on different CUs).  (2) merge: 1024 threads per tile with more than
+// one run: loads the tile (<= SORT_BIG_CHUNK keys) into LDS and runs only the merge levels above SORT_RUN
+// (25 sub-stages instead of 91 for 8192 keys).  Tiles beyond SORT_BIG_CHUNK keys take the generic path
+// (LDS-sorted 8192-key runs + wide strides in global memory).
+constexpr int SORT_RUN = 1024;
+constexpr int SORT_RUNS_PER_TILE = 8;
+constexpr int SORT_BIG_CHUNK = SORT_RUN * SORT_RUNS_PER_TILE;    // 8192 keys = 64 KiB LDS
 
-template <int THREADS, int CHUNK, bool BIG>
-__global__ void __launch_bounds__(THREADS) tile_sort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+__global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
 {
-    __shared__ uint64_t s[CHUNK];
+    __shared__ uint64_t s[SORT_RUN];
     const int tid = threadIdx.x;
     const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
     if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
     const long n = (long)(end64 - beg);
-    if (n <= 1) return;
-    if (BIG ? (n <= SORT_SMALL_MAX) : (n > SORT_SMALL_MAX)) return;
+    if (n <= 1 || n > SORT_BIG_CHUNK) return;
+    const long c0 = (long)blockIdx.y * SORT_RUN;
+    if (c0 >= n) return;
+    const int cn = (int)min((long)SORT_RUN, n - c0);
+    if (cn <= 1) return;
+    uint64_t *g = keys + beg + c0;
+    int m = 2;
+    while (m < cn) m <<= 1;
+    for (int i = tid; i < m; i += 256) s[i] = i < cn ? g[i] : ~0ull;
+    lds_bitonic<256>(s, m, 2, 0, true, tid);
+    for (int i = tid; i < cn; i += 256) g[i] = s[i];
+}
+
+__global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+{
+    constexpr int THREADS = 1024, CHUNK = SORT_BIG_CHUNK;
+    __shared__ uint64_t s[CHUNK];
+    const int tid = threadIdx.x;
+    const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
+    if (end64 > capacity) return;
+    const long n = (long)(end64 - beg);
+    if (n <= SORT_RUN) return;                    // a single presorted run
     uint64_t *g = keys + beg;
     long np2 = 2;
     while (np2 < n) np2 <<= 1;
     const uint64_t INF = ~0ull;
 
-    if (np2 <= CHUNK) {
+    if (np2 <= CHUNK) {                           // runs of SORT_RUN keys are sorted: merge levels only
         const int m = (int)np2;
         for (int i = tid; i < m; i += THREADS) s[i] = i < n ? g[i] : INF;
-        lds_bitonic<THREADS>(s, m, 2, 0, true, tid);
+        lds_bitonic<THREADS>(s, m, 2 * SORT_RUN, 0, true, tid);
         for (int i = tid; i < n; i += THREADS) g[i] = s[i];
         return;
     }
@@ -564,8 +586,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.unit_first, bin.unit_tile, T, mu);
         GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, (tile_sort_kernel<1024, SORT_BIG_CHUNK, true><<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity)));
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, (tile_sort_kernel<256, SORT_SMALL_MAX, false><<<(unsigned)T, 256, 0, stream>>>(img.tile_offset, bin.keys, capacity)));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, capacity));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
