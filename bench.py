@@ -180,9 +180,12 @@ def main():
                 continue
             avg_us = 1000.0 * ms / n
             gbs = ab[name] / (avg_us * 1e-6) / 1e9
-            kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / args.profile_steps,
+            kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
                              "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
                              "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": traffic.get(name)}
+        if not kernels:     # --profile-steps 0: no per-kernel timing requested
+            kernels = {"(not profiled)": {"avg_us": 0.0, "launches_per_step": 0, "algorithmic_bytes": 0, "achieved_GBps": 0.0,
+                                          "frac_of_8TBps": 0.0, "traffic": None}}
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches_per_step"])
         kd = kernels[dom]
         sum_kernel_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels.values())

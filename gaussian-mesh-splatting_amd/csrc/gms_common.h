@@ -238,6 +238,36 @@ __device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t *counters, int 
     return base + rank;
 }
 
+// Split form of the returning variant: `issue` elects leaders and fires the atomic (result pending in
+// `base`), `finish` broadcasts the leader's base.  Lets a caller keep several independent atomics in
+// flight and pay the memory round trip once.
+struct AggTicket { uint32_t rank; int leader; uint32_t base; };
+
+__device__ __forceinline__ AggTicket wave_aggregated_issue(uint32_t *counters, int key, bool active)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    AggTicket t{0u, lane, 0u};
+    uint32_t cnt = 0;
+    bool is_leader = false;
+    uint64_t todo = __ballot(active);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int k = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = active && key == k;
+        const uint64_t same = __ballot(mine);
+        if (mine) { t.rank = (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull)); t.leader = leader; }
+        if (lane == leader) { is_leader = true; cnt = (uint32_t)__builtin_popcountll(same); }
+        todo &= ~same;
+    }
+    if (is_leader) t.base = atomicAdd(&counters[key], cnt);
+    return t;
+}
+
+__device__ __forceinline__ uint32_t wave_aggregated_finish(const AggTicket &t)
+{
+    return (uint32_t)__shfl((int)t.base, t.leader) + t.rank;
+}
+
 // a*b + c*d + e*f + g in the documented order ((a*b (+) c*d) (+) e*f) + g, each (+) fused.
 __device__ __forceinline__ float dot3p(float a, float b, float c, float d, float e, float f, float g)
 {

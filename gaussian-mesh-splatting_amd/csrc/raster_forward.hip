@@ -110,6 +110,7 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
     }
 }
 
+template <int SHDEG>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {
 #pragma clang fp contract(off)
@@ -117,6 +118,32 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < a.P;
+
+    // Fast path: every global load of this thread is issued before anything is computed, so the
+    // position / scale / rotation / opacity / SH round trips overlap instead of chaining.
+    constexpr int NQ = SHDEG >= 0 ? ((SHDEG + 1) * (SHDEG + 1) * 3 + 3) / 4 : 1;
+    float4 stg[NQ];
+    float s_in[3] = {0.f, 0.f, 0.f};
+    float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
+    float op_in = 0.f;
+    if (SHDEG >= 0) {
+        const int g0 = blockIdx.x * BLOCK + wave * WAVE;
+        const int rows = min(WAVE, a.P - g0);
+        const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const int idx = lane + WAVE * j;
+            const int r = idx / NQ, c = idx - r * NQ;
+            stg[j] = idx < rows * NQ ? src[(size_t)r * 12 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (valid) {
+            op_in = a.opac[i];
+            if (!a.cov3Dp) {
+                s_in[0] = a.scales[3 * (size_t)i]; s_in[1] = a.scales[3 * (size_t)i + 1]; s_in[2] = a.scales[3 * (size_t)i + 2];
+                q_in = *reinterpret_cast<const float4 *>(a.rots + 4 * (size_t)i);
+            }
+        }
+    }
 
     float px = 0, py = 0, pz = 0, vx = 0, vy = 0, vz = 0;
     bool vis = false;
@@ -139,10 +166,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 #pragma unroll
             for (int k = 0; k < 6; k++) cv.c[k] = a.cov3Dp[6 * (size_t)i + k];
         } else {
-            float s[3] = {a.scales[3 * (size_t)i], a.scales[3 * (size_t)i + 1], a.scales[3 * (size_t)i + 2]};
-            const float4 qv = *reinterpret_cast<const float4 *>(a.rots + 4 * (size_t)i);
-            float q[4] = {qv.x, qv.y, qv.z, qv.w};
-            cov3d_from_scale_rot(s, a.mod, q, cv);
+            if (SHDEG < 0) {
+                s_in[0] = a.scales[3 * (size_t)i]; s_in[1] = a.scales[3 * (size_t)i + 1]; s_in[2] = a.scales[3 * (size_t)i + 2];
+                q_in = *reinterpret_cast<const float4 *>(a.rots + 4 * (size_t)i);
+            }
+            float q[4] = {q_in.x, q_in.y, q_in.z, q_in.w};
+            cov3d_from_scale_rot(s_in, a.mod, q, cv);
         }
         const float fx = (float)a.W / (2.f * a.tanx), fy = (float)a.H / (2.f * a.tany);
         Ewa e;
@@ -163,13 +192,27 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         piy = ((ndcy + 1.f) * a.H - 1.f) * 0.5f;
         tile_rect(pix, piy, rad, a.gx, a.gy, minx, miny, maxx, maxy);
         if ((maxx - minx) * (maxy - miny) == 0) vis = false;
-        opp = a.opac[i] * hconv;
+        opp = (SHDEG >= 0 ? op_in : a.opac[i]) * hconv;
     }
 
     // ---- colour
     float rgb[3] = {0, 0, 0};
     unsigned clampbits = 0;
-    if (a.shs) {
+    if (SHDEG >= 0) {
+        float *wl = sh_lds + wave * (WAVE * SH_PITCH);
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+            const int idx = lane + WAVE * j;
+            const int r = idx / NQ, c = idx - r * NQ;
+            *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = stg[j];
+        }
+        __syncthreads();
+        if (vis) {
+            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            sh_colour<(SHDEG >= 0 ? SHDEG : 0)>(wl + lane * SH_PITCH, dx * inv, dy * inv, dz * inv, rgb, clampbits);
+        }
+    } else if (a.shs) {
         const int nb = (a.D + 1) * (a.D + 1);
         const int rowf = a.M * 3;                 // floats per Gaussian in memory
         float *wl = sh_lds + wave * (WAVE * SH_PITCH);
@@ -304,7 +347,26 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
     }
     const int area = r > 0 ? (maxx - minx) * (maxy - miny) : 0;
     int cx = minx, cy = miny;
-    for (int k = 0; __any(k < area); k++) {
+    // the first four tiles of every lane (covers 2x2 footprints, the common case): four cursor atomics in
+    // flight, one memory round trip
+    AggTicket tk[4];
+    int tl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const bool act = k < area;
+        tl[k] = act ? cy * gx + cx : -1;
+        tk[k] = wave_aggregated_issue(tile_cursor, tl[k], act);
+        if (++cx == maxx) { cx = minx; cy++; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t rank = wave_aggregated_finish(tk[k]);
+        if (k < area) {
+            const uint64_t slot = (uint64_t)tile_offset[tl[k]] + rank;
+            if (slot < capacity) keys[slot] = key;
+        }
+    }
+    for (int k = 4; __any(k < area); k++) {
         const bool act = k < area;
         const int t = act ? cy * gx + cx : -1;
         const uint32_t rank = wave_aggregated_inc<true>(tile_cursor, t, act);
@@ -351,20 +413,21 @@ template <int THREADS>
 __device__ void lds_bitonic(uint64_t *s, int m, int k0, int j0, bool first_mirror, int tid)
 {
     int prev = 1 << 30;
-    for (int k = k0; k <= m; k <<= 1) {
-        const int hk = k >> 1;
+    for (int k = k0, lk = 31 - __builtin_clz(k0); k <= m; k <<= 1, lk++) {   // all sizes are powers of two:
+        const int hk = k >> 1;                                                // index math with shifts/masks only
         if (k > k0 || first_mirror) {
             stage_sync<THREADS>(k, prev);
             for (int i = tid; i < (m >> 1); i += THREADS) {
-                int blk = i / hk, off = i - blk * hk;
-                int lo = blk * k + off, hi = blk * k + k - 1 - off;
+                const int blk = i >> (lk - 1), off = i & (hk - 1);
+                const int lo = (blk << lk) + off, hi = (blk << lk) + k - 1 - off;
                 ce(s[lo], s[hi]);
             }
         }
-        for (int j = (k > k0 || first_mirror) ? (k >> 2) : j0; j >= 1; j >>= 1) {
+        int j = (k > k0 || first_mirror) ? (k >> 2) : j0;
+        for (int lj = j > 0 ? 31 - __builtin_clz(j) : 0; j >= 1; j >>= 1, lj--) {
             stage_sync<THREADS>(2 * j, prev);
             for (int i = tid; i < (m >> 1); i += THREADS) {
-                int lo = 2 * j * (i / j) + (i % j);
+                const int lo = ((i >> lj) << (lj + 1)) + (i & (j - 1));
                 ce(s[lo], s[lo + j]);
             }
         }
@@ -563,7 +626,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.geom = geom; pa.tile_count = img.tile_count;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
-    GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<<<pblocks, BLOCK, 0, stream>>>(pa));
+    const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (A->cov3D_precomp || (((uintptr_t)A->rotations) & 15u) == 0);
+    switch (sh_fast ? A->D : -1) {
+    case 0: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<0><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    case 1: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<1><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    case 2: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<2><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    case 3: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<3><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    default: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<-1><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    }
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len();
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,

@@ -27,17 +27,33 @@ class HipMeshMixin:
             self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
         self.alpha = alpha
         self._xyz = xyz
-        with torch.no_grad():
-            tri = self.vertices[self.faces]
-        self.triangles = tri
-        self._hip_own_triangles = tri
+        # `triangles` is only read by save_ply and the animated renderers: gathered on first access
+        self.__dict__.pop("_hip_tri", None)
+        self._hip_tri_external = None
         self._hip_cached = (scaling, rotation, scaling_act, rotation_unit)
 
+    @property
+    def triangles(self):
+        ext = self.__dict__.get("_hip_tri_external")
+        if ext is not None:
+            return ext
+        tri = self.__dict__.get("_hip_tri")
+        if tri is None and getattr(self, "vertices", None) is not None and getattr(self, "faces", None) is not None \
+                and torch.is_tensor(self.faces) and self.faces.numel():
+            with torch.no_grad():
+                tri = self.vertices[self.faces]
+            self.__dict__["_hip_tri"] = tri
+        return tri
+
+    @triangles.setter
+    def triangles(self, value):
+        # a renderer / loader replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72)
+        self.__dict__["_hip_tri_external"] = value
+
     def prepare_scaling_rot(self, *unused):
-        tri = getattr(self, "triangles", None)
-        own = getattr(self, "_hip_own_triangles", None)
+        tri = self.__dict__.get("_hip_tri_external")
         cached = getattr(self, "_hip_cached", None)
-        if tri is not None and tri is not own:
+        if tri is not None:
             # a renderer replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72-73):
             # derive scale / rotation from those triangles
             _, _, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
