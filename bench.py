@@ -13,6 +13,7 @@ launch stream), `kernels` (every kernel), `cpu_baseline` (the C oracle port on t
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -94,6 +95,9 @@ def main():
     ap.add_argument("--state", default="trained", choices=["trained", "init"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--mode", default="train", choices=["train", "animate"],
+                    help="train: the headline fwd+bwd step; animate: BASELINE config 5 style forward-only renders with per-frame "
+                         "vertex animation and on-device re-derivation of scale/rotation (secondary line, not the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +142,34 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(device)
+
+    if args.mode == "animate":
+        from games_hip.render import render_animated
+        frame = [0]
+
+        def animate_step():
+            with torch.no_grad():
+                t = 0.05 * frame[0]
+                frame[0] += 1
+                new_v = model.vertices * (1.0 + 0.05 * math.sin(t))           # scripts/render_time_animated.py:68-87 style
+                render_animated(None, new_v[model.faces], cam, model, pipe, bg)
+        for _ in range(args.warmup):
+            animate_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            animate_step()
+        sync()
+        el = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({"metric": "renders/s (fwd only, per-frame vertex animation + fused face->Gaussian + raster)",
+                              "value": round(world * args.steps / el, 2), "unit": "renders/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 4),
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"{args.workload}/{args.state} animate, {scene.num_gaussians} Gaussians, {size}x{size}"}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     for _ in range(args.warmup):
         step()

@@ -84,6 +84,55 @@ class HipMeshMixin:
         return torch.nn.functional.normalize(self._rotation)
 
 
+class HipMultiMeshMixin:
+    """Drop-in for GaussianMultiMeshModel.update_alpha / _calc_xyz / prepare_scaling_rot
+    (games/multi_mesh_splatting/scene/gaussian_multi_mesh_model.py:99-199): the per-mesh python loop and the
+    torch.cat of its results become ONE launch over the concatenated meshes (faces re-indexed by the vertex
+    offsets, splat ranges as CSR because every mesh may carry a different number of splats per face).
+    Host class provides the reference's list attributes: vertices[i], faces[i], _alpha[i] [F_i,S_i,3], _scale[i] [P_i,1]."""
+
+    def _hip_topology(self):
+        key = tuple((int(f.shape[0]), int(a.shape[1]), int(v.shape[0])) for f, a, v in zip(self.faces, self._alpha, self.vertices))
+        cached = self.__dict__.get("_hip_topo")
+        if cached is not None and cached[0] == key:
+            return cached[1:]
+        device = self.vertices[0].device
+        faces, counts = [], []
+        voff = 0
+        for f, a, v in zip(self.faces, self._alpha, self.vertices):
+            faces.append(f.to(device).long() + voff)
+            counts.append(torch.full((int(f.shape[0]),), int(a.shape[1]), dtype=torch.int64))
+            voff += int(v.shape[0])
+        counts = torch.cat(counts)
+        fso = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)]).to(torch.int32)
+        sf = torch.repeat_interleave(torch.arange(counts.numel(), dtype=torch.int32), counts)
+        topo = (torch.cat(faces).contiguous(), fso.to(device), sf.to(device))
+        self.__dict__["_hip_topo"] = (key,) + topo
+        return topo
+
+    def update_alpha(self):
+        faces, fso, sf = self._hip_topology()
+        V = torch.cat(list(self.vertices))
+        A = torch.cat([a.reshape(-1, 3) for a in self._alpha])
+        Sc = torch.cat(list(self._scale))
+        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
+            V, faces, A, Sc, "relu", face_splat_offset=fso, splat_face=sf, fused_activations=True)
+        sizes = [a.shape[0] * a.shape[1] for a in self._alpha]
+        self.alpha = [x.reshape(a.shape) for x, a in zip(torch.split(alpha, sizes), self._alpha)]
+        self._xyz = xyz
+        self._hip_cached = (scaling, rotation, scaling_act, rotation_unit)
+
+    def prepare_scaling_rot(self, *unused):
+        if self.__dict__.get("_hip_cached") is None:
+            self.update_alpha()
+        scaling, rotation, scaling_act, rotation_unit = self._hip_cached
+        self._scaling, self._rotation = scaling, rotation
+        self._hip_activated = (scaling, rotation, scaling_act, rotation_unit)
+
+    get_scaling = HipMeshMixin.get_scaling
+    get_rotation = HipMeshMixin.get_rotation
+
+
 class HipGaussianMeshModel(HipMeshMixin):
     """Stand-alone model (no dependency on the reference tree) used by bench.py / tests."""
 

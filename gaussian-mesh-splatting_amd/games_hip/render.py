@@ -98,3 +98,23 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth_image}
+
+
+def render_animated(idxs, triangles, viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
+                    override_color=None):
+    """renderer/gaussian_animated_renderer/__init__.py:21-121: the mesh is deformed per frame, centres follow
+    `pc.alpha @ triangles` (:61-67) and scale / rotation are re-derived from the deformed triangles (:72-73).
+    With the fused op that is one kernel: assigning `pc.triangles` and calling `prepare_scaling_rot()` runs
+    the op on the explicit triangles; its xyz output is `alpha @ triangles`."""
+    from .mesh_op import triangles_to_gaussians
+    pc.triangles = triangles
+    _, xyz, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
+        triangles, pc._alpha, pc._scale, getattr(pc, "alpha_mode", "relu"), fused_activations=True)
+    pc._scaling, pc._rotation = scaling, rotation
+    pc._hip_activated = (scaling, rotation, scaling_act, rotation_unit)
+
+    class _View:       # same model, centres from the deformed mesh (the reference passes them as means3D)
+        def __getattr__(self, name):
+            return getattr(pc, name)
+        get_xyz = xyz
+    return render(viewpoint_camera, _View(), pipe, bg_color, scaling_modifier, override_color)
