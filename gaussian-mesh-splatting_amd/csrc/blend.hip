@@ -101,6 +101,9 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const Sp
         if (idx < u.end) recs[tid] = rec[(uint32_t)g.keys[idx]];
         __syncthreads();
         const int cnt = (int)min((uint32_t)BLOCK, u.end - base);
+        // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact
+        // value: a quadrant whose pixels are all there (or outside the image) stops evaluating
+        if (__all(Tl < T_MIN || !p.inside)) continue;
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
             while (mask) {

@@ -41,6 +41,8 @@ void set_error(const char *fmt, ...)
 }
 
 // ------------------------------------------------------------------------------------ K1
+constexpr int SMALL_AREA = 64; // tiles a lane walks itself (lock-step, aggregated atomics); larger footprints are expanded by the whole wave
+constexpr int EMIT_FLIGHT = 4; // cursor atomics kept in flight per lane in emit
 constexpr int SH_PITCH = 52;   // dwords per LDS row: 48 used; 52*l mod 64 hits 16 distinct 16-B slots
 
 struct PreArgs {
@@ -265,15 +267,29 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         a.geom.clamped[i] = (uint8_t)clampbits;
         a.radii[i] = (int)rad;
     }
-    // tile coverage counts: all 64 lanes walk their rectangles in lock-step, one aggregated atomic
-    // per distinct tile per step
+    // tile coverage counts.  Footprints up to SMALL_AREA tiles: the 64 lanes walk their rectangles in
+    // lock-step with one aggregated atomic per distinct tile per step (neighbouring splats share tiles, so
+    // aggregation removes most atomics).  Very large footprints: the whole wave expands ONE splat's
+    // rectangle at a time, a tile per lane.
     const int rw = maxx - minx;
     const int area = vis ? rw * (maxy - miny) : 0;
+    const bool small = area <= SMALL_AREA;
     int cx = minx, cy = miny;
-    for (int k = 0; __any(k < area); k++) {
-        const bool act = k < area;
+    for (int k = 0; __any(small && k < area); k++) {
+        const bool act = small && k < area;
         wave_aggregated_inc<false>(a.tile_count, act ? cy * a.gx + cx : -1, act);
         if (++cx == maxx) { cx = minx; cy++; }
+    }
+    uint64_t big = __ballot(!small);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bminx = __builtin_amdgcn_readlane(minx, src), bminy = __builtin_amdgcn_readlane(miny, src);
+        const int brw = __builtin_amdgcn_readlane(rw, src), barea = __builtin_amdgcn_readlane(area, src);
+        for (int k = lane; k < barea; k += WAVE) {
+            const int ty = k / brw, tx = k - ty * brw;
+            atomicAdd(&a.tile_count[(bminy + ty) * a.gx + bminx + tx], 1u);
+        }
     }
 }
 
@@ -345,36 +361,48 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
         tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
         key = ((uint64_t)__float_as_uint(geom.depth[i]) << 32) | (uint32_t)i;
     }
-    const int area = r > 0 ? (maxx - minx) * (maxy - miny) : 0;
+    const int rw = maxx - minx;
+    const int area = r > 0 ? rw * (maxy - miny) : 0;
+    const bool small = area <= SMALL_AREA;
+    const int lane = threadIdx.x & 63;
     int cx = minx, cy = miny;
-    // the first four tiles of every lane (covers 2x2 footprints, the common case): four cursor atomics in
-    // flight, one memory round trip
-    AggTicket tk[4];
-    int tl[4];
+    // footprints up to SMALL_AREA tiles: lock-step walk, EMIT_FLIGHT aggregated cursor atomics in flight per
+    // trip (one memory round trip per EMIT_FLIGHT tiles)
+    for (int k0 = 0; __any(small && k0 < area); k0 += EMIT_FLIGHT) {
+        AggTicket tk[EMIT_FLIGHT];
+        int tl[EMIT_FLIGHT];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const bool act = k < area;
-        tl[k] = act ? cy * gx + cx : -1;
-        tk[k] = wave_aggregated_issue(tile_cursor, tl[k], act);
-        if (++cx == maxx) { cx = minx; cy++; }
-    }
+        for (int k = 0; k < EMIT_FLIGHT; k++) {
+            const bool act = small && (k0 + k) < area;
+            tl[k] = act ? cy * gx + cx : -1;
+            tk[k] = wave_aggregated_issue(tile_cursor, tl[k], act);
+            if (++cx == maxx) { cx = minx; cy++; }
+        }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const uint32_t rank = wave_aggregated_finish(tk[k]);
-        if (k < area) {
-            const uint64_t slot = (uint64_t)tile_offset[tl[k]] + rank;
-            if (slot < capacity) keys[slot] = key;
+        for (int k = 0; k < EMIT_FLIGHT; k++) {
+            const uint32_t rank = wave_aggregated_finish(tk[k]);
+            if (small && (k0 + k) < area) {
+                const uint64_t slot = (uint64_t)tile_offset[tl[k]] + rank;
+                if (slot < capacity) keys[slot] = key;
+            }
         }
     }
-    for (int k = 4; __any(k < area); k++) {
-        const bool act = k < area;
-        const int t = act ? cy * gx + cx : -1;
-        const uint32_t rank = wave_aggregated_inc<true>(tile_cursor, t, act);
-        if (act) {
-            const uint64_t slot = (uint64_t)tile_offset[t] + rank;
-            if (slot < capacity) keys[slot] = key;
+    // large footprints: the wave expands one splat at a time, a tile per lane
+    uint64_t big = __ballot(!small);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bminx = __builtin_amdgcn_readlane(minx, src), bminy = __builtin_amdgcn_readlane(miny, src);
+        const int brw = __builtin_amdgcn_readlane(rw, src), barea = __builtin_amdgcn_readlane(area, src);
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, src);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src);
+        const uint64_t bkey = ((uint64_t)khi << 32) | klo;
+        for (int k = lane; k < barea; k += WAVE) {
+            const int ty = k / brw, tx = k - ty * brw;
+            const int t = (bminy + ty) * gx + bminx + tx;
+            const uint64_t slot = (uint64_t)tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (slot < capacity) keys[slot] = bkey;
         }
-        if (++cx == maxx) { cx = minx; cy++; }
     }
 }
 
