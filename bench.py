@@ -113,7 +113,7 @@ def main():
 
     from diff_gaussian_rasterization import _lib, last_stats
     from games_hip import synthetic as syn
-    from games_hip.ddp import allreduce_gradients
+    from games_hip.ddp import OverlappedGradAllReduce
     from games_hip.model import HipGaussianMeshModel
     from games_hip.render import PipelineParams, render
 
@@ -125,6 +125,7 @@ def main():
     pipe = PipelineParams()
     params = model.parameters()
     inv_norm = 1.0 / (3.0 * size * size)
+    reducer = OverlappedGradAllReduce(params, world) if world > 1 else None
 
     def step():
         model.update_alpha()
@@ -133,8 +134,8 @@ def main():
         with torch.no_grad():
             grad = (image - 0.5) * inv_norm              # dL/dcolor = (image - 0.5) / (3HW), dense
         image.backward(grad)
-        if world > 1:
-            allreduce_gradients(params, world)
+        if reducer is not None:
+            reducer.finish()      # collectives were started from autograd hooks during backward
         for p in params:
             p.grad = None
 

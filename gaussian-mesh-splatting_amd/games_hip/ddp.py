@@ -38,3 +38,36 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, average: boo
         w.wait()
     if average:
         torch._foreach_div_(grads, float(world))
+
+
+class OverlappedGradAllReduce:
+    """Starts each parameter's all-reduce from a post-accumulate-grad hook, i.e. the moment autograd has
+    produced that gradient: the 54 MB SH-rest reduction (ready right after the rasterizer's
+    preprocess-backward kernel) travels over xGMI while the mesh->Gaussian backward still runs.
+    `finish()` waits for the collectives and applies the 1/world averaging.  Semantics are identical to
+    `allreduce_gradients` (tested in tests/test_ddp_cpu.py)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True):
+        self.params = [p for p in params]
+        self.world, self.average = world, average
+        self._works, self._grads, self._handles = [], [], []
+        if world > 1 and dist.is_initialized():
+            for p in self.params:
+                self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def _hook(self, p: torch.Tensor) -> None:
+        if p.grad is not None:
+            self._grads.append(p.grad)
+            self._works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+
+    def finish(self) -> None:
+        for w in self._works:
+            w.wait()
+        if self.average and self._grads:
+            torch._foreach_div_(self._grads, float(self.world))
+        self._works, self._grads = [], []
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
+        self._handles = []

@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from games_hip.ddp import allreduce_gradients, shard_views
+from games_hip.ddp import OverlappedGradAllReduce, allreduce_gradients, shard_views
 
 
 def _free_port():
@@ -34,9 +34,17 @@ def _worker(rank, world, port, q):
         params[3].grad = None                              # a parameter without gradient is skipped
         allreduce_gradients(params, world, average=True)
         out = [None if p.grad is None else p.grad.clone() for p in params]
+        # hook-driven variant: gradients produced by autograd are reduced as they appear
+        params2 = [torch.randn(s, generator=torch.Generator().manual_seed(1234)).requires_grad_(True) for s in shapes[:3]]
+        red = OverlappedGradAllReduce(params2, world)
+        loss = sum((p * l).sum() for p, l in zip(params2, local[:3]))
+        loss.backward()
+        red.finish()
+        red.remove()
+        out2 = [p.grad.clone() for p in params2]
         # camera sharding: same permutation everywhere, disjoint cover of the views within an epoch
         views = [shard_views(8, step, rank, world, seed=7) for step in range(4)]
-        q.put((rank, local, out, views))
+        q.put((rank, local, out, views, out2))
     finally:
         dist.destroy_process_group()
 
@@ -65,7 +73,10 @@ def test_allreduce_equals_mean_of_single_view_gradients():
         res = _run_world(world)
     except Exception:          # e.g. the probed rendezvous port was taken in between: one retry
         res = _run_world(world)
-    (_, l0, o0, v0), (_, l1, o1, v1) = res
+    (_, l0, o0, v0, h0), (_, l1, o1, v1, h1) = res
+    for k in range(3):
+        torch.testing.assert_close(h0[k], (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(h1[k], (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-7)
     for k in range(len(l0)):
         if k == 3:
             assert o0[k] is None and o1[k] is None
