@@ -25,14 +25,14 @@ constexpr int SH_PITCH_B = 52;
 
 struct PreBwdArgs {
     int P, D, M, W, H;
-    const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
+    const float *means3D, *shs, *shs_rest, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
     float mod, tanx, tany;
     int aa;
     const int *radii;
     const uint8_t *clamped;
     const float *accum;     // [P,16] gradient records filled by blend_bwd
     float *dL_dmean2D, *dL_dopacity, *dL_dcolors;
-    float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dscales, *dL_drots;
+    float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscales, *dL_drots;
 };
 
 // SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
@@ -116,7 +116,34 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     const int rows = min(WAVE, a.P - g0);
 
     // stage the SH rows of this wave's 64 Gaussians into LDS (coalesced)
-    if (use_sh) {
+    const bool split = a.shs_rest != nullptr;         // DC [P,3] + REST [P,45] stored separately (M = 16)
+    constexpr int RESTF = 45;
+    if (use_sh && split) {
+        if (__any(vis)) {
+            for (int e = lane; e < rows * 3; e += WAVE) wl[(e / 3) * SH_PITCH_B + (e % 3)] = a.shs[(size_t)g0 * 3 + e];
+            const int need = nb * 3 - 3;              // floats of each REST row the active degree uses
+            if (need == RESTF) {                      // full rows: flat float4 copy of the wave's contiguous block
+                const float *sp = a.shs_rest + (size_t)g0 * RESTF;
+                const int nfl = rows * RESTF;
+                for (int e4 = lane * 4; e4 < nfl; e4 += WAVE * 4) {
+                    float v4[4];
+                    if (e4 + 3 < nfl) { const float4 v = *reinterpret_cast<const float4 *>(sp + e4); v4[0] = v.x; v4[1] = v.y; v4[2] = v.z; v4[3] = v.w; }
+                    else { for (int t = 0; t < 4; t++) v4[t] = e4 + t < nfl ? sp[e4 + t] : 0.f; }
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int e = e4 + t;
+                        if (e < nfl) wl[(e / RESTF) * SH_PITCH_B + 3 + (e % RESTF)] = v4[t];
+                    }
+                }
+            } else {
+                for (int e = lane; e < rows * need; e += WAVE) {
+                    const int r = e / need, c = e - r * need;
+                    wl[r * SH_PITCH_B + 3 + c] = a.shs_rest[((size_t)g0 + r) * RESTF + c];
+                }
+            }
+        }
+        __syncthreads();
+    } else if (use_sh) {
         if (vec_ok) {
             if (__any(vis)) {
                 const int rowq = rowf / 4;
@@ -277,7 +304,26 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     }
 
     // ---- SH gradient rows: zero what was not written, then stream the wave's rows out coalesced
-    if (use_sh) {
+    if (use_sh && split) {
+        for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < 12; q++)
+            *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        if (rows > 0) {
+            for (int e = lane; e < rows * 3; e += WAVE) a.dL_dsh[(size_t)g0 * 3 + e] = wl[(e / 3) * SH_PITCH_B + (e % 3)];
+            float *dp = a.dL_dsh_rest + (size_t)g0 * RESTF;
+            const int nfl = rows * RESTF;
+            for (int e4 = lane * 4; e4 < nfl; e4 += WAVE * 4) {
+                float v4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int e = e4 + t;
+                    v4[t] = e < nfl ? wl[(e / RESTF) * SH_PITCH_B + 3 + (e % RESTF)] : 0.f;
+                }
+                if (e4 + 3 < nfl) *reinterpret_cast<float4 *>(dp + e4) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                else for (int t = 0; t < 4; t++) if (e4 + t < nfl) dp[e4 + t] = v4[t];
+            }
+        }
+    } else if (use_sh) {
         const int used = vis ? nb * 3 : 0;
         if (vec_ok) {
             // chunks the SH backward did not write (culled Gaussian, or coefficients above the active degree)
@@ -328,7 +374,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     const bool sr = A->scales && A->rotations;
     if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
         !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || !A->dL_dopacity || (A->colors_precomp && !A->dL_dcolors) ||
-        !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
+        !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || (A->shs_rest && (!A->dL_dsh_rest || A->M != 16)) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
         (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
         (A->cov3D_precomp && !A->dL_dcov3D)) {
         set_error("gms_rasterize_backward: null or inconsistent pointer arguments");
@@ -358,12 +404,12 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     }
     PreBwdArgs p;
     p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;
-    p.means3D = A->means3D; p.shs = A->shs; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
+    p.means3D = A->means3D; p.shs = A->shs; p.shs_rest = A->shs_rest; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.dL_dmean2D = A->dL_dmeans2D;
     p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
-    p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
+    p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
     return GMS_OK;

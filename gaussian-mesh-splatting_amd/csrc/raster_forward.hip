@@ -47,7 +47,7 @@ constexpr int SH_PITCH = 52;   // dwords per LDS row: 48 used; 52*l mod 64 hits 
 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
-    const float *means3D, *shs, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
+    const float *means3D, *shs, *shs_rest, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
     float mod, tanx, tany;
     int aa;
     int *radii;
@@ -112,7 +112,7 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
     }
 }
 
-template <int SHDEG>
+template <int SHDEG, bool SPLIT>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {
 #pragma clang fp contract(off)
@@ -124,19 +124,45 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     // Fast path: every global load of this thread is issued before anything is computed, so the
     // position / scale / rotation / opacity / SH round trips overlap instead of chaining.
     constexpr int NQ = SHDEG >= 0 ? ((SHDEG + 1) * (SHDEG + 1) * 3 + 3) / 4 : 1;
+    constexpr int NB3 = SHDEG >= 0 ? (SHDEG + 1) * (SHDEG + 1) * 3 : 3;      // floats needed per row
+    constexpr int RESTF = 45;                                                 // floats per row of shs_rest (M = 16)
     float4 stg[NQ];
+    float dcv[3] = {0.f, 0.f, 0.f};
     float s_in[3] = {0.f, 0.f, 0.f};
     float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
     float op_in = 0.f;
     if (SHDEG >= 0) {
         const int g0 = blockIdx.x * BLOCK + wave * WAVE;
         const int rows = min(WAVE, a.P - g0);
-        const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
+        if (!SPLIT) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
 #pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const int idx = lane + WAVE * j;
-            const int r = idx / NQ, c = idx - r * NQ;
-            stg[j] = idx < rows * NQ ? src[(size_t)r * 12 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NQ; j++) {
+                const int idx = lane + WAVE * j;
+                const int r = idx / NQ, c = idx - r * NQ;
+                stg[j] = idx < rows * NQ ? src[(size_t)r * 12 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            // split storage: the wave's DC block (rows*3 floats) and REST block (rows*45 floats) are each
+            // contiguous; both are fetched with flat coalesced loads and re-assembled into the same
+            // [k][c] LDS rows the fused layout uses
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int e = lane + WAVE * j;
+                dcv[j] = e < rows * 3 ? a.shs[(size_t)g0 * 3 + e] : 0.f;
+            }
+            if (SHDEG == 3) {
+                const float *sp = a.shs_rest + (size_t)g0 * RESTF;       // g0 % 64 == 0: 16-byte aligned
+                const float4 *src = reinterpret_cast<const float4 *>(sp);
+                const int nfl = rows * RESTF;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) {
+                    const int e4 = (lane + WAVE * j) * 4;
+                    if (e4 + 3 < nfl) stg[j] = src[lane + WAVE * j];
+                    else stg[j] = make_float4(e4 < nfl ? sp[e4] : 0.f, e4 + 1 < nfl ? sp[e4 + 1] : 0.f,
+                                              e4 + 2 < nfl ? sp[e4 + 2] : 0.f, 0.f);
+                }
+            }
         }
         if (valid) {
             op_in = a.opac[i];
@@ -202,11 +228,39 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     unsigned clampbits = 0;
     if (SHDEG >= 0) {
         float *wl = sh_lds + wave * (WAVE * SH_PITCH);
+        if (!SPLIT) {
 #pragma unroll
-        for (int j = 0; j < NQ; j++) {
-            const int idx = lane + WAVE * j;
-            const int r = idx / NQ, c = idx - r * NQ;
-            *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = stg[j];
+            for (int j = 0; j < NQ; j++) {
+                const int idx = lane + WAVE * j;
+                const int r = idx / NQ, c = idx - r * NQ;
+                *reinterpret_cast<float4 *>(wl + r * SH_PITCH + c * 4) = stg[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int e = lane + WAVE * j;
+                wl[(e / 3) * SH_PITCH + (e % 3)] = dcv[j];
+            }
+            if (SHDEG == 3) {
+#pragma unroll
+                for (int j = 0; j < NQ; j++) {
+                    const float v4[4] = {stg[j].x, stg[j].y, stg[j].z, stg[j].w};
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const int e = (lane + WAVE * j) * 4 + t;       // flat element of the wave's REST block
+                        if (e < WAVE * RESTF) wl[(e / RESTF) * SH_PITCH + 3 + (e % RESTF)] = v4[t];
+                    }
+                }
+            } else if (SHDEG > 0) {
+                // low active degree: only the first NB3-3 floats of each REST row are needed
+                const int g0 = blockIdx.x * BLOCK + wave * WAVE;
+                const int rows = min(WAVE, a.P - g0);
+                constexpr int need = NB3 - 3;
+                for (int e = lane; e < rows * need; e += WAVE) {
+                    const int r = e / need, c = e - r * need;
+                    wl[r * SH_PITCH + 3 + c] = a.shs_rest[((size_t)g0 + r) * RESTF + c];
+                }
+            }
         }
         __syncthreads();
         if (vis) {
@@ -649,19 +703,31 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
 
     PreArgs pa;
     pa.P = P; pa.D = A->D; pa.M = A->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
-    pa.means3D = A->means3D; pa.shs = A->shs; pa.colors = A->colors_precomp; pa.opac = A->opacities;
+    pa.means3D = A->means3D; pa.shs = A->shs; pa.shs_rest = A->shs_rest; pa.colors = A->colors_precomp; pa.opac = A->opacities;
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.geom = geom; pa.tile_count = img.tile_count;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
-    const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (A->cov3D_precomp || (((uintptr_t)A->rotations) & 15u) == 0);
-    switch (sh_fast ? A->D : -1) {
-    case 0: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<0><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
-    case 1: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<1><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
-    case 2: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<2><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
-    case 3: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<3><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
-    default: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, preprocess_fwd_kernel<-1><<<pblocks, BLOCK, 0, stream>>>(pa)); break;
+    const bool split = A->shs_rest != nullptr;
+    const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
+                         (A->cov3D_precomp || (((uintptr_t)A->rotations) & 15u) == 0);
+    if (split && !sh_fast) {
+        set_error("split SH storage (shs_rest) needs M == 16 and 16-byte aligned pointers");
+        return GMS_ERR_INVALID_ARGUMENT;
     }
+#define GMS_PRE(DEG, SP) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<DEG, SP><<<pblocks, BLOCK, 0, stream>>>(pa)))
+    switch ((sh_fast ? A->D : -1) * 2 + (split ? 1 : 0)) {
+    case 0: GMS_PRE(0, false); break;
+    case 1: GMS_PRE(0, true); break;
+    case 2: GMS_PRE(1, false); break;
+    case 3: GMS_PRE(1, true); break;
+    case 4: GMS_PRE(2, false); break;
+    case 5: GMS_PRE(2, true); break;
+    case 6: GMS_PRE(3, false); break;
+    case 7: GMS_PRE(3, true); break;
+    default: GMS_PRE(-1, false); break;
+    }
+#undef GMS_PRE
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len();
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,

@@ -30,7 +30,32 @@ import torch.nn as nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats"]
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats", "SplitSH"]
+
+
+class SplitSH:
+    """SH coefficients kept as the reference stores them: `_features_dc` [P,1,3] and `_features_rest` [P,M-1,3]
+    (scene/gaussian_model.py:107-111 concatenates them into a fresh 57.6 MB tensor every iteration, and autograd
+    splits the gradient back with two more copies).  A model's `get_features` may return this object instead
+    of the concatenation: `GaussianRasterizer` reads both blocks in place and writes both gradients in place.
+    Any other consumer (e.g. the reference's `convert_SHs_python` branch, renderer/gaussian_renderer/__init__.py:83)
+    can treat it as the concatenated tensor: attribute access falls through to a lazily built `torch.cat`."""
+
+    def __init__(self, dc: torch.Tensor, rest: torch.Tensor):
+        self.dc, self.rest = dc, rest
+        self._full = None
+
+    def full(self) -> torch.Tensor:
+        if self._full is None:
+            self._full = torch.cat((self.dc, self.rest), dim=1)
+        return self._full
+
+    @property
+    def shape(self):
+        return torch.Size((self.dc.shape[0], self.dc.shape[1] + self.rest.shape[1], self.dc.shape[2]))
+
+    def __getattr__(self, name):          # only reached for attributes SplitSH itself does not define
+        return getattr(self.full(), name)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -92,14 +117,19 @@ class _Scratch:
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    if isinstance(sh, SplitSH):
+        if sh.dc.shape[1] == 1 and sh.rest.shape[1] == 15 and sh.dc.is_cuda:
+            return _RasterizeGaussians.apply(means3D, means2D, sh.dc, colors_precomp, opacities, scales, rotations,
+                                             cov3Ds_precomp, raster_settings, sh.rest)
+        sh = sh.full()
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+                                     cov3Ds_precomp, raster_settings, None)
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, sh_rest=None):
         rs = raster_settings
         lib = _lib.load()
         _lib.require_gpu(means3D, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)
@@ -120,6 +150,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         if sh.numel() and (sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3):
             raise RuntimeError("sh must have dimensions (num_points, num_coeffs, 3)")
         M = int(sh.shape[1]) if sh.numel() else 0
+        if sh_rest is not None:                 # split storage: sh = DC block, sh_rest = the other M-1 coefficients
+            sh_rest = _f32c(sh_rest)
+            M = int(sh.shape[1] + sh_rest.shape[1])
 
         color = torch.empty((3, H, W), dtype=torch.float32, device=device)
         invdepth = torch.empty((1, H, W), dtype=torch.float32, device=device)
@@ -134,7 +167,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 hint = int(prev * 1.25) + 4096
         a = _lib.RasterForwardArgs(
             P=P, D=int(rs.sh_degree), M=M, width=W, height=H,
-            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh),
+            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh), shs_rest=_lib.ptr(sh_rest),
             colors_precomp=_lib.ptr(colors_precomp), opacities=_lib.ptr(opacities), scales=_lib.ptr(scales),
             rotations=_lib.ptr(rotations), cov3D_precomp=_lib.ptr(cov3Ds_precomp), viewmatrix=_lib.ptr(view),
             projmatrix=_lib.ptr(proj), campos=_lib.ptr(campos), scale_modifier=float(rs.scale_modifier),
@@ -158,7 +191,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.binning_capacity = hint if (hint > 0 and num_rendered <= hint) else max(int(num_rendered), 1)
         ctx.M = M
         empty = torch.empty(0, device=device)
-        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
+        ctx.split = sh_rest is not None
+        ctx.save_for_backward(means3D, sh, sh_rest if sh_rest is not None else empty, colors_precomp, opacities, scales,
+                              rotations, cov3Ds_precomp, radii,
                               scratch.tensors.get("geom", empty), scratch.tensors.get("binning", empty),
                               scratch.tensors.get("image", empty), bg, view, proj, campos)
         ctx.mark_non_differentiable(radii)
@@ -168,7 +203,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     def backward(ctx, grad_color, _grad_radii, grad_invdepth):
         lib = _lib.load()
         rs = ctx.raster_settings
-        (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, image,
+        (means3D, sh, sh_rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii, geom, binning, image,
          bg, view, proj, campos) = ctx.saved_tensors
         device = means3D.device
         P = int(means3D.shape[0])
@@ -185,7 +220,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         dL_dopacity = torch.empty(opacities.shape, dtype=torch.float32, device=device)
         dL_dcolors = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_sh else None
         dL_dmeans3D = torch.empty((P, 3), dtype=torch.float32, device=device)
-        dL_dsh = torch.empty((P, M, 3), dtype=torch.float32, device=device) if use_sh else None
+        dL_dsh = torch.empty(sh.shape, dtype=torch.float32, device=device) if use_sh else None
+        dL_dsh_rest = torch.empty(sh_rest.shape, dtype=torch.float32, device=device) if ctx.split else None
         dL_dscales = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_cov else None
         dL_drot = torch.empty((P, 4), dtype=torch.float32, device=device) if not use_cov else None
         dL_dcov3D = torch.empty((P, 6), dtype=torch.float32, device=device) if use_cov else None
@@ -193,7 +229,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         a = _lib.RasterBackwardArgs(
             P=P, D=int(rs.sh_degree), M=M, width=W, height=H, num_rendered=ctx.num_rendered,
             binning_capacity=ctx.binning_capacity,
-            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh), colors_precomp=_lib.ptr(colors_precomp),
+            background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh),
+            shs_rest=_lib.ptr(sh_rest) if ctx.split else None, colors_precomp=_lib.ptr(colors_precomp),
             opacities=_lib.ptr(opacities), scales=_lib.ptr(scales), rotations=_lib.ptr(rotations),
             cov3D_precomp=_lib.ptr(cov3Ds_precomp), viewmatrix=_lib.ptr(view), projmatrix=_lib.ptr(proj),
             campos=_lib.ptr(campos), scale_modifier=float(rs.scale_modifier), tan_fovx=float(rs.tanfovx),
@@ -202,14 +239,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             image_buffer=_lib.ptr(image), dL_dout_color=_lib.ptr(grad_color), dL_dout_invdepth=_lib.ptr(grad_invdepth),
             grad_accum=_lib.ptr(grad_accum), dL_dmeans2D=_lib.ptr(dL_dmeans2D), dL_dopacity=_lib.ptr(dL_dopacity),
             dL_dcolors=_lib.ptr(dL_dcolors), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
-            dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dscales=_lib.ptr(dL_dscales),
+            dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dsh_rest=_lib.ptr(dL_dsh_rest),
+            dL_dscales=_lib.ptr(dL_dscales),
             dL_drotations=_lib.ptr(dL_drot))
         if P > 0:
             with torch.cuda.device(device):
                 stream = torch.cuda.current_stream(device).cuda_stream
                 _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
-                dL_dcov3D, None)
+                dL_dcov3D, None, dL_dsh_rest)
 
 
 class GaussianRasterizer(nn.Module):

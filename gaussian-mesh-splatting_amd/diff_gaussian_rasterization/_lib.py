@@ -23,7 +23,8 @@ ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runt
 class RasterForwardArgs(C.Structure):
     _fields_ = [
         ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
-        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("background", C.c_void_p), ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p),
+        ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
@@ -41,7 +42,8 @@ class RasterBackwardArgs(C.Structure):
         ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
         ("num_rendered", C.c_int64), ("binning_capacity", C.c_int64),
         ("background", C.c_void_p),
-        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p), ("opacities", C.c_void_p),
+        ("means3D", C.c_void_p), ("shs", C.c_void_p), ("shs_rest", C.c_void_p), ("colors_precomp", C.c_void_p),
+        ("opacities", C.c_void_p),
         ("scales", C.c_void_p), ("rotations", C.c_void_p), ("cov3D_precomp", C.c_void_p),
         ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("scale_modifier", C.c_float), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
@@ -50,7 +52,7 @@ class RasterBackwardArgs(C.Structure):
         ("dL_dout_color", C.c_void_p), ("dL_dout_invdepth", C.c_void_p),
         ("grad_accum", C.c_void_p),
         ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
-        ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p),
+        ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p),
     ]
 

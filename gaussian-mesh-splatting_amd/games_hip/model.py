@@ -83,6 +83,14 @@ class HipMeshMixin:
             return act[3]
         return torch.nn.functional.normalize(self._rotation)
 
+    @property
+    def get_features(self):
+        # scene/gaussian_model.py:107-111 concatenates 57.6 MB per iteration; the rasterizer reads and
+        # differentiates _features_dc / _features_rest in place instead (SplitSH behaves as the concatenation
+        # for any other consumer)
+        from diff_gaussian_rasterization import SplitSH
+        return SplitSH(self._features_dc, self._features_rest)
+
 
 class HipMultiMeshMixin:
     """Drop-in for GaussianMultiMeshModel.update_alpha / _calc_xyz / prepare_scaling_rot
@@ -181,7 +189,9 @@ class HipGaussianMeshModel(HipMeshMixin):
 
     @property
     def get_features(self):
-        return torch.cat((self._features_dc, self._features_rest), dim=1)
+        # no 57.6 MB concatenation per iteration: the rasterizer reads / differentiates both blocks in place
+        from diff_gaussian_rasterization import SplitSH
+        return SplitSH(self._features_dc, self._features_rest)
 
 
 def install(games_module=None):

@@ -68,6 +68,10 @@ typedef struct GmsRasterForwardArgs {
     const float *background;      /* [3] */
     const float *means3D;         /* [P,3] */
     const float *shs;             /* [P,M,3] or NULL */
+    const float *shs_rest;        /* optional split storage (the reference keeps _features_dc [P,1,3] and
+                                     _features_rest [P,M-1,3] as separate parameters and concatenates them every
+                                     iteration, scene/gaussian_model.py:107-111): when non-NULL, `shs` is the DC
+                                     block [P,1,3] and `shs_rest` the remaining [P,M-1,3]; M stays the total */
     const float *colors_precomp;  /* [P,3] or NULL  (exactly one of shs / colors_precomp) */
     const float *opacities;       /* [P] */
     const float *scales;          /* [P,3] or NULL */
@@ -105,7 +109,7 @@ typedef struct GmsRasterBackwardArgs {
                                          the capacity hint when one was given and was sufficient, else
                                          max(num_rendered, 1) */
     const float *background;
-    const float *means3D, *shs, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
+    const float *means3D, *shs, *shs_rest, *colors_precomp, *opacities, *scales, *rotations, *cov3D_precomp;
     const float *viewmatrix, *projmatrix, *campos;
     float scale_modifier, tan_fovx, tan_fovy;
     int32_t antialiasing, debug;
@@ -126,7 +130,8 @@ typedef struct GmsRasterBackwardArgs {
     float *dL_dcolors;     /* [P,3] written only when colors_precomp != NULL (else may be NULL) */
     float *dL_dmeans3D;    /* [P,3] */
     float *dL_dcov3D;      /* [P,6] written only when cov3D_precomp != NULL (else may be NULL) */
-    float *dL_dsh;         /* [P,M,3] written only when shs != NULL */
+    float *dL_dsh;         /* [P,M,3] written only when shs != NULL ([P,1,3] DC block in split storage) */
+    float *dL_dsh_rest;    /* [P,M-1,3] written only when shs_rest != NULL */
     float *dL_dscales;     /* [P,3] written only when scales != NULL */
     float *dL_drotations;  /* [P,4] written only when rotations != NULL */
 } GmsRasterBackwardArgs;

@@ -207,3 +207,34 @@ def test_full_size_parity_with_oracle_through_the_mesh_op():
     grep = U.grad_report({k: t.cpu().numpy() for k, t in gh.items()}, {k: t.numpy() for k, t in go.items()})
     for k, val in grep.items():
         assert val["q_rel"] <= GRAD_REL and val["frac_bad"] <= 2e-3, (k, val)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_split_sh_storage_equals_concatenated(deg):
+    """SplitSH (DC and REST blocks read / differentiated in place) == the reference's torch.cat path."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, SplitSH
+    P = 3000 + deg            # not a multiple of 64: partial last wave
+    sc = syn.random_scene(P, seed=20 + deg, scale_lo=0.01, scale_hi=0.1)
+    cam = syn.orbit_camera(deg, width=144, height=96, radius=3.0).to("cuda")
+    kw = U.settings_kwargs(cam, torch.tensor([0.3, 0.5, 0.7], device="cuda"), sh_degree=deg)
+    rs = GaussianRasterizationSettings(**kw)
+    base = dict(means3D=sc.means3D.cuda(), opacities=sc.opacities.cuda(), scales=sc.scales.cuda(), rotations=sc.rotations.cuda())
+    gen = torch.Generator().manual_seed(1)
+    gc = torch.randn(3, 96, 144, generator=gen).cuda()
+    outs = []
+    for split in (False, True):
+        dc = sc.shs[:, :1].contiguous().cuda().requires_grad_(True)
+        rest = sc.shs[:, 1:].contiguous().cuda().requires_grad_(True)
+        shs = SplitSH(dc, rest) if split else torch.cat((dc, rest), dim=1)
+        m2 = torch.zeros(P, 3, device="cuda", requires_grad=True)
+        color, radii, _ = GaussianRasterizer(rs)(means2D=m2, shs=shs, **base)
+        (color * gc).sum().backward()
+        outs.append((color.detach(), dc.grad, rest.grad))
+    assert torch.equal(outs[0][0], outs[1][0])
+    nb = (deg + 1) ** 2
+    torch.testing.assert_close(outs[1][1], outs[0][1], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-4, atol=1e-6)
+    if nb < 16:
+        assert outs[1][2][:, nb - 1:].abs().max().item() == 0      # coefficients above the active degree: zero gradient
+    sp = SplitSH(sc.shs[:, :1], sc.shs[:, 1:])
+    assert sp.shape == sc.shs.shape and torch.equal(sp.transpose(1, 2), sc.shs.transpose(1, 2))
