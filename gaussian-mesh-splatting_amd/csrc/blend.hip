@@ -36,22 +36,25 @@ struct Unit {
     uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
 };
 
-// Block -> unit.  The dispatcher places block b on XCD b % 8 (observed; speed only).  Units are dealt
+// Block -> unit.  The unit table lists full segments (seg_len entries) first, then the tiles' partial last
+// segments, then the units of empty tiles: blocks are dispatched in index order, so the long-running units
+// start first and the tail of the kernel is made of short ones.  The dispatcher places block b on XCD b % 8 (observed; speed only).  Units are dealt
 // to the XCDs in runs of UNIT_RUN consecutive units: a run is a stretch of neighbouring tiles that
 // gather the same splat records (L2 locality), while successive runs rotate over the eight XCDs so the
 // heavy image centre and the empty border are spread over all of them (units are far from equal work).
-constexpr uint32_t UNIT_RUN = 16;
+constexpr uint32_t UNIT_RUN_MAX = 64;   // grid padding granularity; the run length itself is g.unit_run
 
 __device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
 {
     const uint32_t nunits = g.unit_first[g.T];
     const uint32_t s = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
-    const uint32_t idx = ((s / UNIT_RUN) * 8u + xcd) * UNIT_RUN + (s % UNIT_RUN);
+    const uint32_t run = g.unit_run;
+    const uint32_t idx = ((s / run) * 8u + xcd) * run + (s % run);
     if (idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
-    u.tile = (int)g.unit_tile[idx];
-    const uint32_t first = g.unit_first[u.tile];
-    u.seg = (int)(idx - first);
-    u.nseg = (int)(g.unit_first[u.tile + 1] - first);
+    const uint2 ts = g.unit_tile[idx];
+    u.tile = (int)ts.x;
+    u.seg = (int)ts.y;
+    u.nseg = (int)(g.unit_first[u.tile + 1] - g.unit_first[u.tile]);
     u.tx = u.tile % g.gx; u.ty = u.tile / g.gx;
     u.tile_beg = g.tile_offset[u.tile];
     const uint32_t tile_end = g.tile_offset[u.tile + 1];
@@ -306,6 +309,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     if (!load_unit(g, u)) return;
     if (u.end <= u.beg) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long t_start = g.dbg_buf ? wall_clock64() : 0ull;
+    struct Stamp {      // experiment: wave 0 lane 0 records [start, end] of its wave on every exit path
+        unsigned long long *buf, t0; uint32_t block; bool on;
+        __device__ ~Stamp() { if (on) { buf[2 * (size_t)block] = t0; buf[2 * (size_t)block + 1] = wall_clock64(); } }
+    } stamp{g.dbg_buf, t_start, blockIdx.x, g.dbg_buf != nullptr && lane == 0};
+    if (stamp.on) stamp.buf = g.dbg_buf + 8ull * 65536ull * (unsigned)wave;      // one region per wave index
     const Pix p = pixel_of(g, u);
     const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
@@ -426,9 +435,11 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
 }
 
 // ------------------------------------------------------------------------------------ host
+static unsigned long long *g_dbg_buf = nullptr;
+constexpr size_t DBG_BYTES = 4 * 8ull * 65536ull * 8;     // 4 waves x 65536 blocks x {start,end}
 int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    const unsigned blocks = 8u * UNIT_RUN * ((max_units + 8u * UNIT_RUN - 1u) / (8u * UNIT_RUN));
+    const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
     GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
     GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
     GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, o));
@@ -444,10 +455,21 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     static int dbg = -1;
     if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = e ? atoi(e) : 0; }
     g.dbg = (uint32_t)dbg;
-    const unsigned blocks = 8u * UNIT_RUN * ((max_units + 8u * UNIT_RUN - 1u) / (8u * UNIT_RUN));
+    g.dbg_buf = nullptr;
+    if (dbg & 16) {
+        if (!g_dbg_buf) (void)hipMalloc((void **)&g_dbg_buf, DBG_BYTES);
+        if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
+    }
+    const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
     GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, a));
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
     return GMS_OK;
 }
 
 }  // namespace gms
+
+extern "C" int gms_debug_read(unsigned long long *host, size_t bytes)
+{
+    if (!gms::g_dbg_buf) return -1;
+    return (int)hipMemcpy(host, gms::g_dbg_buf, bytes < gms::DBG_BYTES ? bytes : gms::DBG_BYTES, hipMemcpyDeviceToHost);
+}

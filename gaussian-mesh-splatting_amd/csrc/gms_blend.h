@@ -17,12 +17,14 @@ struct BlendGrid {
     const uint32_t *tile_offset;   // [T+1]
     const uint32_t *unit_first;    // [T+1] first unit of each tile; unit_first[T] = number of units
     const uint32_t *mseg_first;    // [T+1] first segment-state slot of each multi-segment tile
-    const uint32_t *unit_tile;     // [units] tile of each unit
+    const uint2 *unit_tile;        // [units] (tile, segment) of each unit, heaviest first
     const uint64_t *keys;          // sorted (depth, id) keys
     float *seg_state;              // [slots][SEG_FIELDS][256]
     uint64_t capacity;             // instances the binning buffer can hold
     uint32_t max_units;            // entries of unit_tile
     uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)
+    uint32_t unit_run;             // consecutive units dealt to one XCD (power of two <= 64)
+    unsigned long long *dbg_buf;   // GMS_DBG&16: per block {start, end} wall clock (100 MHz), else NULL
 };
 
 struct BlendFwdOut {
@@ -47,6 +49,7 @@ struct BlendBwdArgs {
 
 // segment length used by this process (env GMS_SEG_LEN, default 256; multiple of 256)
 uint32_t seg_len();
+uint32_t unit_run();
 inline uint32_t max_units(uint32_t T, uint64_t instances, uint32_t L) { return T + (uint32_t)(instances / L) + 1u; }
 inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_t)(instances / L) + 2u; }
 

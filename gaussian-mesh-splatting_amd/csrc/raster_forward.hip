@@ -351,54 +351,94 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 // One block: exclusive scans over the tiles of (a) instance counts -> tile_offset (offset[T] = N),
 // (b) segments per tile -> unit_first, (c) segments of multi-segment tiles -> mseg_first (slots of
 // the per-unit pixel state).  Also resets the emit cursors.
-__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t *part, int tid, uint32_t &total)
+constexpr int NSCAN = 9;
+constexpr int NCLASS = 6;     // dispatch classes: full | partial >=3/4 L | >=1/2 L | >=1/4 L | < 1/4 L | empty
+// NSCAN exclusive scans at once over the per-thread partial sums (Hillis-Steele in LDS, one barrier pair per step)
+__device__ __forceinline__ void block_exclusive_multi(uint32_t v[NSCAN], uint32_t (*part)[BLOCK], int tid, uint32_t total[NSCAN])
 {
-    __syncthreads();
-    part[tid] = v;
+#pragma unroll
+    for (int q = 0; q < NSCAN; q++) part[q][tid] = v[q];
     __syncthreads();
     for (int d = 1; d < BLOCK; d <<= 1) {
-        uint32_t x = tid >= d ? part[tid - d] : 0;
+        uint32_t x[NSCAN];
+#pragma unroll
+        for (int q = 0; q < NSCAN; q++) x[q] = tid >= d ? part[q][tid - d] : 0;
         __syncthreads();
-        part[tid] += x;
+#pragma unroll
+        for (int q = 0; q < NSCAN; q++) part[q][tid] += x[q];
         __syncthreads();
     }
-    total = part[BLOCK - 1];
-    return part[tid] - v;
+#pragma unroll
+    for (int q = 0; q < NSCAN; q++) { total[q] = part[q][BLOCK - 1]; v[q] = part[q][tid] - v[q]; }
+}
+
+// per-tile quantities scanned: instances, segments, segments of multi-segment tiles, full / partial / empty segments
+__device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NSCAN])
+{
+    const uint32_t ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
+    t[0] = c; t[1] = ns; t[2] = ns > 1 ? ns : 0;
+    const uint32_t r = c % L;
+    t[3] = c / L;
+    t[4] = r * 4 >= 3 * L ? 1u : 0u;
+    t[5] = (r * 4 < 3 * L && r * 2 >= L) ? 1u : 0u;
+    t[6] = (r * 2 < L && r * 4 >= L) ? 1u : 0u;
+    t[7] = (r * 4 < L && r != 0) ? 1u : 0u;
+    t[8] = c == 0 ? 1u : 0u;
 }
 
 __global__ void __launch_bounds__(BLOCK) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
-                                                          uint32_t *unit_first, uint32_t *mseg_first, int T, uint32_t L)
+                                                          uint32_t *unit_first, uint32_t *mseg_first, uint32_t *class_first,
+                                                          int T, uint32_t L)
 {
-    __shared__ uint32_t part[BLOCK];
+    __shared__ uint32_t part[NSCAN][BLOCK];
     const int tid = threadIdx.x;
     const int per = (T + BLOCK - 1) / BLOCK;
     const int b = tid * per, e = min(T, b + per);
-    uint32_t s0 = 0, s1 = 0, s2 = 0;
+    uint32_t run[NSCAN] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tot[NSCAN];
     for (int t = b; t < e; t++) {
-        const uint32_t c = count[t], ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
-        s0 += c; s1 += ns; s2 += ns > 1 ? ns : 0;
+        uint32_t q[NSCAN];
+        tile_terms(count[t], L, q);
+#pragma unroll
+        for (int k = 0; k < NSCAN; k++) run[k] += q[k];
     }
-    uint32_t tot0, tot1, tot2;
-    uint32_t r0 = block_exclusive(s0, part, tid, tot0);
-    uint32_t r1 = block_exclusive(s1, part, tid, tot1);
-    uint32_t r2 = block_exclusive(s2, part, tid, tot2);
+    block_exclusive_multi(run, part, tid, tot);
     for (int t = b; t < e; t++) {
-        const uint32_t c = count[t], ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
-        offset[t] = r0; unit_first[t] = r1; mseg_first[t] = r2;
+        uint32_t q[NSCAN];
+        tile_terms(count[t], L, q);
+        offset[t] = run[0]; unit_first[t] = run[1]; mseg_first[t] = run[2];
+#pragma unroll
+        for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + t] = run[3 + k];
         cursor[t] = 0;
-        r0 += c; r1 += ns; r2 += ns > 1 ? ns : 0;
+#pragma unroll
+        for (int k = 0; k < NSCAN; k++) run[k] += q[k];
     }
-    if (tid == 0) { offset[T] = tot0; unit_first[T] = tot1; mseg_first[T] = tot2; }
+    if (tid == 0) {
+        offset[T] = tot[0]; unit_first[T] = tot[1]; mseg_first[T] = tot[2];
+#pragma unroll
+        for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + T] = tot[3 + k];
+    }
 }
 
-// unit table: unit_tile[unit_first[t] + s] = t
-__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *unit_first, uint32_t *unit_tile, int T,
-                                                           uint32_t max_units)
+// unit table, heaviest first: [all full segments | partial last segments | units of empty tiles]
+__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count, const uint32_t *class_first, uint2 *unit_tile,
+                                                           int T, uint32_t L, uint32_t max_units)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T) return;
-    const uint32_t b = unit_first[t], e = unit_first[t + 1];
-    for (uint32_t u = b; u < e && u < max_units; u++) unit_tile[u] = (uint32_t)t;
+    const uint32_t c = count[t], nfull = c / L;
+    uint32_t u = class_first[t];
+    for (uint32_t s = 0; s < nfull; s++, u++)
+        if (u < max_units) unit_tile[u] = make_uint2((uint32_t)t, s);
+    uint32_t q[NSCAN];
+    tile_terms(c, L, q);
+    uint32_t base = class_first[T];                     // all full units come first
+    for (int k = 1; k < NCLASS; k++) {
+        if (q[3 + k]) {
+            u = base + class_first[k * (T + 1) + t];
+            if (u < max_units) unit_tile[u] = make_uint2((uint32_t)t, k == NCLASS - 1 ? 0u : nfull);
+        }
+        base += class_first[k * (T + 1) + T];
+    }
 }
 
 // ------------------------------------------------------------------------------------ K3
@@ -640,6 +680,18 @@ uint32_t seg_len()
     return L;
 }
 
+uint32_t unit_run()
+{
+    static uint32_t R = 0;
+    if (R == 0) {
+        uint32_t v = 4;
+        if (const char *e = getenv("GMS_UNIT_RUN")) v = (uint32_t)atoi(e);
+        R = 1;
+        while (R * 2 <= v && R < 64) R *= 2;
+    }
+    return R;
+}
+
 }  // namespace gms
 
 using namespace gms;
@@ -731,7 +783,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len();
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, T, L));
+                                                                                   img.unit_first, img.mseg_first, img.class_first, T, L));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
     int32_t *slot = pinned_slot();
@@ -748,7 +800,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                              img.tile_cursor, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
-        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.unit_first, bin.unit_tile, T, mu);
+        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.tile_count, img.class_first, bin.unit_tile, T, L, mu);
         GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, capacity));
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity));
@@ -756,7 +808,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
-        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0;
+        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr;
         return launch_blend_forward(g, bo, mu, A->debug != 0, stream);
     };
 
