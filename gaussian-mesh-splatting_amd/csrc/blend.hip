@@ -29,6 +29,11 @@
 
 namespace gms {
 
+#ifndef GMS_QUEUE
+#define GMS_QUEUE 256
+#endif
+constexpr int QUEUE = GMS_QUEUE;   // LDS splat-queue entries per batch (<= BLOCK)
+
 struct Unit {
     int tile, seg, nseg, tx, ty;
     uint32_t tile_beg;     // first entry of the tile in the sorted list
@@ -91,19 +96,19 @@ __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cn
 // ------------------------------------------------------------------------------------ tloc
 __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const SplatRec *rec)
 {
-    __shared__ SplatRec recs[BLOCK];
+    __shared__ SplatRec recs[QUEUE];
     Unit u;
     if (!load_unit(g, u)) return;
     if (u.nseg == 1 || u.seg == u.nseg - 1) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const Pix p = pixel_of(g, u);
     float Tl = 1.f;
-    for (uint32_t base = u.beg; base < u.end; base += BLOCK) {
+    for (uint32_t base = u.beg; base < u.end; base += QUEUE) {
         __syncthreads();
         const uint32_t idx = base + tid;
-        if (idx < u.end) recs[tid] = rec[(uint32_t)g.keys[idx]];
+        if (tid < QUEUE && idx < u.end) recs[tid] = rec[(uint32_t)g.keys[idx]];
         __syncthreads();
-        const int cnt = (int)min((uint32_t)BLOCK, u.end - base);
+        const int cnt = (int)min((uint32_t)QUEUE, u.end - base);
         // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact
         // value: a quadrant whose pixels are all there (or outside the image) stops evaluating
         if (__all(Tl < T_MIN || !p.inside)) continue;
@@ -134,7 +139,7 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const Sp
 // ------------------------------------------------------------------------------------ fwd
 __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
-    __shared__ SplatRec recs[BLOCK];
+    __shared__ SplatRec recs[QUEUE];
     Unit u;
     if (!load_unit(g, u)) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -147,12 +152,12 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdO
     uint32_t last = 0;
     bool done = !p.inside || dead_on_entry;
 
-    for (uint32_t base = u.beg; base < u.end; base += BLOCK) {
+    for (uint32_t base = u.beg; base < u.end; base += QUEUE) {
         if (__syncthreads_and(done)) break;
         const uint32_t idx = base + tid;
-        if (idx < u.end) recs[tid] = o.rec[(uint32_t)g.keys[idx]];
+        if (tid < QUEUE && idx < u.end) recs[tid] = o.rec[(uint32_t)g.keys[idx]];
         __syncthreads();
-        const int cnt = (int)min((uint32_t)BLOCK, u.end - base);
+        const int cnt = (int)min((uint32_t)QUEUE, u.end - base);
         if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
@@ -269,41 +274,47 @@ struct BwdState {
     float T, acc0, acc1, acc2, accd, last_alpha, lc0, lc1, lc2, lastd;
 };
 
-// One splat against one pixel: updates the recurrence and returns the ten partial gradients
-// v = (mean2D.x, mean2D.y, conic A, conic B, conic C, opacity, r, g, b, inverse depth).
-__device__ __forceinline__ void bwd_step(BwdState &s, const float4 &r0, const float4 &r1, const float4 &r2, float dx,
-                                         float dy, float G, float alpha, float dp0, float dp1, float dp2, float dinvd,
-                                         float Tfinal, float bgdot, float halfW, float halfH, float *v)
+// One splat against one pixel, branch-free: updates the recurrence and returns the ten partial gradients
+// v = (mean2D.x, mean2D.y, conic A, conic B, conic C, opacity, r, g, b, inverse depth).  A lane for which the
+// pair is inactive runs the same code with alpha = opacity = G = 0: a zero-alpha splat is transparent to the
+// recurrence (T unchanged; acc <- last_alpha*lc + (1-last_alpha)*acc commits the previous splat, then
+// last_alpha = 0 makes the next step reproduce that value exactly) and every output becomes exactly 0.
+__device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r0, const float4 &r1, const float4 &r2,
+                                         float dx, float dy, float G_in, float alpha_in, float dp0, float dp1, float dp2,
+                                         float dinvd, float Tfinal, float bgdot, float halfW, float halfH, float *v)
 {
-    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01
+    const float alpha = act ? alpha_in : 0.f, G = act ? G_in : 0.f, op = act ? r1.y : 0.f;
+    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01; rcp(1) == 1
     s.T = s.T * rcp1ma;
     const float w = alpha * s.T;
-    s.acc0 = s.last_alpha * s.lc0 + (1.f - s.last_alpha) * s.acc0;
-    s.acc1 = s.last_alpha * s.lc1 + (1.f - s.last_alpha) * s.acc1;
-    s.acc2 = s.last_alpha * s.lc2 + (1.f - s.last_alpha) * s.acc2;
-    s.accd = s.last_alpha * s.lastd + (1.f - s.last_alpha) * s.accd;
+    const float om = 1.f - s.last_alpha;
+    s.acc0 = s.last_alpha * s.lc0 + om * s.acc0;
+    s.acc1 = s.last_alpha * s.lc1 + om * s.acc1;
+    s.acc2 = s.last_alpha * s.lc2 + om * s.acc2;
+    s.accd = s.last_alpha * s.lastd + om * s.accd;
     s.lc0 = r1.z; s.lc1 = r1.w; s.lc2 = r2.x; s.lastd = r2.y;
     float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2 + (r2.y - s.accd) * dinvd;
     v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = w * dinvd;
     dL_dalpha *= s.T;
     s.last_alpha = alpha;
     dL_dalpha -= Tfinal * rcp1ma * bgdot;
-    const float dL_dG = r1.y * dL_dalpha;                      // alpha = min(0.99, op*G) is straight-through
+    const float dL_dG = op * dL_dalpha;                        // alpha = min(0.99, op*G) is straight-through
     const float gdx = G * dx, gdy = G * dy;
     const float dG_ddx = -gdx * r0.z - gdy * r0.w;
     const float dG_ddy = -gdy * r1.x - gdx * r0.w;
     v[0] = dL_dG * dG_ddx * halfW;
     v[1] = dL_dG * dG_ddy * halfH;
-    v[2] = -0.5f * gdx * dx * dL_dG;
-    v[3] = -0.5f * gdx * dy * dL_dG;
-    v[4] = -0.5f * gdy * dy * dL_dG;
+    const float h = -0.5f * dL_dG;
+    v[2] = h * gdx * dx;
+    v[3] = h * gdx * dy;
+    v[4] = h * gdy * dy;
     v[5] = G * dL_dalpha;
 }
 
 __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    __shared__ SplatRec recs[BLOCK];
-    __shared__ uint32_t ids[BLOCK];
+    __shared__ SplatRec recs[QUEUE];
+    __shared__ uint32_t ids[QUEUE];
     __shared__ uint32_t wave_max[4];
     Unit u;
     if (!load_unit(g, u)) return;
@@ -371,8 +382,8 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     if (top == 0) return;
     if (g.dbg & 2u) return;                              // experiment: prologue only
 
-    for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > BLOCK ? hi - BLOCK : seg_lo) {
-        const int cnt = (int)min((uint32_t)BLOCK, hi - seg_lo);
+    for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > QUEUE ? hi - QUEUE : seg_lo) {
+        const int cnt = (int)min((uint32_t)QUEUE, hi - seg_lo);
         __syncthreads();                              // previous queue fully consumed
         if (tid < cnt) {
             const uint32_t e = hi - 1 - tid;          // queue slot 0 = backmost entry
@@ -406,13 +417,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 const bool actb = two && posb < last && pb <= 0.f && alb >= ALPHA_MIN;
                 const bool anya = __any(acta), anyb = __any(actb);
                 if (!(anya || anyb)) continue;
-                float va[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                float vb[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                if (acta) bwd_step(st8, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
-                if (actb) bwd_step(st8, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                float va[10], vb[10];
                 const bool noatomics = (g.dbg & 1u) != 0;                 // experiment switch
-                if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }   // experiment: no reduction
                 if (anya && anyb) {
+                    bwd_step(st8, acta, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
+                    bwd_step(st8, actb, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                    if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
                     float y0a, y1a, y0b, y1b;
                     wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
                     if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
@@ -421,13 +431,18 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                         unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
                         unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
                     }
-                } else {
+                } else if (anya) {
+                    bwd_step(st8, acta, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
                     float y0, y1;
-                    float *v = anya ? va : vb;
-                    wave_reduce10(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], y0, y1);
+                    wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
                     if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
-                    const size_t id = ids[anya ? ka : kb];
-                    if (alane) unsafeAtomicAdd(abase + id * GRAD_STRIDE, use_y1 ? y1 : y0);
+                    if (alane) unsafeAtomicAdd(abase + (size_t)ids[ka] * GRAD_STRIDE, use_y1 ? y1 : y0);
+                } else {
+                    bwd_step(st8, actb, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                    float y0, y1;
+                    wave_reduce10(vb[0], vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7], vb[8], vb[9], y0, y1);
+                    if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
+                    if (alane) unsafeAtomicAdd(abase + (size_t)ids[kb] * GRAD_STRIDE, use_y1 ? y1 : y0);
                 }
             }
         }

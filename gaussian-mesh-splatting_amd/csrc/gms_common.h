@@ -146,6 +146,21 @@ __device__ __forceinline__ void swap16(float &a, float &b)
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// five / three independent swaps behind ONE hazard nop (their operands were written by earlier VALU ops;
+// consecutive swaps touch different registers)
+__device__ __forceinline__ void swap32x5(float &a0, float &a1, float &b0, float &b1, float &c0, float &c1, float &d0,
+                                         float &d1, float &e0, float &e1)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\tv_permlane32_swap_b32 %8, %9"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1), "+v"(d0), "+v"(d1), "+v"(e0), "+v"(e1));
+}
+__device__ __forceinline__ void swap16x3(float &a0, float &a1, float &b0, float &b1, float &c0, float &c1)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5"
+                 : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
+}
+
 // Transposing wave reduction of ten values: every stage adds partner lanes AND halves the number
 // of live registers (the two halves / rows / half-rows end up holding different values), ~26 VALU
 // instead of 80 for ten independent butterflies.  Result layout:
@@ -154,15 +169,13 @@ __device__ __forceinline__ void swap16(float &a, float &b)
 __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                               float v7, float v8, float v9, float &y0, float &y1)
 {
-    swap32(v0, v1); float w0 = v0 + v1;
-    swap32(v2, v3); float w1 = v2 + v3;
-    swap32(v4, v5); float w2 = v4 + v5;
-    swap32(v6, v7); float w3 = v6 + v7;
-    swap32(v8, v9); float w4 = v8 + v9;
-    swap16(w0, w1); float x0 = w0 + w1;          // rows (v0, v2, v1, v3)
-    swap16(w2, w3); float x1 = w2 + w3;          // rows (v4, v6, v5, v7)
+    swap32x5(v0, v1, v2, v3, v4, v5, v6, v7, v8, v9);
+    float w0 = v0 + v1, w1 = v2 + v3, w2 = v4 + v5, w3 = v6 + v7, w4 = v8 + v9;
     float z = 0.f;
-    swap16(w4, z);  float x2 = w4 + z;           // rows (v8, 0, v9, 0)
+    swap16x3(w0, w1, w2, w3, w4, z);
+    const float x0 = w0 + w1;                    // rows (v0, v2, v1, v3)
+    const float x1 = w2 + w3;                    // rows (v4, v6, v5, v7)
+    const float x2 = w4 + z;                     // rows (v8, 0, v9, 0)
     const float a = dpp_add<0x128>(x0);          // row_ror:8 : lane l += lane l^8 (within the row)
     const float b = dpp_add<0x128>(x1);
     y0 = (threadIdx.x & 8) ? b : a;
@@ -175,12 +188,13 @@ __device__ __forceinline__ void wave_reduce10(float v0, float v1, float v2, floa
 // for each): the second chain fills the issue slots the first one leaves while waiting.
 __device__ __forceinline__ void wave_reduce10x2(float *a, float *b, float &y0a, float &y1a, float &y0b, float &y1b)
 {
-    swap32(a[0], a[1]); swap32(b[0], b[1]); swap32(a[2], a[3]); swap32(b[2], b[3]); swap32(a[4], a[5]);
-    swap32(b[4], b[5]); swap32(a[6], a[7]); swap32(b[6], b[7]); swap32(a[8], a[9]); swap32(b[8], b[9]);
+    swap32x5(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]);
+    swap32x5(b[0], b[1], b[2], b[3], b[4], b[5], b[6], b[7], b[8], b[9]);
     float wa0 = a[0] + a[1], wb0 = b[0] + b[1], wa1 = a[2] + a[3], wb1 = b[2] + b[3], wa2 = a[4] + a[5];
     float wb2 = b[4] + b[5], wa3 = a[6] + a[7], wb3 = b[6] + b[7], wa4 = a[8] + a[9], wb4 = b[8] + b[9];
     float za = 0.f, zb = 0.f;
-    swap16(wa0, wa1); swap16(wb0, wb1); swap16(wa2, wa3); swap16(wb2, wb3); swap16(wa4, za); swap16(wb4, zb);
+    swap16x3(wa0, wa1, wa2, wa3, wa4, za);
+    swap16x3(wb0, wb1, wb2, wb3, wb4, zb);
     const float xa0 = wa0 + wa1, xb0 = wb0 + wb1, xa1 = wa2 + wa3, xb1 = wb2 + wb3, xa2 = wa4 + za, xb2 = wb4 + zb;
     const bool hi8 = (threadIdx.x & 8) != 0;
     const float pa = dpp_add<0x128>(xa0), pb = dpp_add<0x128>(xb0), qa = dpp_add<0x128>(xa1), qb = dpp_add<0x128>(xb1);

@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
                 // low active degree: only the first NB3-3 floats of each REST row are needed
                 const int g0 = blockIdx.x * BLOCK + wave * WAVE;
                 const int rows = min(WAVE, a.P - g0);
-                constexpr int need = NB3 - 3;
+                constexpr int need = NB3 > 3 ? NB3 - 3 : 1;
                 for (int e = lane; e < rows * need; e += WAVE) {
                     const int r = e / need, c = e - r * need;
                     wl[r * SH_PITCH + 3 + c] = a.shs_rest[((size_t)g0 + r) * RESTF + c];
