@@ -12,8 +12,8 @@
 //            (any further contributing splat fails the T*(1-a) < 1e-4 test).  Exact front-to-back
 //            walk with the reference's skip/stop tests from T_start.  Single-segment tiles write
 //            the final image directly; multi-segment units write (C, D, T_end, last) partials.
-//   finalize (multi-segment tiles) sums the partials in segment order, writes image / final_T /
-//            n_contrib, and replaces each partial by the suffix sum the backward pass needs.
+//   finalize (multi-segment tiles) sums the partials in segment order and writes image / final_T /
+//            n_contrib; the partials stay in place for the backward pass.
 //   bwd      per unit, back-to-front from (T_end, suffix colour / T_end): the reference's recurrence
 //            restarted at a segment boundary.  Ten partial gradients per (wave, splat) are summed
 //            over the 64 lanes with DPP row operations and leave the wave as ONE hardware float
@@ -255,17 +255,6 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
         o.out_color[2 * HW + pid] = C2 + T * o.bg[2];
         o.out_invdepth[pid] = Dp;
     }
-    // suffix sums for the backward pass: S_k = sum of the partials of the segments behind k
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
-    for (int k = nseg - 1; k >= 0; k--) {
-        float *st = st0 + (size_t)k * SEG_FLOATS;
-        const bool live = st[SEG_TEND * TILE_PIX + tid] >= 0.f;
-        const float c0 = st[SEG_C0 * TILE_PIX + tid], c1 = st[SEG_C1 * TILE_PIX + tid], c2 = st[SEG_C2 * TILE_PIX + tid];
-        const float d = st[SEG_D * TILE_PIX + tid];
-        st[SEG_C0 * TILE_PIX + tid] = S0; st[SEG_C1 * TILE_PIX + tid] = S1; st[SEG_C2 * TILE_PIX + tid] = S2;
-        st[SEG_D * TILE_PIX + tid] = SD;
-        if (live) { S0 += c0; S1 += c1; S2 += c2; SD += d; }
-    }
 }
 
 // ------------------------------------------------------------------------------------ bwd
@@ -344,10 +333,19 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
         const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
         const float te = st[SEG_TEND * TILE_PIX + tid];
         if (te > 0.f) {
+            // restart of the recurrence at the segment boundary: T after this segment's last applied splat and
+            // the colour composited behind it (sum of the live partials of the later segments) divided by that T
             st8.T = te;
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
+            for (int k = u.nseg - 1; k > u.seg; k--) {
+                const float *sk = g.seg_state + (size_t)(u.slot0 + k) * SEG_FLOATS;
+                if (sk[SEG_TEND * TILE_PIX + tid] >= 0.f) {
+                    S0 += sk[SEG_C0 * TILE_PIX + tid]; S1 += sk[SEG_C1 * TILE_PIX + tid]; S2 += sk[SEG_C2 * TILE_PIX + tid];
+                    SD += sk[SEG_D * TILE_PIX + tid];
+                }
+            }
             const float inv = 1.f / te;
-            st8.acc0 = st[SEG_C0 * TILE_PIX + tid] * inv; st8.acc1 = st[SEG_C1 * TILE_PIX + tid] * inv;
-            st8.acc2 = st[SEG_C2 * TILE_PIX + tid] * inv; st8.accd = st[SEG_D * TILE_PIX + tid] * inv;
+            st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
         }
     }
     const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;

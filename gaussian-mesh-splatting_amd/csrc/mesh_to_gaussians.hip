@@ -221,7 +221,8 @@ __device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, c
 }
 
 // differentiate quaternion + frame once per face and scatter into the three vertices
-__device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float *dL_dvertices)
+// returns d loss / d (t0, t1, t2) of the face in out[9]
+__device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float out[9])
 {
     // ---- quaternion -> dL/dR (columns v0, v1, v2)
     float q[4];
@@ -301,10 +302,9 @@ __device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, Face
     V3 dt0 = G.dt0 + g_mean - (g_e1 + g_e2);
     V3 dt1 = G.dt1 + g_mean + g_u1 + g_e1;
     V3 dt2 = G.dt2 + g_mean + g_v2i + g_e2;
-    const int64_t i0 = a.faces[3 * (size_t)f], i1 = a.faces[3 * (size_t)f + 1], i2 = a.faces[3 * (size_t)f + 2];
-    unsafeAtomicAdd(dL_dvertices + 3 * i0, dt0.x); unsafeAtomicAdd(dL_dvertices + 3 * i0 + 1, dt0.y); unsafeAtomicAdd(dL_dvertices + 3 * i0 + 2, dt0.z);
-    unsafeAtomicAdd(dL_dvertices + 3 * i1, dt1.x); unsafeAtomicAdd(dL_dvertices + 3 * i1 + 1, dt1.y); unsafeAtomicAdd(dL_dvertices + 3 * i1 + 2, dt1.z);
-    unsafeAtomicAdd(dL_dvertices + 3 * i2, dt2.x); unsafeAtomicAdd(dL_dvertices + 3 * i2 + 1, dt2.y); unsafeAtomicAdd(dL_dvertices + 3 * i2 + 2, dt2.z);
+    out[0] = dt0.x; out[1] = dt0.y; out[2] = dt0.z;
+    out[3] = dt1.x; out[4] = dt1.y; out[5] = dt1.z;
+    out[6] = dt2.x; out[7] = dt2.y; out[8] = dt2.z;
 }
 
 __device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, int64_t &b, int64_t &e)
@@ -317,8 +317,12 @@ __device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, in
 __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
                                                                      const float *dL_drot, float *dL_dvertices)
 {
+    __shared__ float lds9[4 * WAVE * 9];
+    __shared__ int ldsi[4 * WAVE * 3];
     const int f = blockIdx.x * BLOCK + threadIdx.x;
-    if (f >= a.F) return;
+    const bool valid = f < a.F;
+    float out[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (valid) {
     V3 t0, t1, t2;
     load_face(a, f, t0, t1, t2);
     Frame fr;
@@ -327,7 +331,25 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs
     int64_t b, e;
     face_splat_range(a, f, b, e);
     for (int64_t p = b; p < e; p++) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
-    face_backward(a, f, fr, G, dL_dvertices);
+    face_backward(a, f, fr, G, out);
+    }
+    // Scatter into vertices.grad: the wave's 64 x 9 values are transposed through LDS so that three adjacent
+    // lanes add the x, y, z of ONE vertex (same cache line -> one L2 transaction instead of three).
+    float *w9 = lds9 + (threadIdx.x >> 6) * (WAVE * 9);
+    int *wi = ldsi + (threadIdx.x >> 6) * (WAVE * 3);
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 9; k++) w9[lane * 9 + k] = out[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) wi[lane * 3 + k] = valid ? (int)a.faces[3 * (size_t)f + k] : -1;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        const int e = j * WAVE + lane;          // e = face_in_wave * 9 + vertex * 3 + component
+        const int fl = e / 9, r = e - fl * 9;
+        const int vi = wi[fl * 3 + r / 3];
+        if (vi >= 0) unsafeAtomicAdd(dL_dvertices + 3 * (size_t)vi + (r % 3), w9[e]);
+    }
 }
 
 // many splats per face (FLAME-like, 50-100): one wave per face, lanes stride over the splats
@@ -348,7 +370,14 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_wave_kernel(GmsMeshArgs a
     float *v = reinterpret_cast<float *>(&G);
 #pragma unroll
     for (int k = 0; k < (int)(sizeof(FaceGrad) / 4); k++) v[k] = wave_sum_to_lane63(v[k]);
-    if (lane == 63) face_backward(a, f, fr, G, dL_dvertices);
+    if (lane == 63) {
+        float out[9];
+        face_backward(a, f, fr, G, out);
+        for (int k = 0; k < 3; k++) {
+            const int64_t vi = a.faces[3 * (size_t)f + k];
+            for (int c = 0; c < 3; c++) unsafeAtomicAdd(dL_dvertices + 3 * vi + c, out[3 * k + c]);
+        }
+    }
 }
 
 }  // namespace gms

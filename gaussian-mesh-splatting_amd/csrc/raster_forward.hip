@@ -353,26 +353,9 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 // the per-unit pixel state).  Also resets the emit cursors.
 constexpr int NSCAN = 9;
 constexpr int NCLASS = 6;     // dispatch classes: full | partial >=3/4 L | >=1/2 L | >=1/4 L | < 1/4 L | empty
-// NSCAN exclusive scans at once over the per-thread partial sums (Hillis-Steele in LDS, one barrier pair per step)
-__device__ __forceinline__ void block_exclusive_multi(uint32_t v[NSCAN], uint32_t (*part)[BLOCK], int tid, uint32_t total[NSCAN])
-{
-#pragma unroll
-    for (int q = 0; q < NSCAN; q++) part[q][tid] = v[q];
-    __syncthreads();
-    for (int d = 1; d < BLOCK; d <<= 1) {
-        uint32_t x[NSCAN];
-#pragma unroll
-        for (int q = 0; q < NSCAN; q++) x[q] = tid >= d ? part[q][tid - d] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NSCAN; q++) part[q][tid] += x[q];
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < NSCAN; q++) { total[q] = part[q][BLOCK - 1]; v[q] = part[q][tid] - v[q]; }
-}
+constexpr int SCAN_THREADS = 1024;
 
-// per-tile quantities scanned: instances, segments, segments of multi-segment tiles, full / partial / empty segments
+// per-tile quantities scanned: instances, segments, segments of multi-segment tiles, then the dispatch classes
 __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NSCAN])
 {
     const uint32_t ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
@@ -386,22 +369,54 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
     t[8] = c == 0 ? 1u : 0u;
 }
 
-__global__ void __launch_bounds__(BLOCK) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
-                                                          uint32_t *unit_first, uint32_t *mseg_first, uint32_t *class_first,
-                                                          int T, uint32_t L)
+// One block of 1024 threads: NSCAN exclusive scans over the tiles at once.  Each wave scans its 64 per-thread
+// sums with DPP-free shuffles, the 16 wave totals are scanned by the first wave: two block barriers in all.
+__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
+                                                                 uint32_t *unit_first, uint32_t *mseg_first,
+                                                                 uint32_t *class_first, int T, uint32_t L)
 {
-    __shared__ uint32_t part[NSCAN][BLOCK];
-    const int tid = threadIdx.x;
-    const int per = (T + BLOCK - 1) / BLOCK;
+    __shared__ uint32_t wave_tot[NSCAN][SCAN_THREADS / WAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
     const int b = tid * per, e = min(T, b + per);
-    uint32_t run[NSCAN] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, tot[NSCAN];
+    uint32_t run[NSCAN], own[NSCAN];
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) run[k] = 0;
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
         tile_terms(count[t], L, q);
 #pragma unroll
         for (int k = 0; k < NSCAN; k++) run[k] += q[k];
     }
-    block_exclusive_multi(run, part, tid, tot);
+    // inclusive scan inside the wave
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) {
+        own[k] = run[k];
+        for (int d = 1; d < WAVE; d <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)run[k], d);
+            if (lane >= d) run[k] += x;
+        }
+        if (lane == WAVE - 1) wave_tot[k][wave] = run[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NSCAN; k++) {
+            uint32_t v = lane < SCAN_THREADS / WAVE ? wave_tot[k][lane] : 0u;
+            for (int d = 1; d < SCAN_THREADS / WAVE; d <<= 1) {
+                const uint32_t x = (uint32_t)__shfl_up((int)v, d);
+                if (lane >= d) v += x;
+            }
+            if (lane < SCAN_THREADS / WAVE) wave_tot[k][lane] = v;      // inclusive over waves
+        }
+    }
+    __syncthreads();
+    uint32_t tot[NSCAN];
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) {
+        tot[k] = wave_tot[k][SCAN_THREADS / WAVE - 1];
+        run[k] = run[k] - own[k] + (wave > 0 ? wave_tot[k][wave - 1] : 0u);   // exclusive prefix of this thread's chunk
+    }
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
         tile_terms(count[t], L, q);
@@ -782,7 +797,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
 #undef GMS_PRE
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len();
-    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, BLOCK, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
+    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
                                                                                    img.unit_first, img.mseg_first, img.class_first, T, L));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
