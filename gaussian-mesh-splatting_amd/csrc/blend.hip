@@ -33,6 +33,7 @@ namespace gms {
 #define GMS_QUEUE 256
 #endif
 constexpr int QUEUE = GMS_QUEUE;   // LDS splat-queue entries per batch (<= BLOCK)
+constexpr int TLOC_HEAD = 4;       // segments whose transmittance products are always evaluated
 
 struct Unit {
     int tile, seg, nseg, tx, ty;
@@ -94,13 +95,20 @@ __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cn
 }
 
 // ------------------------------------------------------------------------------------ tloc
-__global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const SplatRec *rec)
+__global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const SplatRec *rec, int phase)
 {
     __shared__ SplatRec recs[QUEUE];
     Unit u;
     if (!load_unit(g, u)) return;
     if (u.nseg == 1 || u.seg == u.nseg - 1) return;
+    // phase 0: the first TLOC_HEAD segments of every tile; phase 1: the rest, unless the head already
+    // finished every pixel of the tile (then the products are irrelevant: write 0, evaluate nothing)
+    if (phase >= 0 && (u.seg < TLOC_HEAD) != (phase == 0)) return;     // phase -1: every segment in one launch
     const int tid = threadIdx.x, lane = tid & 63;
+    if (phase == 1 && g.tile_dead[u.tile]) {
+        g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = 0.f;
+        return;
+    }
     const Pix p = pixel_of(g, u);
     float Tl = 1.f;
     for (uint32_t base = u.beg; base < u.end; base += QUEUE) {
@@ -134,6 +142,22 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const Sp
         }
     }
     g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = Tl;
+}
+
+// tile_dead[t] = 1 when the product of the first TLOC_HEAD segment transmittances is < 1e-4 for every pixel
+__global__ void __launch_bounds__(BLOCK) blend_tloc_check_kernel(BlendGrid g)
+{
+    const int tile = blockIdx.x;
+    const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
+    if (nseg <= TLOC_HEAD + 1) return;             // no phase-1 segment exists (the last one needs no product)
+    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xi = (tile % g.gx) * TILE + (wave & 1) * 8 + (lane & 7), yi = (tile / g.gx) * TILE + (wave >> 1) * 8 + (lane >> 3);
+    const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
+    float T = 1.f;
+    for (int k = 0; k < TLOC_HEAD; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    const int dead = __syncthreads_and(T < T_MIN || xi >= g.W || yi >= g.H);
+    if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
 }
 
 // ------------------------------------------------------------------------------------ fwd
@@ -337,12 +361,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
             // the colour composited behind it (sum of the live partials of the later segments) divided by that T
             st8.T = te;
             float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
-            for (int k = u.nseg - 1; k > u.seg; k--) {
+            // a pixel that is dead on entry to segment k is dead for every later one: stop at the first
+            for (int k = u.seg + 1; k < u.nseg; k++) {
                 const float *sk = g.seg_state + (size_t)(u.slot0 + k) * SEG_FLOATS;
-                if (sk[SEG_TEND * TILE_PIX + tid] >= 0.f) {
-                    S0 += sk[SEG_C0 * TILE_PIX + tid]; S1 += sk[SEG_C1 * TILE_PIX + tid]; S2 += sk[SEG_C2 * TILE_PIX + tid];
-                    SD += sk[SEG_D * TILE_PIX + tid];
-                }
+                if (sk[SEG_TEND * TILE_PIX + tid] < 0.f) break;
+                S0 += sk[SEG_C0 * TILE_PIX + tid]; S1 += sk[SEG_C1 * TILE_PIX + tid]; S2 += sk[SEG_C2 * TILE_PIX + tid];
+                SD += sk[SEG_D * TILE_PIX + tid];
             }
             const float inv = 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
@@ -452,8 +476,17 @@ static unsigned long long *g_dbg_buf = nullptr;
 constexpr size_t DBG_BYTES = 4 * 8ull * 65536ull * 8;     // 4 waves x 65536 blocks x {start,end}
 int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    // two-phase transmittance products pay off when tiles are deep on average (> 2 segments per tile over the
+    // whole image); shallow scenes take one launch
+    const bool deep = g.capacity > 2ull * g.seg_len * (uint64_t)g.T;
     const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
-    GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
+    if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, 0));
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, 1));
+    } else {
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, -1));
+    }
     GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
     GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_fwd");

@@ -20,6 +20,7 @@ struct BlendGrid {
     const uint2 *unit_tile;        // [units] (tile, segment) of each unit, heaviest first
     const uint64_t *keys;          // sorted (depth, id) keys
     float *seg_state;              // [slots][SEG_FIELDS][256]
+    uint32_t *tile_dead;           // [T] set by the tloc check: every pixel finished within the first segments
     uint64_t capacity;             // instances the binning buffer can hold
     uint32_t max_units;            // entries of unit_tile
     uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)

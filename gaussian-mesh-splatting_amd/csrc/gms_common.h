@@ -66,11 +66,12 @@ struct ImageState {
     uint32_t *unit_first;   // [T+1]   exclusive scan of segments per tile; unit_first[T] = #units
     uint32_t *mseg_first;   // [T+1]   exclusive scan of segments of multi-segment tiles only
     uint32_t *class_first;  // [6][T+1] exclusive scans per dispatch class (full, 4 partial size classes, empty)
+    uint32_t *tile_dead;    // [T]     all pixels of the tile finished within the first few segments
     static __host__ __device__ size_t bytes(size_t W, size_t H)
     {
         size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + 3 * align_up((T + 1) * 4, 256) +
-               align_up(6 * (T + 1) * 4, 256);
+               align_up(6 * (T + 1) * 4, 256) + align_up(T * 4, 256);
     }
     static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
     {
@@ -84,7 +85,8 @@ struct ImageState {
         s.tile_offset = (uint32_t *)p; p += align_up((T + 1) * 4, 256);
         s.unit_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
         s.mseg_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
-        s.class_first = (uint32_t *)p;
+        s.class_first = (uint32_t *)p; p += align_up(6 * (T + 1) * 4, 256);
+        s.tile_dead = (uint32_t *)p;
         return s;
     }
 };
@@ -253,6 +255,34 @@ __device__ __forceinline__ uint32_t wave_aggregated_inc(uint32_t *counters, int 
     if (!RETURNING) return 0;
     base = (uint32_t)__shfl((int)base, my_leader);
     return base + rank;
+}
+
+// Block-level tile table in LDS (open addressing): the (Gaussian, tile) instances of the 256 consecutive
+// Gaussians of a block fall into a few dozen distinct tiles, so counting them in LDS first turns one global
+// atomic per wave-step-and-tile into one per block-and-tile.  `tt_insert` returns the slot (or -1 when 16
+// probes found only other tiles: the caller then falls back to a direct global atomic).
+constexpr int TT_SLOTS = 1024;
+__device__ __forceinline__ uint32_t tt_hash(int tile) { return ((uint32_t)tile * 2654435761u) >> 22; }
+__device__ __forceinline__ int tt_insert(int *key, int tile)
+{
+    uint32_t h = tt_hash(tile);
+    for (int probe = 0; probe < 16; probe++) {
+        const int old = atomicCAS(&key[h], -1, tile);
+        if (old == -1 || old == tile) return (int)h;
+        h = (h + 1) & (TT_SLOTS - 1);
+    }
+    return -1;
+}
+__device__ __forceinline__ int tt_find(const int *key, int tile)
+{
+    uint32_t h = tt_hash(tile);
+    for (int probe = 0; probe < 16; probe++) {
+        const int k = key[h];
+        if (k == tile) return (int)h;
+        if (k == -1) return -1;
+        h = (h + 1) & (TT_SLOTS - 1);
+    }
+    return -1;
 }
 
 // Split form of the returning variant: `issue` elects leaders and fires the atomic (result pending in

@@ -42,7 +42,6 @@ void set_error(const char *fmt, ...)
 
 // ------------------------------------------------------------------------------------ K1
 constexpr int SMALL_AREA = 64; // tiles a lane walks itself (lock-step, aggregated atomics); larger footprints are expanded by the whole wave
-constexpr int EMIT_FLIGHT = 4; // cursor atomics kept in flight per lane in emit
 constexpr int SH_PITCH = 52;   // dwords per LDS row: 48 used; 52*l mod 64 hits 16 distinct 16-B slots
 
 struct PreArgs {
@@ -321,19 +320,30 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         a.geom.clamped[i] = (uint8_t)clampbits;
         a.radii[i] = (int)rad;
     }
-    // tile coverage counts.  Footprints up to SMALL_AREA tiles: the 64 lanes walk their rectangles in
-    // lock-step with one aggregated atomic per distinct tile per step (neighbouring splats share tiles, so
-    // aggregation removes most atomics).  Very large footprints: the whole wave expands ONE splat's
-    // rectangle at a time, a tile per lane.
+    // tile coverage counts.  Footprints up to SMALL_AREA tiles are counted in the block's LDS tile table and
+    // flushed with one global atomic per distinct tile; very large footprints are expanded by the whole wave,
+    // a tile per lane, straight to global memory.
     const int rw = maxx - minx;
     const int area = vis ? rw * (maxy - miny) : 0;
     const bool small = area <= SMALL_AREA;
-    int cx = minx, cy = miny;
-    for (int k = 0; __any(small && k < area); k++) {
-        const bool act = small && k < area;
-        wave_aggregated_inc<false>(a.tile_count, act ? cy * a.gx + cx : -1, act);
-        if (++cx == maxx) { cx = minx; cy++; }
+    __syncthreads();                               // SH rows no longer needed: their LDS becomes the tile table
+    int *tt_key = reinterpret_cast<int *>(sh_lds);
+    uint32_t *tt_cnt = reinterpret_cast<uint32_t *>(sh_lds) + TT_SLOTS;
+    for (int q = tid; q < TT_SLOTS; q += BLOCK) { tt_key[q] = -1; tt_cnt[q] = 0; }
+    __syncthreads();
+    if (small) {
+        int cx = minx, cy = miny;
+        for (int k = 0; k < area; k++) {
+            const int t = cy * a.gx + cx;
+            const int sl = tt_insert(tt_key, t);
+            if (sl >= 0) atomicAdd(&tt_cnt[sl], 1u);
+            else atomicAdd(&a.tile_count[t], 1u);
+            if (++cx == maxx) { cx = minx; cy++; }
+        }
     }
+    __syncthreads();
+    for (int q = tid; q < TT_SLOTS; q += BLOCK)
+        if (tt_key[q] >= 0) atomicAdd(&a.tile_count[tt_key[q]], tt_cnt[q]);
     uint64_t big = __ballot(!small);
     while (big) {
         const int src = __builtin_ctzll(big);
@@ -475,25 +485,36 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
     const bool small = area <= SMALL_AREA;
     const int lane = threadIdx.x & 63;
     int cx = minx, cy = miny;
-    // footprints up to SMALL_AREA tiles: lock-step walk, EMIT_FLIGHT aggregated cursor atomics in flight per
-    // trip (one memory round trip per EMIT_FLIGHT tiles)
-    for (int k0 = 0; __any(small && k0 < area); k0 += EMIT_FLIGHT) {
-        AggTicket tk[EMIT_FLIGHT];
-        int tl[EMIT_FLIGHT];
-#pragma unroll
-        for (int k = 0; k < EMIT_FLIGHT; k++) {
-            const bool act = small && (k0 + k) < area;
-            tl[k] = act ? cy * gx + cx : -1;
-            tk[k] = wave_aggregated_issue(tile_cursor, tl[k], act);
+    // footprints up to SMALL_AREA tiles: count per tile in the block's LDS table, fetch one cursor range per
+    // distinct tile (one global atomic each, all in flight together), then hand out ranks from LDS
+    __shared__ int tt_key[TT_SLOTS];
+    __shared__ uint32_t tt_cnt[TT_SLOTS];
+    __shared__ uint32_t tt_base[TT_SLOTS];
+    for (int q = threadIdx.x; q < TT_SLOTS; q += BLOCK) { tt_key[q] = -1; tt_cnt[q] = 0; }
+    __syncthreads();
+    if (small) {
+        for (int k = 0; k < area; k++) {
+            const int sl = tt_insert(tt_key, cy * gx + cx);
+            if (sl >= 0) atomicAdd(&tt_cnt[sl], 1u);
             if (++cx == maxx) { cx = minx; cy++; }
         }
-#pragma unroll
-        for (int k = 0; k < EMIT_FLIGHT; k++) {
-            const uint32_t rank = wave_aggregated_finish(tk[k]);
-            if (small && (k0 + k) < area) {
-                const uint64_t slot = (uint64_t)tile_offset[tl[k]] + rank;
-                if (slot < capacity) keys[slot] = key;
-            }
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < TT_SLOTS; q += BLOCK)
+        if (tt_key[q] >= 0) {
+            tt_base[q] = tile_offset[tt_key[q]] + atomicAdd(&tile_cursor[tt_key[q]], tt_cnt[q]);
+            tt_cnt[q] = 0;
+        }
+    __syncthreads();
+    if (small) {
+        cx = minx; cy = miny;
+        for (int k = 0; k < area; k++) {
+            const int t = cy * gx + cx;
+            const int sl = tt_find(tt_key, t);
+            const uint64_t slot = sl >= 0 ? (uint64_t)tt_base[sl] + atomicAdd(&tt_cnt[sl], 1u)
+                                          : (uint64_t)tile_offset[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (slot < capacity) keys[slot] = key;
+            if (++cx == maxx) { cx = minx; cy++; }
         }
     }
     // large footprints: the wave expands one splat at a time, a tile per lane
@@ -823,7 +844,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
-        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr;
+        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
         return launch_blend_forward(g, bo, mu, A->debug != 0, stream);
     };
 
