@@ -137,17 +137,8 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
 // gfx950 lane-swap instructions (the clang builtins mis-model the second result in ROCm 7.2, so
 // they are issued as inline asm; `s_nop 1` covers the VALU-write -> permlane-swap-read hazard that
 // hipcc does not track for asm operands).  All 64 lanes must be active.
-//   swap32(a, b): a <- [a.lo32lanes, b.lo32lanes],  b <- [a.hi32lanes, b.hi32lanes]
-//   swap16(a, b): rows (16 lanes) a=(r0,r1,r2,r3), b=(s0,s1,s2,s3) -> a=(r0,s0,r2,s2), b=(r1,s1,r3,s3)
-__device__ __forceinline__ void swap32(float &a, float &b)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-__device__ __forceinline__ void swap16(float &a, float &b)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-}
-
+//   v_permlane32_swap a, b: a <- [a.lo32lanes, b.lo32lanes],  b <- [a.hi32lanes, b.hi32lanes]
+//   v_permlane16_swap a, b: rows (16 lanes) a=(r0,r1,r2,r3), b=(s0,s1,s2,s3) -> a=(r0,s0,r2,s2), b=(r1,s1,r3,s3)
 // five / three independent swaps behind ONE hazard nop (their operands were written by earlier VALU ops;
 // consecutive swaps touch different registers)
 __device__ __forceinline__ void swap32x5(float &a0, float &a1, float &b0, float &b1, float &c0, float &c1, float &d0,

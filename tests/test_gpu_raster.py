@@ -238,3 +238,15 @@ def test_split_sh_storage_equals_concatenated(deg):
         assert outs[1][2][:, nb - 1:].abs().max().item() == 0      # coefficients above the active degree: zero gradient
     sp = SplitSH(sc.shs[:, :1], sc.shs[:, 1:])
     assert sp.shape == sc.shs.shape and torch.equal(sp.transpose(1, 2), sc.shs.transpose(1, 2))
+
+
+def test_debug_and_prefiltered_flags_are_accepted():
+    """`debug=True` (pipe.debug, arguments/__init__.py:68) syncs and checks after every kernel; `prefiltered`
+    is accepted for API parity.  Results are unchanged."""
+    sc = syn.random_scene(1500, seed=31)
+    cam = syn.orbit_camera(1, width=96, height=80, radius=3.0)
+    kw = U.settings_kwargs(cam, torch.zeros(3))
+    a = U.hip_render(_inputs(sc), kw, need_grad=False)
+    kw2 = dict(kw, debug=True, prefiltered=True)
+    b = U.hip_render(_inputs(sc), kw2, grad_color=np.ones((3, 80, 96), np.float32))
+    assert np.array_equal(a["color"], b["color"]) and np.isfinite(b["grads"]["means3D"]).all()
