@@ -70,6 +70,7 @@ EXPORTS = (
     "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
+    "gms_knn_workspace_bytes", "gms_knn_mean_dist2",
 )
 K_COUNT = 12
 
@@ -108,6 +109,10 @@ def load():
         lib.gms_geom_bytes.argtypes = [C.c_int32]
         lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
         lib.gms_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        lib.gms_knn_workspace_bytes.restype = C.c_size_t
+        lib.gms_knn_workspace_bytes.argtypes = [C.c_int32]
+        lib.gms_knn_mean_dist2.restype = C.c_int32
+        lib.gms_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.gms_profile_enable.argtypes = [C.c_int32]
         lib.gms_profile_enable.restype = None
         lib.gms_profile_reset.restype = None

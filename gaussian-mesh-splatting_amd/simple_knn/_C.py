@@ -1,18 +1,29 @@
-"""distCUDA2(points[N,3]) -> float[N]: mean squared distance to the 3 nearest neighbours (self excluded)."""
+"""distCUDA2(points[N,3]) -> float[N]: mean squared distance to the 3 nearest neighbours (self excluded).
+
+HIP implementation (csrc/knn.hip, uniform-grid exact search) behind `gms_knn_mean_dist2`; replaces the reference's
+un-vendored `simple_knn._C.distCUDA2` (.gitmodules:1-3; call sites scene/gaussian_model.py:134,
+games/flat_splatting/scene/flat_gaussian_model.py:47).  GPU tensors only, as upstream -- there is no CPU fallback."""
+import ctypes as C
+
 import torch
+
+from diff_gaussian_rasterization import _lib
 
 
 def distCUDA2(points: torch.Tensor) -> torch.Tensor:
-    pts = points.detach().float()
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError("distCUDA2 expects points of shape [N,3]")
+    _lib.require_gpu(points)
+    lib = _lib.load()
+    pts = points.detach().to(torch.float32).contiguous()
     n = pts.shape[0]
     out = torch.empty(n, dtype=torch.float32, device=pts.device)
     if n == 0:
         return out
-    k = min(3, max(n - 1, 1))
-    chunk = max(1, min(n, (1 << 26) // max(n, 1)))          # <= 256 MiB of distances per chunk
-    for s in range(0, n, chunk):
-        e = min(n, s + chunk)
-        d = torch.cdist(pts[s:e], pts).square_()
-        d[torch.arange(e - s, device=pts.device), torch.arange(s, e, device=pts.device)] = float("inf")
-        out[s:e] = d.topk(k, dim=1, largest=False).values.mean(dim=1) if n > 1 else 0.0
+    with torch.cuda.device(pts.device):
+        nbytes = lib.gms_knn_workspace_bytes(n)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+        rc = lib.gms_knn_mean_dist2(n, _lib.ptr(pts), _lib.ptr(out), _lib.ptr(work), nbytes,
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "gms_knn_mean_dist2")
     return out

@@ -176,6 +176,16 @@ int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *args, const float *dL_
                                        const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
                                        float *dL_dscale, void *stream);
 
+/* ---- exact 3-NN mean squared distance ---------------------------------
+ * Replaces the un-vendored `simple_knn._C.distCUDA2(points)` (.gitmodules:1-3) called at
+ * scene/gaussian_model.py:134 and games/flat_splatting/scene/flat_gaussian_model.py:47 to size the initial
+ * Gaussians: out[i] = mean of the squared distances from point i to its 3 nearest OTHER points
+ * (coincident points count with distance 0; with N < 4 the mean runs over the N-1 points there are).
+ * `workspace` is caller-owned device scratch of at least gms_knn_workspace_bytes(N) bytes. */
+size_t gms_knn_workspace_bytes(int32_t N);
+int32_t gms_knn_mean_dist2(int32_t N, const float *points /* [N,3] */, float *out /* [N] */, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
 /* ---- per-kernel timing (HIP events on the launch stream; off by default) ------------------
  * When enabled every kernel launch made by this library is bracketed by two hipEvents on the
  * caller's stream.  gms_profile_read() synchronises the recorded events and returns the summed
