@@ -43,6 +43,8 @@ def algorithmic_bytes(P, N, F, W, H):
         "mesh_bwd_face": 40 * P + 36 * F,
         "blend_tloc": 0,        # implementation passes of the segment-parallel compositing: their traffic is
         "blend_finalize": 0,    # overhead on top of blend_fwd's algorithmic bytes, not extra algorithmic work
+        "l1_ssim_fwd": 20 * 3 * HW,   # --loss l1_ssim only: read image + gt, write three derivative maps
+        "l1_ssim_bwd": 24 * 3 * HW,   # read image + gt + three maps, write dL/dimage
     }
 
 
@@ -101,6 +103,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "animate"],
                     help="train: the headline fwd+bwd step; animate: BASELINE config 5 style forward-only renders with per-frame "
                          "vertex animation and on-device re-derivation of scale/rotation (secondary line, not the headline)")
+    ap.add_argument("--loss", default="dense_grad", choices=["dense_grad", "l1_ssim"],
+                    help="dense_grad: the headline step of SURVEY 8(d), dL/dcolor = (image-0.5)/(3HW); l1_ssim: the reference's "
+                         "training loss (train.py:106-107) through the fused HIP L1+SSIM kernels against a synthetic target")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,13 +135,21 @@ def main():
     inv_norm = 1.0 / (3.0 * size * size)
     reducer = OverlappedGradAllReduce(params, world) if world > 1 else None
 
+    if args.loss == "l1_ssim":
+        from games_hip.loss import l1_ssim_loss
+        yy, xx = torch.meshgrid(torch.linspace(0, 6, size, device=device), torch.linspace(0, 5, size, device=device), indexing="ij")
+        gt_image = (0.5 + 0.4 * torch.sin(2.0 * xx) * torch.cos(1.5 * yy)).expand(3, size, size).contiguous()
+
     def step():
         model.update_alpha()
         model.prepare_scaling_rot()
         image = render(cam, model, pipe, bg)["render"]
-        with torch.no_grad():
-            grad = (image - 0.5) * inv_norm              # dL/dcolor = (image - 0.5) / (3HW), dense
-        image.backward(grad)
+        if args.loss == "l1_ssim":
+            l1_ssim_loss(image, gt_image, 0.2).backward()
+        else:
+            with torch.no_grad():
+                grad = (image - 0.5) * inv_norm          # dL/dcolor = (image - 0.5) / (3HW), dense
+            image.backward(grad)
         if reducer is not None:
             reducer.finish()      # collectives were started from autograd hooks during backward
         for p in params:
@@ -235,7 +248,8 @@ def main():
                                    f"mesh-bound Gaussians, SH degree 3, {size}x{size}, orbit camera k=rank%8, white bg",
                        "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
                        "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single view",
-                       "step": "K0 fwd + render fwd + bwd (+ grad all-reduce when N>1)"},
+                       "step": "K0 fwd + render fwd + bwd (+ grad all-reduce when N>1)"
+                               + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                          "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"], "avg_launch_us": kd["avg_us"],
                          "note": "blend kernels are VALU/LDS-bound (no dense contraction, no MFMA); HBM-bound kernels "

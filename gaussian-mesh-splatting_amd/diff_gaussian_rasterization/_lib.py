@@ -65,14 +65,22 @@ class MeshArgs(C.Structure):
     ]
 
 
+class LossArgs(C.Structure):
+    _fields_ = [
+        ("planes", C.c_int32), ("height", C.c_int32), ("width", C.c_int32), ("img", C.c_void_p), ("gt", C.c_void_p),
+        ("w_l1", C.c_float), ("w_ssim", C.c_float), ("bias", C.c_float),
+    ]
+
+
 # every symbol include/gmsplat.h declares
 EXPORTS = (
     "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
-    "gms_knn_workspace_bytes", "gms_knn_mean_dist2",
+    "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
+    "gms_l1_ssim_backward",
 )
-K_COUNT = 12
+K_COUNT = 14
 
 _lock = threading.Lock()
 _lib = None
@@ -113,6 +121,12 @@ def load():
         lib.gms_knn_workspace_bytes.argtypes = [C.c_int32]
         lib.gms_knn_mean_dist2.restype = C.c_int32
         lib.gms_knn_mean_dist2.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.gms_l1_ssim_partials.restype = C.c_size_t
+        lib.gms_l1_ssim_partials.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        lib.gms_l1_ssim_forward.restype = C.c_int32
+        lib.gms_l1_ssim_forward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
+        lib.gms_l1_ssim_backward.restype = C.c_int32
+        lib.gms_l1_ssim_backward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
         lib.gms_profile_enable.argtypes = [C.c_int32]
         lib.gms_profile_enable.restype = None
         lib.gms_profile_reset.restype = None

@@ -186,6 +186,28 @@ size_t gms_knn_workspace_bytes(int32_t N);
 int32_t gms_knn_mean_dist2(int32_t N, const float *points /* [N,3] */, float *out /* [N] */, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* ---- fused L1 + SSIM photometric loss ---------------------------------
+ * Replaces train.py:106-107 built on utils/loss_utils.py:17-18 (l1_loss) and :33-63 (ssim: 11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1=0.01^2, C2=0.03^2, mean over every pixel of every plane):
+ *     value = w_l1 * mean|img-gt| + w_ssim * mean(ssim_map(img, gt)) + bias
+ * The training loss is (w_l1, w_ssim, bias) = (1-lambda, -lambda, lambda); ssim() alone is (0, 1, 0). */
+typedef struct GmsLossArgs {
+    int32_t planes;               /* channels x batch: the window is applied per plane (conv2d groups=channel) */
+    int32_t height, width;
+    const float *img;             /* [planes,H,W] the rendered image (differentiated) */
+    const float *gt;              /* [planes,H,W] */
+    float w_l1, w_ssim, bias;
+} GmsLossArgs;
+
+/* floats needed in `partials` (per-block sums, reduced in a fixed order: the value is deterministic) */
+size_t gms_l1_ssim_partials(int32_t planes, int32_t height, int32_t width);
+/* out[3] = {value, mean|img-gt|, mean ssim}.  dmaps [3,planes,H,W] receives the derivatives of the SSIM map
+ * w.r.t. its window moments for the backward pass; NULL when no gradient is needed. */
+int32_t gms_l1_ssim_forward(const GmsLossArgs *args, float *dmaps, float *partials, float *out, void *stream);
+/* dL_dimg [planes,H,W] = dL_dvalue * dvalue/dimg; dL_dvalue is a DEVICE scalar (NULL = 1.0). */
+int32_t gms_l1_ssim_backward(const GmsLossArgs *args, const float *dmaps, const float *dL_dvalue, float *dL_dimg,
+                             void *stream);
+
 /* ---- per-kernel timing (HIP events on the launch stream; off by default) ------------------
  * When enabled every kernel launch made by this library is bracketed by two hipEvents on the
  * caller's stream.  gms_profile_read() synchronises the recorded events and returns the summed
@@ -203,7 +225,9 @@ int32_t gms_knn_mean_dist2(int32_t N, const float *points /* [N,3] */, float *ou
 #define GMS_K_MESH_BWD_FACE 9
 #define GMS_K_BLEND_TLOC 10
 #define GMS_K_BLEND_FINALIZE 11
-#define GMS_K_COUNT 12
+#define GMS_K_LOSS_FWD 12
+#define GMS_K_LOSS_BWD 13
+#define GMS_K_COUNT 14
 void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);

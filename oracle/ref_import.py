@@ -54,6 +54,7 @@ def import_reference():
     ns.general_utils = importlib.import_module("utils.general_utils")
     ns.sh_utils = importlib.import_module("utils.sh_utils")
     ns.graphics_utils = importlib.import_module("utils.graphics_utils")
+    ns.loss_utils = importlib.import_module("utils.loss_utils")
     ns.gaussian_model = importlib.import_module("scene.gaussian_model")
     ns.mesh_model = importlib.import_module("games.mesh_splatting.scene.gaussian_mesh_model")
     ns.multi_mesh_model = importlib.import_module("games.multi_mesh_splatting.scene.gaussian_multi_mesh_model")

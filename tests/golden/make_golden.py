@@ -13,6 +13,8 @@ What is pinned here (reference code executed, CPU, float32):
   stages.npz         eval_sh (utils/sh_utils.py:57), geom_transform_points (utils/graphics_utils.py:22),
                      build_covariance_from_scaling_rotation (scene/gaussian_model.py:27-31),
                      rot_to_quat_batch (utils/general_utils.py:43), getProjectionMatrix/getWorld2View2
+  loss.npz           l1_loss / ssim (utils/loss_utils.py:17-63) and the training loss of train.py:106-107 with its
+                     autograd gradient w.r.t. the rendered image, on two image pairs
 The rasterizer itself cannot be pinned this way (source absent from the reference tree).
 """
 import os
@@ -69,10 +71,37 @@ def run_mesh_model(ref, vertices, faces, _alpha, _scale, seed):
         d_vertices=m.vertices.grad, d_alpha=m._alpha.grad, d_scale=m._scale.grad)
 
 
+def loss_fixture(ref):
+    """Photometric loss: reference functions executed on CPU float32."""
+    g = torch.Generator().manual_seed(21)
+    d = {}
+    for tag, shape in (("a", (3, 70, 90)), ("b", (1, 3, 40, 33))):
+        yy, xx = torch.meshgrid(torch.linspace(0, 3, shape[-2]), torch.linspace(0, 4, shape[-1]), indexing="ij")
+        base = 0.5 + 0.4 * torch.sin(2.1 * xx + 0.3) * torch.cos(1.7 * yy)
+        gt = (base.expand(shape) + 0.05 * torch.randn(shape, generator=g)).clamp(0, 1).contiguous()
+        img = (gt + 0.1 * torch.randn(shape, generator=g)).clamp(0, 1)
+        img[..., :8, :8] = gt[..., :8, :8]                       # exactly-equal block: sign(0) = 0 in the L1 gradient
+        img[..., 20:30, 50:] = 0.0                               # flat region: variance terms vanish
+        img = img.contiguous().requires_grad_(True)
+        l1 = ref.loss_utils.l1_loss(img, gt)
+        ss = ref.loss_utils.ssim(img, gt)
+        loss = (1.0 - 0.2) * l1 + 0.2 * (1.0 - ss)
+        loss.backward()
+        d.update({f"img_{tag}": img.detach(), f"gt_{tag}": gt, f"l1_{tag}": l1.detach(), f"ssim_{tag}": ss.detach(),
+                  f"loss_{tag}": loss.detach(), f"d_img_{tag}": img.grad.clone()})
+        img.grad = None
+        ref.loss_utils.ssim(img, gt).backward()
+        d[f"d_ssim_{tag}"] = img.grad.clone()
+    return d
+
+
 def main():
     ref = ref_import.import_reference()
     torch.manual_seed(0)
     tonp = lambda d: {k: (v.numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+    np.savez_compressed(os.path.join(HERE, "loss.npz"), **tonp(loss_fixture(ref)))
+    if "--only-loss" in sys.argv:
+        return
 
     # ---- K0 single mesh
     v, f, a, s = k0_inputs(0, 8, 10, 2)
