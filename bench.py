@@ -45,6 +45,7 @@ def algorithmic_bytes(P, N, F, W, H):
         "blend_finalize": 0,    # overhead on top of blend_fwd's algorithmic bytes, not extra algorithmic work
         "l1_ssim_fwd": 20 * 3 * HW,   # --loss l1_ssim only: read image + gt, write three derivative maps
         "l1_ssim_bwd": 24 * 3 * HW,   # read image + gt + three maps, write dL/dimage
+        "adam": 28 * (3 * F // 2 + 6 + 52 * P),   # --optimizer fused_adam: 16 B read + 12 B written per parameter element
     }
 
 
@@ -106,6 +107,10 @@ def main():
     ap.add_argument("--loss", default="dense_grad", choices=["dense_grad", "l1_ssim"],
                     help="dense_grad: the headline step of SURVEY 8(d), dL/dcolor = (image-0.5)/(3HW); l1_ssim: the reference's "
                          "training loss (train.py:106-107) through the fused HIP L1+SSIM kernels against a synthetic target")
+    ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
+                    help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
+                         "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
+                         "the scene, and with it the work per step, stays fixed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,6 +145,10 @@ def main():
         yy, xx = torch.meshgrid(torch.linspace(0, 6, size, device=device), torch.linspace(0, 5, size, device=device), indexing="ij")
         gt_image = (0.5 + 0.4 * torch.sin(2.0 * xx) * torch.cos(1.5 * yy)).expand(3, size, size).contiguous()
 
+    if args.optimizer != "none":
+        model.training_setup(vertices_lr=1e-12, alpha_lr=1e-12, feature_lr=1e-12, opacity_lr=1e-12, scaling_lr=1e-12,
+                             fused=args.optimizer == "fused_adam")
+
     def step():
         model.update_alpha()
         model.prepare_scaling_rot()
@@ -152,8 +161,12 @@ def main():
             image.backward(grad)
         if reducer is not None:
             reducer.finish()      # collectives were started from autograd hooks during backward
-        for p in params:
-            p.grad = None
+        if args.optimizer != "none":
+            model.optimizer.step()
+            model.optimizer.zero_grad(set_to_none=True)
+        else:
+            for p in params:
+                p.grad = None
 
     def sync():
         if world > 1:
@@ -249,7 +262,8 @@ def main():
                        "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
                        "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single view",
                        "step": "K0 fwd + render fwd + bwd (+ grad all-reduce when N>1)"
-                               + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")},
+                               + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")
+                               + (f" + optimizer.step() [{args.optimizer}]" if args.optimizer != "none" else "")},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                          "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"], "avg_launch_us": kd["avg_us"],
                          "note": "blend kernels are VALU/LDS-bound (no dense contraction, no MFMA); HBM-bound kernels "

@@ -72,15 +72,22 @@ class LossArgs(C.Structure):
     ]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [
+        ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("n", C.c_int64), ("lr", C.c_float), ("step", C.c_int32),
+    ]
+
+
 # every symbol include/gmsplat.h declares
 EXPORTS = (
     "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
-    "gms_l1_ssim_backward",
+    "gms_l1_ssim_backward", "gms_adam_step",
 )
-K_COUNT = 14
+K_COUNT = 15
 
 _lock = threading.Lock()
 _lib = None
@@ -127,6 +134,8 @@ def load():
         lib.gms_l1_ssim_forward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
         lib.gms_l1_ssim_backward.restype = C.c_int32
         lib.gms_l1_ssim_backward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
+        lib.gms_adam_step.restype = C.c_int32
+        lib.gms_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
         lib.gms_profile_enable.argtypes = [C.c_int32]
         lib.gms_profile_enable.restype = None
         lib.gms_profile_reset.restype = None

@@ -168,7 +168,8 @@ class HipGaussianMeshModel(HipMeshMixin):
     def parameters(self):
         return [self.vertices, self._alpha, self._features_dc, self._features_rest, self._opacity, self._scale]
 
-    def training_setup(self, vertices_lr=0.0, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005):
+    def training_setup(self, vertices_lr=0.0, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+                       fused=True):
         groups = [
             {"params": [self.vertices], "lr": vertices_lr, "name": "vertices"},
             {"params": [self._alpha], "lr": alpha_lr, "name": "alpha"},
@@ -177,7 +178,11 @@ class HipGaussianMeshModel(HipMeshMixin):
             {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
             {"params": [self._scale], "lr": scaling_lr, "name": "scaling"},
         ]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        if fused:       # one HIP launch per step (csrc/adam.hip); same state layout as torch.optim.Adam
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
     @property
     def get_xyz(self):

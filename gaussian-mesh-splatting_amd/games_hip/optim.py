@@ -1,0 +1,61 @@
+"""FusedAdam: `torch.optim.Adam` for the reference's training_setup() with the whole step in one HIP launch.
+
+Drop-in for `torch.optim.Adam(l_params, lr=0.0, eps=1e-15)` (games/mesh_splatting/scene/gaussian_mesh_model.py:183,
+scene/gaussian_model.py:160): same constructor, same `param_groups` (per-group 'lr' / 'name'), same `state` layout
+({'step', 'exp_avg', 'exp_avg_sq'} per parameter) so the reference's optimizer surgery during densification
+(scene/gaussian_model.py:284-375 replace/cat/prune of `optimizer.state`) and `state_dict()` checkpoints keep working.
+csrc/adam.hip does the arithmetic of torch/optim/adam.py::_single_tensor_adam; GPU float32 parameters only."""
+import ctypes as C
+
+import torch
+
+from diff_gaussian_rasterization import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("FusedAdam implements what the reference uses: no weight decay, no amsgrad")
+        if not 0.0 <= lr or not 0.0 <= eps or not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError("invalid Adam hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        by_hyper = {}
+        keep = []
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdam does not support sparse gradients")
+                _lib.require_gpu(p)
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam needs contiguous float32 parameters")
+                state = self.state[p]
+                if len(state) == 0:
+                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                state["step"] += 1
+                g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.float().contiguous()
+                m, v = state["exp_avg"], state["exp_avg_sq"]
+                if not (m.is_contiguous() and v.is_contiguous()):
+                    m, v = state["exp_avg"], state["exp_avg_sq"] = m.contiguous(), v.contiguous()
+                keep.append(g)
+                by_hyper.setdefault((p.device, float(beta1), float(beta2), float(group["eps"])), []).append(
+                    _lib.AdamTensor(param=p.data_ptr(), grad=g.data_ptr(), exp_avg=m.data_ptr(), exp_avg_sq=v.data_ptr(),
+                                    n=p.numel(), lr=float(group["lr"]), step=int(state["step"])))
+        for (device, beta1, beta2, eps), tensors in by_hyper.items():
+            arr = (_lib.AdamTensor * len(tensors))(*tensors)
+            with torch.cuda.device(device):
+                rc = lib.gms_adam_step(arr, len(tensors), beta1, beta2, eps, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "gms_adam_step")
+        return loss

@@ -208,6 +208,24 @@ int32_t gms_l1_ssim_forward(const GmsLossArgs *args, float *dmaps, float *partia
 int32_t gms_l1_ssim_backward(const GmsLossArgs *args, const float *dmaps, const float *dL_dvalue, float *dL_dimg,
                              void *stream);
 
+/* ---- multi-tensor Adam step --------------------------------------------
+ * Replaces `gaussians.optimizer.step()` (train.py:147) for torch.optim.Adam(groups, lr=0.0, eps=1e-15) as built
+ * by training_setup() (games/mesh_splatting/scene/gaussian_mesh_model.py:174-183): every tensor of every group in
+ * one launch (per GMS_ADAM_MAX_TENSORS tensors).  `step` is the 1-based step count AFTER the increment, `lr` the
+ * group's learning rate.  No amsgrad / weight decay / maximize (the reference uses none). */
+#define GMS_ADAM_MAX_TENSORS 16
+typedef struct GmsAdamTensor {
+    float *param;                 /* [n] updated in place */
+    const float *grad;            /* [n] */
+    float *exp_avg;               /* [n] updated in place */
+    float *exp_avg_sq;            /* [n] updated in place */
+    int64_t n;
+    float lr;
+    int32_t step;
+} GmsAdamTensor;
+int32_t gms_adam_step(const GmsAdamTensor *tensors /* HOST array */, int32_t count, double beta1, double beta2, double eps,
+                      void *stream);
+
 /* ---- per-kernel timing (HIP events on the launch stream; off by default) ------------------
  * When enabled every kernel launch made by this library is bracketed by two hipEvents on the
  * caller's stream.  gms_profile_read() synchronises the recorded events and returns the summed
@@ -227,7 +245,8 @@ int32_t gms_l1_ssim_backward(const GmsLossArgs *args, const float *dmaps, const 
 #define GMS_K_BLEND_FINALIZE 11
 #define GMS_K_LOSS_FWD 12
 #define GMS_K_LOSS_BWD 13
-#define GMS_K_COUNT 14
+#define GMS_K_ADAM 14
+#define GMS_K_COUNT 15
 void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);

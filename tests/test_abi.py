@@ -32,13 +32,13 @@ def test_struct_layouts_match_the_header():
     import subprocess
     import tempfile
     from diff_gaussian_rasterization import _lib
-    src = '#include <stdio.h>\n#include "gmsplat.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(GmsRasterForwardArgs), sizeof(GmsRasterBackwardArgs), sizeof(GmsMeshArgs), sizeof(GmsLossArgs));return 0;}\n'
+    src = '#include <stdio.h>\n#include "gmsplat.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(GmsRasterForwardArgs), sizeof(GmsRasterBackwardArgs), sizeof(GmsMeshArgs), sizeof(GmsLossArgs), sizeof(GmsAdamTensor));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")], check=True)
         sizes = [int(x) for x in subprocess.run([os.path.join(d, "p")], capture_output=True, text=True, check=True).stdout.split()]
     assert sizes == [ctypes.sizeof(_lib.RasterForwardArgs), ctypes.sizeof(_lib.RasterBackwardArgs), ctypes.sizeof(_lib.MeshArgs),
-                     ctypes.sizeof(_lib.LossArgs)]
+                     ctypes.sizeof(_lib.LossArgs), ctypes.sizeof(_lib.AdamTensor)]
 
 
 def test_python_surface_matches_reference_call_sites():
