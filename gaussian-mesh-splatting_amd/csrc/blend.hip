@@ -284,46 +284,41 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
 // ------------------------------------------------------------------------------------ bwd
 // per-pixel state of the back-to-front recurrence
 struct BwdState {
-    float T, acc0, acc1, acc2, accd, last_alpha, lc0, lc1, lc2, lastd;
+    float T, acc0, acc1, acc2, accd;      // transmittance after, and colour / inverse depth composited behind, the cursor
 };
 
-// One splat against one pixel, branch-free: updates the recurrence and returns the ten partial gradients
-// v = (mean2D.x, mean2D.y, conic A, conic B, conic C, opacity, r, g, b, inverse depth).  A lane for which the
-// pair is inactive runs the same code with alpha = opacity = G = 0: a zero-alpha splat is transparent to the
-// recurrence (T unchanged; acc <- last_alpha*lc + (1-last_alpha)*acc commits the previous splat, then
-// last_alpha = 0 makes the next step reproduce that value exactly) and every output becomes exactly 0.
-__device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r0, const float4 &r1, const float4 &r2,
-                                         float dx, float dy, float G_in, float alpha_in, float dp0, float dp1, float dp2,
-                                         float dinvd, float Tfinal, float bgdot, float halfW, float halfH, float *v)
+// One splat against one pixel, branch-free: updates the recurrence and returns ten partial sums
+// v = (q dx, q dy, q dx^2, q dx dy, q dy^2, q, w r', w g', w b', w d') with q = dL/dG * G: the geometric part is
+// accumulated as MOMENTS of q -- the map to the gradients of (mean2D, conic, opacity) is linear with per-splat
+// constants and is applied once per Gaussian in preprocess_bwd.  A lane for which the pair is inactive runs the
+// same code with alpha = G = 0: a zero-alpha splat is transparent to the recurrence (T and the colour behind stay
+// exactly as they were) and every output becomes exactly 0.
+template <bool INVD>
+__device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1, const float4 &r2, float dx, float dy,
+                                         float G_in, float alpha_in, float dp0, float dp1, float dp2, float dinvd,
+                                         float Tfinal_bgdot, float *v)
 {
-    const float alpha = act ? alpha_in : 0.f, G = act ? G_in : 0.f, op = act ? r1.y : 0.f;
-    const float rcp1ma = __builtin_amdgcn_rcpf(1.f - alpha);   // 1 - alpha >= 0.01; rcp(1) == 1
-    s.T = s.T * rcp1ma;
+    const float alpha = act ? alpha_in : 0.f;
+    const float Gop = act ? G_in * r1.y : 0.f;                 // alpha = min(0.99, op*G) is straight-through
+    const float om = 1.f - alpha;
+    const float rcp1ma = __builtin_amdgcn_rcpf(om);            // 1 - alpha >= 0.01; rcp(1) == 1
+    s.T = s.T * rcp1ma;                                        // transmittance in front of this splat
     const float w = alpha * s.T;
-    const float om = 1.f - s.last_alpha;
-    s.acc0 = s.last_alpha * s.lc0 + om * s.acc0;
-    s.acc1 = s.last_alpha * s.lc1 + om * s.acc1;
-    s.acc2 = s.last_alpha * s.lc2 + om * s.acc2;
-    s.accd = s.last_alpha * s.lastd + om * s.accd;
-    s.lc0 = r1.z; s.lc1 = r1.w; s.lc2 = r2.x; s.lastd = r2.y;
-    float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2 + (r2.y - s.accd) * dinvd;
-    v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = w * dinvd;
-    dL_dalpha *= s.T;
-    s.last_alpha = alpha;
-    dL_dalpha -= Tfinal * rcp1ma * bgdot;
-    const float dL_dG = op * dL_dalpha;                        // alpha = min(0.99, op*G) is straight-through
-    const float gdx = G * dx, gdy = G * dy;
-    const float dG_ddx = -gdx * r0.z - gdy * r0.w;
-    const float dG_ddy = -gdy * r1.x - gdx * r0.w;
-    v[0] = dL_dG * dG_ddx * halfW;
-    v[1] = dL_dG * dG_ddy * halfH;
-    const float h = -0.5f * dL_dG;
-    v[2] = h * gdx * dx;
-    v[3] = h * gdx * dy;
-    v[4] = h * gdy * dy;
-    v[5] = G * dL_dalpha;
+    float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2;
+    if (INVD) dL_dalpha += (r2.y - s.accd) * dinvd;
+    dL_dalpha = dL_dalpha * s.T - Tfinal_bgdot * rcp1ma;
+    // colour composited behind the NEXT (nearer) splat
+    s.acc0 = alpha * r1.z + om * s.acc0;
+    s.acc1 = alpha * r1.w + om * s.acc1;
+    s.acc2 = alpha * r2.x + om * s.acc2;
+    if (INVD) s.accd = alpha * r2.y + om * s.accd;
+    v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = INVD ? w * dinvd : 0.f;
+    const float q = Gop * dL_dalpha;
+    const float qx = q * dx, qy = q * dy;
+    v[0] = qx; v[1] = qy; v[2] = qx * dx; v[3] = qx * dy; v[4] = qy * dy; v[5] = q;
 }
 
+template <bool INVD>
 __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     __shared__ SplatRec recs[QUEUE];
@@ -347,12 +342,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
     if (p.inside) {
         dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
-        if (a.dL_dinvd) dinvd = a.dL_dinvd[pid];
+        if (INVD) dinvd = a.dL_dinvd[pid];
     }
-    const float bgdot = a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2;
+    const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
     const uint32_t seg_lo = u.beg - u.tile_beg, seg_hi = u.end - u.tile_beg;   // positions covered by this unit
 
-    BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
     if (u.nseg > 1) {
         const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
         const float te = st[SEG_TEND * TILE_PIX + tid];
@@ -366,13 +361,12 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 const float *sk = g.seg_state + (size_t)(u.slot0 + k) * SEG_FLOATS;
                 if (sk[SEG_TEND * TILE_PIX + tid] < 0.f) break;
                 S0 += sk[SEG_C0 * TILE_PIX + tid]; S1 += sk[SEG_C1 * TILE_PIX + tid]; S2 += sk[SEG_C2 * TILE_PIX + tid];
-                SD += sk[SEG_D * TILE_PIX + tid];
+                if (INVD) SD += sk[SEG_D * TILE_PIX + tid];
             }
             const float inv = 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
         }
     }
-    const float halfW = 0.5f * g.W, halfH = 0.5f * g.H;
 
     // wave_reduce10 leaves the ten totals in lanes 0,8,...,56 (y0) and 4, 36 (y1): those ten lanes add
     // into the ten fields of the splat's 64-byte gradient record with ONE atomic instruction.
@@ -389,7 +383,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     }
     if (lane == 4) afield = GRAD_B;
     if (lane == 36) afield = GRAD_ID;
-    const bool alane = (lane & 7) == 0 || lane == 4 || (lane == 36 && a.has_invd);
+    const bool alane = (lane & 7) == 0 || lane == 4 || (lane == 36 && INVD);
     float *const abase = a.accum + afield;
     const bool use_y1 = (lane & 7) != 0;
 
@@ -442,8 +436,8 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                 float va[10], vb[10];
                 const bool noatomics = (g.dbg & 1u) != 0;                 // experiment switch
                 if (anya && anyb) {
-                    bwd_step(st8, acta, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
-                    bwd_step(st8, actb, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                    bwd_step<INVD>(st8, acta, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                    bwd_step<INVD>(st8, actb, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
                     if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
                     float y0a, y1a, y0b, y1b;
                     wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
@@ -454,13 +448,13 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                         unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
                     }
                 } else if (anya) {
-                    bwd_step(st8, acta, a0, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, va);
+                    bwd_step<INVD>(st8, acta, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
                     float y0, y1;
                     wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
                     if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
                     if (alane) unsafeAtomicAdd(abase + (size_t)ids[ka] * GRAD_STRIDE, use_y1 ? y1 : y0);
                 } else {
-                    bwd_step(st8, actb, b0, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal, bgdot, halfW, halfH, vb);
+                    bwd_step<INVD>(st8, actb, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
                     float y0, y1;
                     wave_reduce10(vb[0], vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7], vb[8], vb[9], y0, y1);
                     if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
@@ -507,7 +501,10 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
         if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
     }
     const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
-    GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, a));
+    if (a.has_invd && a.dL_dinvd)
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<true><<<blocks, BLOCK, 0, stream>>>(g, a));
+    else
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<false><<<blocks, BLOCK, 0, stream>>>(g, a));
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
     return GMS_OK;
 }

@@ -170,10 +170,14 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         const float4 *rec = reinterpret_cast<const float4 *>(a.accum + (size_t)i * GRAD_STRIDE);
         ga = rec[0]; gb = rec[1]; gc4 = rec[2];
     }
-    const float acc_mx = ga.x, acc_my = ga.y, acc_ca = ga.z, acc_cb = ga.w, acc_cc = gb.x;
+    // blend_bwd accumulates MOMENTS of q = dL/dG * G over the pixels (gms_blend.h GRAD_*): sum q*dx, q*dy, q*dx*dx,
+    // q*dx*dy, q*dy*dy and sum q.  The per-splat linear map to the gradients of (pixel mean, conic, opacity') uses
+    // only per-Gaussian constants (conic, opacity'), so it is applied once here instead of per pixel pair there.
+    const float mom_x = ga.x, mom_y = ga.y, mom_xx = ga.z, mom_xy = ga.w, mom_yy = gb.x, mom_0 = gb.y;
+    float acc_mx = 0.f, acc_my = 0.f;
     const float acc_col[3] = {gb.z, gb.w, gc4.x};
     const float acc_id = gc4.y;
-    float dop = gb.y;
+    float dop = 0.f;
     float *row = wl + lane * SH_PITCH_B;
 
     if (vis) {
@@ -197,7 +201,18 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         ewa_project(V, vx, vy, vz, cv, fx, fy, 1.3f * a.tanx, 1.3f * a.tany, e);
         const float b = e.b, aD = e.a0 + DILATE, cD = e.c0 + DILATE;
         const float det = aD * cD - b * b;
-        const float gA = acc_ca, gB = acc_cb, gC = acc_cc;
+        {
+            // conic exactly as preprocess_fwd formed it; d power / d(dx) = -(A dx + B dy), d power / dA = -dx^2/2,
+            // d power / dB carries the reference's 1/2, alpha = opacity' * G (straight-through clamp)
+            const float dinv = 1.f / det;
+            const float cA = cD * dinv, cB = -b * dinv, cC = aD * dinv;
+            acc_mx = -(0.5f * (float)a.W) * (cA * mom_x + cB * mom_y);
+            acc_my = -(0.5f * (float)a.H) * (cC * mom_y + cB * mom_x);
+            float opp = a.opac[i];
+            if (a.aa) opp *= sqrtf(fmaxf(0.000025f, (e.a0 * e.c0 - b * b) / det));
+            dop = opp > 0.f ? mom_0 / opp : 0.f;
+        }
+        const float gA = -0.5f * mom_xx, gB = -0.5f * mom_xy, gC = -0.5f * mom_yy;
         const float d2inv = 1.f / (det * det + 0.0000001f);
         float dL_da = d2inv * (-cD * cD * gA + 2.f * b * cD * gB + (det - aD * cD) * gC);
         float dL_dc = d2inv * (-aD * aD * gC + 2.f * aD * b * gB + (det - aD * cD) * gA);

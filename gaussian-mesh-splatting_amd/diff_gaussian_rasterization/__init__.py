@@ -134,6 +134,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         lib = _lib.load()
         _lib.require_gpu(means3D, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)
         device = means3D.device
+        # an output the loss does not use (inverse depth in train.py) arrives as None in backward instead of a
+        # materialised zero image: the backward kernels then skip that channel altogether
+        ctx.set_materialize_grads(False)
         if means3D.dim() != 2 or means3D.shape[1] != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")
         P = int(means3D.shape[0])
