@@ -94,12 +94,18 @@ __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cn
     return !(q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1);
 }
 
+// experiment (GMS_DBG timelines): lane 0 of every wave records [start, end] of its wave on every exit path
+struct Stamp {
+    unsigned long long *buf, t0; uint32_t block; bool on;
+    __device__ __forceinline__ Stamp(unsigned long long *b) : buf(b), t0(b ? wall_clock64() : 0ull), block(blockIdx.x),
+        on(b != nullptr && (threadIdx.x & 63) == 0) { if (on) buf = b + 8ull * 65536ull * (threadIdx.x >> 6); }
+    __device__ __forceinline__ ~Stamp() { if (on) { buf[2 * (size_t)block] = t0; buf[2 * (size_t)block + 1] = wall_clock64(); } }
+};
+
 // ------------------------------------------------------------------------------------ tloc
-__global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const SplatRec *rec, int phase)
+template <int NE>
+__device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase)
 {
-    __shared__ SplatRec recs[QUEUE];
-    Unit u;
-    if (!load_unit(g, u)) return;
     if (u.nseg == 1 || u.seg == u.nseg - 1) return;
     // phase 0: the first TLOC_HEAD segments of every tile; phase 1: the rest, unless the head already
     // finished every pixel of the tile (then the products are irrelevant: write 0, evaluate nothing)
@@ -123,21 +129,24 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_kernel(BlendGrid g, const Sp
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
             while (mask) {
-                // two queue entries per trip: their alpha evaluations are independent (ILP hides the
-                // LDS and exp latency); only the transmittance product is sequential
-                const int ka = chunk + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const bool two = mask != 0;
-                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
-                mask &= mask - 1;                                   // no-op when mask is already 0
-                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, b0 = recs[kb].q0, b1 = recs[kb].q1;
-                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
-                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
-                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
-                const float ala = fminf(ALPHA_MAX, a1.y * __expf(pa));
-                const float alb = fminf(ALPHA_MAX, b1.y * __expf(pb));
-                if (pa <= 0.f && ala >= ALPHA_MIN) Tl *= (1.f - ala);
-                if (two && pb <= 0.f && alb >= ALPHA_MIN) Tl *= (1.f - alb);
+                // NE queue entries per trip: independent alpha evaluations, sequential transmittance product
+                int k[NE]; bool val[NE]; float al[NE], pw[NE];
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    val[e] = mask != 0;
+                    k[e] = val[e] ? chunk + __builtin_ctzll(mask) : k[e > 0 ? e - 1 : 0];
+                    mask &= mask - 1;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const float4 r0 = recs[k[e]].q0, r1 = recs[k[e]].q1;
+                    const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                    pw[e] = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                    al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++)
+                    if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
             }
         }
     }
@@ -161,11 +170,9 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_check_kernel(BlendGrid g)
 }
 
 // ------------------------------------------------------------------------------------ fwd
-__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
+template <int NE>
+__device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs)
 {
-    __shared__ SplatRec recs[QUEUE];
-    Unit u;
-    if (!load_unit(g, u)) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const Pix p = pixel_of(g, u);
 
@@ -186,41 +193,34 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdO
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
             while (mask) {
-                // two queue entries per trip (independent alpha evaluation, sequential compositing)
-                const int ka = chunk + __builtin_ctzll(mask);       // wave-uniform queue slots
-                mask &= mask - 1;
-                const bool two = mask != 0;
-                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
-                mask &= mask - 1;
-                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, a2 = recs[ka].q2;
-                const float4 b0 = recs[kb].q0, b1 = recs[kb].q1, b2 = recs[kb].q2;
-                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
-                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
-                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
-                const float ala = fminf(ALPHA_MAX, a1.y * __expf(pa));
-                const float alb = fminf(ALPHA_MAX, b1.y * __expf(pb));
-                {
-                    bool act = !done && pa <= 0.f && ala >= ALPHA_MIN;
-                    const float testT = T * (1.f - ala);
-                    if (act && testT < T_MIN) { done = true; act = false; }
-                    if (act) {
-                        const float w = ala * T;
-                        C0 += a1.z * w; C1 += a1.w * w; C2 += a2.x * w;
-                        Dp += a2.y * w;
-                        T = testT;
-                        last = (base - u.tile_beg) + (uint32_t)ka + 1u;
-                    }
+                // NE queue entries per trip: their alpha evaluations are independent (ILP hides the LDS and exp
+                // latency when few waves are resident); only the compositing recurrence is sequential
+                int k[NE]; bool val[NE]; float al[NE], pw[NE]; float4 r1[NE], r2[NE];
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    val[e] = mask != 0;
+                    k[e] = val[e] ? chunk + __builtin_ctzll(mask) : k[e > 0 ? e - 1 : 0];   // wave-uniform queue slots
+                    mask &= mask - 1;                                                         // no-op once mask is 0
                 }
-                if (two) {
-                    bool act = !done && pb <= 0.f && alb >= ALPHA_MIN;
-                    const float testT = T * (1.f - alb);
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const float4 r0 = recs[k[e]].q0;
+                    r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
+                    const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                    pw[e] = -0.5f * (r0.z * dx * dx + r1[e].x * dy * dy) - r0.w * dx * dy;
+                    al[e] = fminf(ALPHA_MAX, r1[e].y * __expf(pw[e]));
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
+                    const float testT = T * (1.f - al[e]);
                     if (act && testT < T_MIN) { done = true; act = false; }
                     if (act) {
-                        const float w = alb * T;
-                        C0 += b1.z * w; C1 += b1.w * w; C2 += b2.x * w;
-                        Dp += b2.y * w;
+                        const float w = al[e] * T;
+                        C0 += r1[e].z * w; C1 += r1[e].w * w; C2 += r2[e].x * w;
+                        Dp += r2[e].y * w;
                         T = testT;
-                        last = (base - u.tile_beg) + (uint32_t)kb + 1u;
+                        last = (base - u.tile_beg) + (uint32_t)k[e] + 1u;
                     }
                 }
                 if (__all(done)) break;
@@ -243,7 +243,36 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdO
         st[SEG_D * TILE_PIX + tid] = Dp;
         st[SEG_TEND * TILE_PIX + tid] = dead_on_entry ? -1.f : T;
         st[SEG_LAST * TILE_PIX + tid] = __uint_as_float(last);
+        // the first segment's exact walk doubles as its transmittance product: a pixel that terminated here is
+        // dead on entry to every later segment (any value < 1e-4 says so); one that did not has multiplied
+        // exactly the (1 - alpha) factors the product would
+        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + tid] = done ? 0.f : T;
     }
+}
+
+// First launch: every unit that depends on nothing -- the exact walk of each tile's FIRST segment (single-segment
+// tiles are finished by it) and, for the middle segments of multi-segment tiles, the transmittance products.
+template <int NE>
+__global__ void __launch_bounds__(BLOCK) blend_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
+{
+    __shared__ SplatRec recs[QUEUE];
+    Unit u;
+    if (!load_unit(g, u)) return;
+    Stamp stamp((g.dbg & 256u) ? g.dbg_buf : nullptr);
+    if (u.seg == 0) { if (phase <= 0 && !(g.dbg & 32u)) fwd_unit<NE>(g, o, u, recs); }
+    else if (!(g.dbg & 64u)) tloc_unit<NE>(g, o.rec, u, recs, phase);
+}
+
+// Second launch: segments 1.. of the multi-segment tiles, from the prefix product of the segments in front.
+template <int NE>
+__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
+{
+    __shared__ SplatRec recs[QUEUE];
+    Unit u;
+    if (!load_unit(g, u)) return;
+    if (u.seg == 0) return;
+    Stamp stamp((g.dbg & 128u) ? g.dbg_buf : nullptr);
+    fwd_unit<NE>(g, o, u, recs);
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -318,7 +347,7 @@ __device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1
     v[0] = qx; v[1] = qy; v[2] = qx * dx; v[3] = qx * dy; v[4] = qy * dy; v[5] = q;
 }
 
-template <bool INVD>
+template <bool INVD, int NE>
 __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     __shared__ SplatRec recs[QUEUE];
@@ -328,12 +357,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     if (!load_unit(g, u)) return;
     if (u.end <= u.beg) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long t_start = g.dbg_buf ? wall_clock64() : 0ull;
-    struct Stamp {      // experiment: wave 0 lane 0 records [start, end] of its wave on every exit path
-        unsigned long long *buf, t0; uint32_t block; bool on;
-        __device__ ~Stamp() { if (on) { buf[2 * (size_t)block] = t0; buf[2 * (size_t)block + 1] = wall_clock64(); } }
-    } stamp{g.dbg_buf, t_start, blockIdx.x, g.dbg_buf != nullptr && lane == 0};
-    if (stamp.on) stamp.buf = g.dbg_buf + 8ull * 65536ull * (unsigned)wave;      // one region per wave index
+    Stamp stamp((g.dbg & 16u) ? g.dbg_buf : nullptr);
     const Pix p = pixel_of(g, u);
     const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
@@ -414,51 +438,54 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
             if (g.dbg & 4u) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
-                // two queue entries per trip: loads, exp and the two wave reductions are independent and
-                // interleave; only the per-pixel recurrence is sequential (entry a is behind entry b)
-                const int ka = chunk + __builtin_ctzll(mask);
-                mask &= mask - 1;
-                const bool two = mask != 0;
-                const int kb = two ? chunk + __builtin_ctzll(mask) : ka;
-                mask &= mask - 1;
-                const uint32_t posa = hi - 1 - (uint32_t)ka, posb = hi - 1 - (uint32_t)kb;   // 0-based tile positions
-                const float4 a0 = recs[ka].q0, a1 = recs[ka].q1, a2 = recs[ka].q2;
-                const float4 b0 = recs[kb].q0, b1 = recs[kb].q1, b2 = recs[kb].q2;
-                const float dxa = a0.x - p.xf, dya = a0.y - p.yf, dxb = b0.x - p.xf, dyb = b0.y - p.yf;
-                const float pa = -0.5f * (a0.z * dxa * dxa + a1.x * dya * dya) - a0.w * dxa * dya;
-                const float pb = -0.5f * (b0.z * dxb * dxb + b1.x * dyb * dyb) - b0.w * dxb * dyb;
-                const float Ga = __expf(pa), Gb = __expf(pb);
-                const float ala = fminf(ALPHA_MAX, a1.y * Ga), alb = fminf(ALPHA_MAX, b1.y * Gb);
-                const bool acta = posa < last && pa <= 0.f && ala >= ALPHA_MIN;
-                const bool actb = two && posb < last && pb <= 0.f && alb >= ALPHA_MIN;
-                const bool anya = __any(acta), anyb = __any(actb);
-                if (!(anya || anyb)) continue;
-                float va[10], vb[10];
-                const bool noatomics = (g.dbg & 1u) != 0;                 // experiment switch
-                if (anya && anyb) {
-                    bwd_step<INVD>(st8, acta, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
-                    bwd_step<INVD>(st8, actb, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
-                    if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
-                    float y0a, y1a, y0b, y1b;
-                    wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
-                    if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
-                    const size_t ida = ids[ka], idb = ids[kb];
-                    if (alane) {
-                        unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
-                        unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
+                // NE queue entries per trip: loads, exp and the wave reductions of different entries are independent
+                // and interleave; only the per-pixel recurrence is sequential (entry e is behind entry e+1)
+                int k[NE]; bool val[NE], act[NE], any[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE];
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    val[e] = mask != 0;
+                    k[e] = val[e] ? chunk + __builtin_ctzll(mask) : k[e > 0 ? e - 1 : 0];
+                    mask &= mask - 1;
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    const float4 r0 = recs[k[e]].q0;
+                    r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
+                    dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
+                    const float pw = -0.5f * (r0.z * dx[e] * dx[e] + r1[e].x * dy[e] * dy[e]) - r0.w * dx[e] * dy[e];
+                    G[e] = __expf(pw);
+                    al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
+                    const uint32_t pos = hi - 1 - (uint32_t)k[e];                  // 0-based tile position
+                    act[e] = val[e] && pos < last && pw <= 0.f && al[e] >= ALPHA_MIN;
+                    any[e] = __any(act[e]);
+                }
+                const bool noatomics = (g.dbg & 1u) != 0;                           // experiment switch
+#pragma unroll
+                for (int e = 0; e < NE; e += 2) {
+                    const int f = e + 1;
+                    if (!(any[e] || any[f])) continue;
+                    float va[10], vb[10];
+                    if (any[e] && any[f]) {
+                        bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                        bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
+                        if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
+                        float y0a, y1a, y0b, y1b;
+                        wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
+                        if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
+                        const size_t ida = ids[k[e]], idb = ids[k[f]];
+                        if (alane) {
+                            unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
+                            unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
+                        }
+                    } else {
+                        // (static indices only: a runtime-selected element would push the arrays to scratch)
+                        if (any[e]) bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                        else bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                        float y0, y1;
+                        wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
+                        if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
+                        if (alane) unsafeAtomicAdd(abase + (size_t)ids[any[e] ? k[e] : k[f]] * GRAD_STRIDE, use_y1 ? y1 : y0);
                     }
-                } else if (anya) {
-                    bwd_step<INVD>(st8, acta, a1, a2, dxa, dya, Ga, ala, dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
-                    float y0, y1;
-                    wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
-                    if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
-                    if (alane) unsafeAtomicAdd(abase + (size_t)ids[ka] * GRAD_STRIDE, use_y1 ? y1 : y0);
-                } else {
-                    bwd_step<INVD>(st8, actb, b1, b2, dxb, dyb, Gb, alb, dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
-                    float y0, y1;
-                    wave_reduce10(vb[0], vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7], vb[8], vb[9], y0, y1);
-                    if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
-                    if (alane) unsafeAtomicAdd(abase + (size_t)ids[kb] * GRAD_STRIDE, use_y1 ? y1 : y0);
                 }
             }
         }
@@ -468,21 +495,34 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
 // ------------------------------------------------------------------------------------ host
 static unsigned long long *g_dbg_buf = nullptr;
 constexpr size_t DBG_BYTES = 4 * 8ull * 65536ull * 8;     // 4 waves x 65536 blocks x {start,end}
-int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
     // two-phase transmittance products pay off when tiles are deep on average (> 2 segments per tile over the
     // whole image); shallow scenes take one launch
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = e ? atoi(e) : 0; }
+    BlendGrid g = g_in;
+    g.dbg = (uint32_t)dbg;
+    g.dbg_buf = nullptr;
+    if (dbg & (128 | 256)) {
+        if (!g_dbg_buf) (void)hipMalloc((void **)&g_dbg_buf, DBG_BYTES);
+        if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
+    }
     const bool deep = g.capacity > 2ull * g.seg_len * (uint64_t)g.T;
     const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
+    static int trip = -1;
+    if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 4; }
+    auto head = trip == 2 ? blend_head_kernel<2> : blend_head_kernel<4>;
+    auto fwd2 = trip == 2 ? blend_fwd_kernel<2> : blend_fwd_kernel<4>;
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, 0));
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, 1));
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec, -1));
+        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, -1));
     }
     GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
-    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, blend_fwd_kernel<<<blocks, BLOCK, 0, stream>>>(g, o));
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<blocks, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, blend_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_finalize");
@@ -501,10 +541,12 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
         if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
     }
     const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
-    if (a.has_invd && a.dL_dinvd)
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<true><<<blocks, BLOCK, 0, stream>>>(g, a));
-    else
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, blend_bwd_kernel<false><<<blocks, BLOCK, 0, stream>>>(g, a));
+    static int trip = -1;
+    if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 4; }
+    const bool invd = a.has_invd && a.dL_dinvd;
+    auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4> : blend_bwd_kernel<false, 4>)
+                          : (invd ? blend_bwd_kernel<true, 2> : blend_bwd_kernel<false, 2>);
+    GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
     return GMS_OK;
 }
