@@ -177,7 +177,17 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
     const Pix p = pixel_of(g, u);
 
     float T = 1.f;
-    for (int k = 0; k < u.seg; k++) T *= g.seg_state[(size_t)(u.slot0 + k) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    {
+        // prefix product of the segments in front, four independent loads per step (same left-to-right order)
+        const float *tl = g.seg_state + (size_t)u.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid;
+        int k = 0;
+        for (; k + 4 <= u.seg; k += 4) {
+            const float t0 = tl[(size_t)k * SEG_FLOATS], t1 = tl[(size_t)(k + 1) * SEG_FLOATS];
+            const float t2 = tl[(size_t)(k + 2) * SEG_FLOATS], t3 = tl[(size_t)(k + 3) * SEG_FLOATS];
+            T = T * t0 * t1 * t2 * t3;
+        }
+        for (; k < u.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
+    }
     const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
@@ -289,14 +299,24 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
     float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
     uint32_t last = 0;
-    for (int k = 0; k < nseg; k++) {
-        const float *st = st0 + (size_t)k * SEG_FLOATS;
-        const float te = st[SEG_TEND * TILE_PIX + tid];
-        if (te >= 0.f) {
-            C0 += st[SEG_C0 * TILE_PIX + tid]; C1 += st[SEG_C1 * TILE_PIX + tid]; C2 += st[SEG_C2 * TILE_PIX + tid];
-            Dp += st[SEG_D * TILE_PIX + tid];
-            T = te;
-            last = max(last, __float_as_uint(st[SEG_LAST * TILE_PIX + tid]));
+    // four segments per step, every load issued before the first use: a 27-segment tile is otherwise 27 dependent
+    // memory round trips, and this kernel's duration is its deepest tile
+    constexpr int U = 4;
+    for (int k0 = 0; k0 < nseg; k0 += U) {
+        float te[U], c0[U], c1[U], c2[U], dd[U], la[U];
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const float *st = st0 + (size_t)min(k0 + j, nseg - 1) * SEG_FLOATS;
+            te[j] = st[SEG_TEND * TILE_PIX + tid]; c0[j] = st[SEG_C0 * TILE_PIX + tid]; c1[j] = st[SEG_C1 * TILE_PIX + tid];
+            c2[j] = st[SEG_C2 * TILE_PIX + tid]; dd[j] = st[SEG_D * TILE_PIX + tid]; la[j] = st[SEG_LAST * TILE_PIX + tid];
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            if (k0 + j < nseg && te[j] >= 0.f) {          // a segment entered dead (te < 0) contributed nothing
+                C0 += c0[j]; C1 += c1[j]; C2 += c2[j]; Dp += dd[j];
+                T = te[j];
+                last = max(last, __float_as_uint(la[j]));
+            }
         }
     }
     if (xi < g.W && yi < g.H) {
@@ -380,12 +400,24 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
             // the colour composited behind it (sum of the live partials of the later segments) divided by that T
             st8.T = te;
             float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
-            // a pixel that is dead on entry to segment k is dead for every later one: stop at the first
-            for (int k = u.seg + 1; k < u.nseg; k++) {
-                const float *sk = g.seg_state + (size_t)(u.slot0 + k) * SEG_FLOATS;
-                if (sk[SEG_TEND * TILE_PIX + tid] < 0.f) break;
-                S0 += sk[SEG_C0 * TILE_PIX + tid]; S1 += sk[SEG_C1 * TILE_PIX + tid]; S2 += sk[SEG_C2 * TILE_PIX + tid];
-                if (INVD) SD += sk[SEG_D * TILE_PIX + tid];
+            // a pixel that is dead on entry to segment k is dead for every later one: stop at the first.  Four
+            // segments per step with all loads issued up front (a deep tile is otherwise a chain of round trips).
+            bool stop = false;
+            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += 4) {
+                float tk[4], c0[4], c1[4], c2[4], dd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float *sk = g.seg_state + (size_t)(u.slot0 + min(k0 + j, u.nseg - 1)) * SEG_FLOATS;
+                    tk[j] = sk[SEG_TEND * TILE_PIX + tid]; c0[j] = sk[SEG_C0 * TILE_PIX + tid];
+                    c1[j] = sk[SEG_C1 * TILE_PIX + tid]; c2[j] = sk[SEG_C2 * TILE_PIX + tid];
+                    dd[j] = INVD ? sk[SEG_D * TILE_PIX + tid] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k0 + j >= u.nseg || tk[j] < 0.f) stop = true;
+                    if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
+                }
+                if (__all(stop)) break;
             }
             const float inv = 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
