@@ -138,6 +138,7 @@ def main():
     pipe = PipelineParams()
     params = model.parameters()
     inv_norm = 1.0 / (3.0 * size * size)
+    neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
     reducer = OverlappedGradAllReduce(params, world) if world > 1 else None
 
     if args.loss == "l1_ssim":
@@ -156,8 +157,8 @@ def main():
         if args.loss == "l1_ssim":
             l1_ssim_loss(image, gt_image, 0.2).backward()
         else:
-            with torch.no_grad():
-                grad = (image - 0.5) * inv_norm          # dL/dcolor = (image - 0.5) / (3HW), dense
+            with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
+                grad = torch.add(neg_half_norm, image, alpha=inv_norm)      # one elementwise kernel
             image.backward(grad)
         if reducer is not None:
             reducer.finish()      # collectives were started from autograd hooks during backward

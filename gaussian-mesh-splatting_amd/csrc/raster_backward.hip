@@ -30,7 +30,8 @@ struct PreBwdArgs {
     int aa;
     const int *radii;
     const uint8_t *clamped;
-    const float *accum;     // [P,16] gradient records filled by blend_bwd
+    float *accum;           // [P,16] gradient records filled by blend_bwd
+    int rezero;             // clear each record after reading it
     float *dL_dmean2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscales, *dL_drots;
 };
@@ -167,8 +168,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     // the Gaussian's 64-byte gradient record (three coalesced float4 loads)
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga, gc4 = ga;
     if (valid) {
-        const float4 *rec = reinterpret_cast<const float4 *>(a.accum + (size_t)i * GRAD_STRIDE);
+        float4 *rec = reinterpret_cast<float4 *>(a.accum + (size_t)i * GRAD_STRIDE);
         ga = rec[0]; gb = rec[1]; gc4 = rec[2];
+        if (a.rezero && vis) {                      // only visible Gaussians were ever added to
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            rec[0] = z; rec[1] = z; rec[2] = z;
+        }
     }
     // blend_bwd accumulates MOMENTS of q = dL/dG * G over the pixels (gms_blend.h GRAD_*): sum q*dx, q*dy, q*dx*dx,
     // q*dx*dy, q*dy*dy and sum q.  The per-splat linear map to the gradients of (pixel mean, conic, opacity') uses
@@ -422,7 +427,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.means3D = A->means3D; p.shs = A->shs; p.shs_rest = A->shs_rest; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
-    p.clamped = geom.clamped; p.accum = A->grad_accum; p.dL_dmean2D = A->dL_dmeans2D;
+    p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
     p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));

@@ -126,6 +126,9 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings, None)
 
 
+_accum_cache = {}      # (device index, stream, P) -> zeroed [P,16] gradient-record buffer
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -217,8 +220,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         grad_color = _f32c(grad_color) if grad_color is not None else torch.zeros((3, H, W), device=device)
         grad_invdepth = _f32c(grad_invdepth) if grad_invdepth is not None else None
 
-        # one zero-filled 64-byte gradient record per Gaussian for the blend kernel's atomics
-        grad_accum = torch.zeros((max(P, 1), 16), dtype=torch.float32, device=device)
+        # one zeroed 64-byte gradient record per Gaussian for the blend kernel's atomics.  The buffer is kept per
+        # (device, stream, P): the backward kernels leave it zero again (grad_accum_rezero), so there is no
+        # 64*P-byte memset per iteration.  Calls on one stream are ordered, so sharing it between them is safe.
+        stream = torch.cuda.current_stream(device).cuda_stream
+        accum_key = (device.index, stream, P)
+        grad_accum = _accum_cache.pop(accum_key, None)
+        if grad_accum is None:
+            grad_accum = torch.zeros((max(P, 1), 16), dtype=torch.float32, device=device)
         dL_dmeans2D = torch.empty((P, 3), dtype=torch.float32, device=device)
         dL_dopacity = torch.empty(opacities.shape, dtype=torch.float32, device=device)
         dL_dcolors = torch.empty((P, 3), dtype=torch.float32, device=device) if not use_sh else None
@@ -244,11 +253,14 @@ class _RasterizeGaussians(torch.autograd.Function):
             dL_dcolors=_lib.ptr(dL_dcolors), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
             dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dsh_rest=_lib.ptr(dL_dsh_rest),
             dL_dscales=_lib.ptr(dL_dscales),
-            dL_drotations=_lib.ptr(dL_drot))
+            dL_drotations=_lib.ptr(dL_drot), grad_accum_rezero=1)
         if P > 0:
             with torch.cuda.device(device):
-                stream = torch.cuda.current_stream(device).cuda_stream
                 _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
+        # only a call that completed hands its (re-zeroed) buffer back; a failed one lets it go
+        if len(_accum_cache) >= 8:
+            _accum_cache.clear()
+        _accum_cache[accum_key] = grad_accum
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
                 dL_dcov3D, None, dL_dsh_rest)
 

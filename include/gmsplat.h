@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 1
+#define GMS_ABI_VERSION 2
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -119,10 +119,11 @@ typedef struct GmsRasterBackwardArgs {
     const void *image_buffer;
     const float *dL_dout_color;       /* [3,H,W] */
     const float *dL_dout_invdepth;    /* [1,H,W] or NULL */
-    /* scratch (device): [P,16] floats, 64-byte aligned, MUST be zero-filled by the caller.  One 64-byte
-     * record per Gaussian {mean2D.x, mean2D.y, conic A, B, C, opacity, r, g, b, inverse depth, pad x6}:
-     * the blend kernel's ten partial sums of a (wave, splat) pair leave as ONE atomic instruction whose
-     * lanes all hit the same cache line. */
+    /* scratch (device): [P,16] floats, 64-byte aligned, MUST be all zero on entry.  One 64-byte record per
+     * Gaussian: the ten per-pixel partial sums of a (wave, splat) pair -- five moments of q = dL/dG*G (q dx, q dy,
+     * q dx^2, q dx dy, q dy^2), sum q, the colour weights r, g, b and the inverse-depth weight -- leave the blend
+     * kernel as ONE atomic instruction whose lanes all hit the same cache line; preprocess_bwd maps the moments
+     * to the gradients of (mean2D, conic, opacity).  See grad_accum_rezero below. */
     float *grad_accum;
     /* outputs (device), all fully overwritten (no zero-fill needed) */
     float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column = 0 */
@@ -134,6 +135,9 @@ typedef struct GmsRasterBackwardArgs {
     float *dL_dsh_rest;    /* [P,M-1,3] written only when shs_rest != NULL */
     float *dL_dscales;     /* [P,3] written only when scales != NULL */
     float *dL_drotations;  /* [P,4] written only when rotations != NULL */
+    /* 1: the call leaves grad_accum all zero again (the consuming kernel clears each record it read), so a caller
+     * that keeps the buffer per (device, stream, P) never pays a 64*P-byte memset per backward; 0: left dirty. */
+    int32_t grad_accum_rezero;
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);

@@ -44,7 +44,9 @@ def _worker(rank, world, port, q):
         out2 = [p.grad.clone() for p in params2]
         # camera sharding: same permutation everywhere, disjoint cover of the views within an epoch
         views = [shard_views(8, step, rank, world, seed=7) for step in range(4)]
-        q.put((rank, local, out, views, out2))
+        # numpy copies: a torch tensor would travel as a shared-memory file descriptor that dies with this process
+        npy = lambda ts: [None if t is None else t.detach().numpy().copy() for t in ts]
+        q.put((rank, npy(local), npy(out), views, npy(out2)))
     finally:
         dist.destroy_process_group()
 
@@ -58,6 +60,8 @@ def _run_world(world):
         p.start()
     try:
         res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+        tt = lambda xs: [None if x is None else torch.from_numpy(x) for x in xs]
+        res = [(r, tt(l), tt(o), v, tt(o2)) for r, l, o, v, o2 in res]
     finally:
         for p in procs:
             p.join(timeout=120)
