@@ -134,11 +134,13 @@ __device__ __forceinline__ void barycentric(int mode, const float *raw, float al
 }
 
 __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *alpha_out, float *xyz, float *scaling,
-                                                         float *rotation, float *scaling_act, float *rotation_unit)
+                                                         float *rotation, float *scaling_act, float *rotation_unit,
+                                                         float *opacity_act)
 {
 #pragma clang fp contract(off)
     const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= a.P) return;
+    if (opacity_act) opacity_act[p] = 1.f / (1.f + expf(-a._opacity[p]));      // get_opacity: torch.sigmoid
     const int f = splat_to_face(a, p);
     V3 t0, t1, t2;
     load_face(a, f, t0, t1, t2);
@@ -168,10 +170,18 @@ __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *a
 
 // ------------------------------------------------------------------ backward, per splat
 __global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
-                                                               float *dL_dalpha, float *dL_dscale)
+                                                               float *dL_dalpha, float *dL_dscale, float *dL_dvertices,
+                                                               const float *dL_dopacity_act, float *dL_d_opacity)
 {
+    // the vertex gradient is accumulated with atomics by the face kernel that follows on the stream: clear it here
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < 3 * (int64_t)a.V; e += (int64_t)gridDim.x * BLOCK)
+        dL_dvertices[e] = 0.f;
     const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= a.P) return;
+    if (dL_d_opacity) {                             // sigmoid backward: g * (1 - y) * y
+        const float y = 1.f / (1.f + expf(-a._opacity[p]));
+        dL_d_opacity[p] = dL_dopacity_act[p] * (1.f - y) * y;
+    }
     const int f = splat_to_face(a, p);
     V3 t0, t1, t2;
     load_face(a, f, t0, t1, t2);
@@ -400,7 +410,8 @@ static int32_t check_mesh_args(const GmsMeshArgs *A)
 }
 
 extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *alpha, float *xyz, float *scaling,
-                                                 float *rotation, float *scaling_act, float *rotation_unit, void *stream_)
+                                                 float *rotation, float *scaling_act, float *rotation_unit,
+                                                 float *opacity_act, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
@@ -408,14 +419,16 @@ extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *al
     if (rc != GMS_OK) return rc;
     if (A->P == 0) return GMS_OK;
     if (!xyz || !scaling || !rotation) { set_error("mesh forward: null output"); return GMS_ERR_INVALID_ARGUMENT; }
-    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation, scaling_act, rotation_unit));
+    if (opacity_act && !A->_opacity) { set_error("mesh forward: opacity_activated requested without _opacity"); return GMS_ERR_INVALID_ARGUMENT; }
+    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation, scaling_act, rotation_unit, opacity_act));
     GMS_KERNEL_CHECK(0, stream, "mesh_fwd");
     return GMS_OK;
 }
 
 extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const float *dL_dxyz, const float *dL_dscaling,
-                                                  const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
-                                                  float *dL_dscale, void *stream_)
+                                                  const float *dL_drotation, const float *dL_dopacity_act,
+                                                  float *dL_dvertices, float *dL_dalpha, float *dL_dscale,
+                                                  float *dL_d_opacity, void *stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
@@ -426,7 +439,11 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
         set_error("mesh backward: null gradient pointer");
         return GMS_ERR_INVALID_ARGUMENT;
     }
-    GMS_LAUNCH(GMS_K_MESH_BWD_SPLAT, stream, mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale));
+    if (dL_d_opacity && (!A->_opacity || !dL_dopacity_act)) {
+        set_error("mesh backward: dL_d_opacity requested without _opacity / dL_dopacity_activated");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    GMS_LAUNCH(GMS_K_MESH_BWD_SPLAT, stream, mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale, dL_dvertices, dL_dopacity_act, dL_d_opacity));
     GMS_KERNEL_CHECK(0, stream, "mesh_bwd_splat");
     const double avg = (double)A->P / (double)(A->F > 0 ? A->F : 1);
     if (avg >= 16.0) {

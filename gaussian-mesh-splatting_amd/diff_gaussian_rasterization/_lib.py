@@ -61,7 +61,7 @@ class MeshArgs(C.Structure):
     _fields_ = [
         ("F", C.c_int32), ("V", C.c_int32), ("P", C.c_int64), ("splats_per_face", C.c_int32), ("alpha_mode", C.c_int32),
         ("vertices", C.c_void_p), ("faces", C.c_void_p), ("face_splat_offset", C.c_void_p), ("splat_face", C.c_void_p),
-        ("_alpha", C.c_void_p), ("_scale", C.c_void_p), ("fused_activations", C.c_int32),
+        ("_alpha", C.c_void_p), ("_scale", C.c_void_p), ("fused_activations", C.c_int32), ("_opacity", C.c_void_p),
     ]
 
 
@@ -114,9 +114,9 @@ def load():
         lib.gms_mark_visible.restype = C.c_int32
         lib.gms_mark_visible.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.gms_mesh_to_gaussians_forward.restype = C.c_int32
-        lib.gms_mesh_to_gaussians_forward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 7
+        lib.gms_mesh_to_gaussians_forward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 8
         lib.gms_mesh_to_gaussians_backward.restype = C.c_int32
-        lib.gms_mesh_to_gaussians_backward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 7
+        lib.gms_mesh_to_gaussians_backward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 9
         lib.gms_abi_version.restype = C.c_int32
         lib.gms_last_error.restype = C.c_char_p
         for n in ("gms_geom_bytes", "gms_image_bytes", "gms_binning_bytes"):

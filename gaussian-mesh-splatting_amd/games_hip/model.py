@@ -23,8 +23,13 @@ class HipMeshMixin:
     alpha_mode = "relu"
 
     def update_alpha(self):
-        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
-            self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
+        opa = getattr(self, "_opacity", None)
+        fuse_opacity = torch.is_tensor(opa) and opa.is_cuda and opa.numel() == self._scale.numel()
+        out = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True,
+                                _opacity=opa if fuse_opacity else None)
+        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = out[:6]
+        # get_opacity (scene/gaussian_model.py:113-115) from the same kernel; valid while _opacity is unchanged
+        self._hip_opacity = (opa, opa._version, out[6]) if fuse_opacity else None
         self.alpha = alpha
         self._xyz = xyz
         # `triangles` is only read by save_ply and the animated renderers: gathered on first access
@@ -82,6 +87,13 @@ class HipMeshMixin:
         if act is not None and act[1] is self._rotation:
             return act[3]
         return torch.nn.functional.normalize(self._rotation)
+
+    @property
+    def get_opacity(self):
+        cached = getattr(self, "_hip_opacity", None)
+        if cached is not None and cached[0] is self._opacity and cached[1] == self._opacity._version:
+            return cached[2]
+        return torch.sigmoid(self._opacity)
 
     @property
     def get_features(self):
@@ -188,15 +200,6 @@ class HipGaussianMeshModel(HipMeshMixin):
     def get_xyz(self):
         return self._xyz
 
-    @property
-    def get_opacity(self):
-        return torch.sigmoid(self._opacity)
-
-    @property
-    def get_features(self):
-        # no 57.6 MB concatenation per iteration: the rasterizer reads / differentiates both blocks in place
-        from diff_gaussian_rasterization import SplitSH
-        return SplitSH(self._features_dc, self._features_rest)
 
 
 def install(games_module=None):

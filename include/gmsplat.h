@@ -165,20 +165,24 @@ typedef struct GmsMeshArgs {
     int32_t fused_activations;    /* 1: the property getters of scene/gaussian_model.py:95-101 are fused in:
                                      forward also writes exp(scaling) and normalize(rotation); backward takes
                                      the gradients w.r.t. THOSE instead of (scaling, rotation) */
+    const float *_opacity;        /* [P] raw opacities or NULL: fuses get_opacity = sigmoid(_opacity)
+                                     (scene/gaussian_model.py:113-115) and its backward into the same kernels */
 } GmsMeshArgs;
 
 /* Outputs: alpha [P,3] (normalised barycentrics, kept because save_ply / the animated renderer
  * read `pc.alpha`), xyz [P,3], scaling [P,3] = log(relu(_scale*s)+eps), rotation [P,4] quaternion. */
 int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *args, float *alpha, float *xyz, float *scaling,
                                       float *rotation, float *scaling_activated /* [P,3] or NULL */,
-                                      float *rotation_unit /* [P,4] or NULL */, void *stream);
+                                      float *rotation_unit /* [P,4] or NULL */,
+                                      float *opacity_activated /* [P] or NULL; needs args->_opacity */, void *stream);
 
-/* Gradients of (xyz, scaling, rotation) -> (vertices, _alpha, _scale).  dL_dvertices [V,3] is
- * accumulated with atomics and MUST be zero-filled by the caller; dL_dalpha [P,3] and
- * dL_dscale [P] are fully overwritten. */
+/* Gradients of (xyz, scaling, rotation[, sigmoid(_opacity)]) -> (vertices, _alpha, _scale[, _opacity]).  Every
+ * output is fully overwritten: dL_dvertices [V,3] is cleared by the first kernel and accumulated with atomics by
+ * the second; dL_dalpha [P,3], dL_dscale [P] and dL_d_opacity [P] (NULL = not requested) are plain stores. */
 int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *args, const float *dL_dxyz, const float *dL_dscaling,
-                                       const float *dL_drotation, float *dL_dvertices, float *dL_dalpha,
-                                       float *dL_dscale, void *stream);
+                                       const float *dL_drotation, const float *dL_dopacity_activated /* or NULL */,
+                                       float *dL_dvertices, float *dL_dalpha, float *dL_dscale,
+                                       float *dL_d_opacity /* or NULL */, void *stream);
 
 /* ---- exact 3-NN mean squared distance ---------------------------------
  * Replaces the un-vendored `simple_knn._C.distCUDA2(points)` (.gitmodules:1-3) called at

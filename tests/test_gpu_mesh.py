@@ -184,3 +184,34 @@ def test_animated_render_follows_the_deformed_mesh():
     amb = o.state.details()["pix_ambig"].astype(bool)
     diff = np.abs(img.cpu().numpy() - o.color).max(0)
     assert (diff[~amb] <= 2e-4).mean() > 0.999 and amb.mean() < 0.02      # K0 rounding can move a radius by one
+
+
+def test_fused_opacity_getter_matches_torch_sigmoid_and_its_gradient():
+    """get_opacity = sigmoid(_opacity) (scene/gaussian_model.py:113-115) rides in the K0 kernels."""
+    from games_hip.mesh_op import mesh_to_gaussians
+    scene = syn.mesh_scene("tiny")
+    v, f = scene.vertices.cuda().requires_grad_(True), scene.faces.cuda()
+    a, s = scene._alpha.cuda().requires_grad_(True), scene._scale.cuda().requires_grad_(True)
+    g = torch.Generator().manual_seed(3)
+    raw = (4.0 * torch.randn(s.shape[0], 1, generator=g)).cuda().requires_grad_(True)
+    up = torch.randn(s.shape[0], 1, generator=g).cuda()
+    out = mesh_to_gaussians(v, f, a, s, "relu", fused_activations=True, _opacity=raw)
+    assert len(out) == 7 and out[6].shape == raw.shape
+    ref = torch.sigmoid(raw.detach().clone().requires_grad_(True))
+    assert float((out[6] - ref).abs().max()) <= 2e-7
+    ((out[6] * up).sum() + out[1].sum() + out[4].sum() + out[5].sum()).backward()
+    raw2 = raw.detach().clone().requires_grad_(True)
+    (torch.sigmoid(raw2) * up).sum().backward()
+    assert float((raw.grad - raw2.grad).abs().max()) <= 1e-6 * float(raw2.grad.abs().max()) + 1e-9
+    assert torch.isfinite(v.grad).all() and float(v.grad.abs().max()) > 0
+
+
+def test_model_getter_falls_back_when_opacity_changes_after_update_alpha():
+    from games_hip.model import HipGaussianMeshModel
+    m = HipGaussianMeshModel.from_scene(syn.mesh_scene("tiny"), "cuda")
+    m.update_alpha(); m.prepare_scaling_rot()
+    fused = m.get_opacity
+    assert float((fused - torch.sigmoid(m._opacity)).abs().max()) <= 2e-7
+    with torch.no_grad():
+        m._opacity.add_(1.0)                       # e.g. an optimizer step without update_alpha()
+    assert float((m.get_opacity - torch.sigmoid(m._opacity)).abs().max()) == 0.0
