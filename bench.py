@@ -49,22 +49,37 @@ def algorithmic_bytes(P, N, F, W, H):
     }
 
 
-def cpu_baseline(workload, state, max_seconds=25.0):
+def cpu_baseline(workload, state, max_seconds=12.0):
     """The oracle (C restatement of the rasterizer + torch restatement of K0) timed on the host cores."""
     from games_hip import synthetic as syn
     from oracle import gs_oracle, mesh_oracle
-    # torch-CPU elementwise/gather ops of the K0 restatement stop scaling (and then collapse) beyond a few
-    # threads; the C rasterizer oracle uses every core through OpenMP
-    k0_threads = min(16, os.cpu_count() or 1)
+    # torch-CPU elementwise/gather ops of the K0 restatement stop scaling (and then collapse) beyond a few threads;
+    # the C rasterizer oracle (OpenMP) is given the thread count that is fastest on this host (calibrated below:
+    # on a 256-thread box 16-64 threads beat all 256)
+    ncpu = os.cpu_count() or 1
+    k0_threads = min(16, ncpu)
     torch.set_num_threads(k0_threads)
     sc = syn.mesh_scene(workload, state=state)
     cam = syn.orbit_camera(0, width=sc.meta["image"], height=sc.meta["image"])
     kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
               bg=torch.ones(3), viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
               campos=cam.camera_center)
+    with torch.no_grad():
+        _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(sc.vertices, sc.faces, sc._alpha, sc._scale)
+        cal = mesh_oracle.activated(xyz, scaling, rot, sc._opacity, sc._features_dc, sc._features_rest)
+    best = (float("inf"), k0_threads)
+    for nt in sorted({min(n, ncpu) for n in (16, 32, 64, 128)}):
+        for rep in range(2):                        # first call at a new thread count pays thread start-up
+            t0 = time.time()
+            o = gs_oracle.rasterize(means3D=cal[0], opacities=cal[3], shs=cal[4], scales=cal[1], rotations=cal[2], nthreads=nt, **kw)
+            gs_oracle.backward(o, syn.upstream_grad(torch.from_numpy(o.color)))
+            dt = time.time() - t0
+        if dt < best[0]:
+            best = (dt, nt)
+    oracle_threads = best[1]
     times, pieces = [], {}
     t_start = time.time()
-    for it in range(4):
+    for it in range(40):
         t0 = time.time()
         v = sc.vertices.clone().requires_grad_(True)
         a = sc._alpha.clone().requires_grad_(True)
@@ -72,7 +87,7 @@ def cpu_baseline(workload, state, max_seconds=25.0):
         _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(v, sc.faces, a, s)
         xyz_a, s_a, r_a, op_a, shs = mesh_oracle.activated(xyz, scaling, rot, sc._opacity, sc._features_dc, sc._features_rest)
         t1 = time.time()
-        o = gs_oracle.rasterize(means3D=xyz_a, opacities=op_a, shs=shs, scales=s_a, rotations=r_a, **kw)
+        o = gs_oracle.rasterize(means3D=xyz_a, opacities=op_a, shs=shs, scales=s_a, rotations=r_a, nthreads=oracle_threads, **kw)
         t2 = time.time()
         g = gs_oracle.backward(o, syn.upstream_grad(torch.from_numpy(o.color)))
         t3 = time.time()
@@ -80,16 +95,16 @@ def cpu_baseline(workload, state, max_seconds=25.0):
                 + (r_a * torch.from_numpy(g["rotations"])).sum())
         loss.backward()
         t4 = time.time()
-        if it > 0 or time.time() - t_start > max_seconds / 2:
+        if it > 0 or time.time() - t_start > max_seconds / 2:       # iteration 0 pays the one-time library / page warm-up
             times.append(t4 - t0)
             pieces = {"k0_fwd_s": t1 - t0, "raster_fwd_s": t2 - t1, "raster_bwd_s": t3 - t2, "k0_bwd_s": t4 - t3}
         if time.time() - t_start > max_seconds:
             break
     t = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / t, "unit": "iters/s", "cores": gs_oracle.max_threads(), "kind": "port",
+    return {"value": 1.0 / t, "unit": "iters/s", "cores": oracle_threads, "kind": "port",
             "sample": f"{len(times)} full fwd+bwd iteration(s) of the same workload ({workload}/{state}, "
-                      f"{sc.num_gaussians} Gaussians, {cam.image_width}x{cam.image_height}); C oracle with OpenMP + "
-                      f"torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
+                      f"{sc.num_gaussians} Gaussians, {cam.image_width}x{cam.image_height}); C oracle with OpenMP "
+                      f"({oracle_threads} threads, fastest of 16/32/64/128) + torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
 
 
 def main():
