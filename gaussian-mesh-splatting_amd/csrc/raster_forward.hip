@@ -26,6 +26,9 @@
 #include <stdlib.h>
 
 #include "gms_blend.h"
+#include <atomic>
+#include <chrono>
+
 #include "gms_common.h"
 #include "gms_project.h"
 
@@ -383,7 +386,8 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
 // sums with DPP-free shuffles, the 16 wave totals are scanned by the first wave: two block barriers in all.
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
                                                                  uint32_t *unit_first, uint32_t *mseg_first,
-                                                                 uint32_t *class_first, int T, uint32_t L)
+                                                                 uint32_t *class_first, int T, uint32_t L, int32_t *host_slot,
+                                                                 int32_t seq)
 {
     __shared__ uint32_t wave_tot[NSCAN][SCAN_THREADS / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -426,6 +430,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
     for (int k = 0; k < NSCAN; k++) {
         tot[k] = wave_tot[k][SCAN_THREADS / WAVE - 1];
         run[k] = run[k] - own[k] + (wave > 0 ? wave_tot[k][wave - 1] : 0u);   // exclusive prefix of this thread's chunk
+    }
+    // The instance count N goes straight to the host: two system-scope stores into pinned memory (value, then the
+    // call's sequence number) that the waiting host thread polls -- no copy-engine hop, no event wake-up latency.
+    if (tid == 0 && host_slot) {
+        __hip_atomic_store(&host_slot[0], (int32_t)tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_slot[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
@@ -694,14 +704,44 @@ __global__ void mark_visible_kernel(int P, const float *means3D, const float *vi
     present[i] = vz > NEAR_Z ? 1 : 0;
 }
 
-// pinned read-back slot, one per host thread
+// pinned, device-visible read-back slot, one per host thread: {N, sequence number of the call that wrote it}
 static int32_t *pinned_slot()
 {
     static thread_local int32_t *slot = nullptr;
     if (!slot) {
-        if (hipHostMalloc((void **)&slot, 64, hipHostMallocDefault) != hipSuccess) slot = nullptr;
+        if (hipHostMalloc((void **)&slot, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) slot = nullptr;
+        else { slot[0] = 0; slot[1] = 0; }
     }
     return slot;
+}
+
+// Wait until the tile_scan kernel of call `seq` has published N.  The host spins on the pinned slot (the kernel
+// is at most one forward + one backward away); after 10 s without an answer the stream is synchronised so a
+// faulted kernel surfaces as an error instead of a hang.
+static std::atomic<int64_t> g_wait_ns{0}, g_wait_calls{0};
+
+static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, int64_t *N)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tally {
+        std::chrono::steady_clock::time_point t0;
+        ~Tally() { g_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_wait_calls++; }
+    } tally{t0};
+    for (uint32_t spins = 0;; spins++) {
+        if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == seq) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xffffu) == 0xffffu &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+            GMS_HIP_CHECK(hipStreamSynchronize(stream));
+            if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != seq) {
+                set_error("tile_scan did not publish the instance count");
+                return GMS_ERR_HIP;
+            }
+            break;
+        }
+    }
+    *N = (int64_t)(uint32_t)__atomic_load_n(&slot[0], __ATOMIC_RELAXED);
+    return GMS_OK;
 }
 
 uint32_t seg_len()
@@ -818,13 +858,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
 #undef GMS_PRE
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len();
-    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, img.class_first, T, L));
-    GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
-
     int32_t *slot = pinned_slot();
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
-    GMS_HIP_CHECK(hipMemcpyAsync(slot, img.tile_offset + T, 4, hipMemcpyDeviceToHost, stream));
+    static thread_local int32_t seq_counter = 0;
+    const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
+    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
+                                                                                   img.unit_first, img.mseg_first, img.class_first, T, L,
+                                                                                   slot, seq));
+    GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
     BlendFwdOut bo;
     bo.rec = geom.rec; bo.bg = A->background; bo.final_T = img.final_T; bo.n_contrib = img.n_contrib;
@@ -854,14 +895,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
-        hipEvent_t ev;
-        GMS_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        GMS_HIP_CHECK(hipEventRecord(ev, stream));       // after the N copy
         int32_t rc = enqueue_tail(bin_mem, cap);
-        if (rc != GMS_OK) { (void)hipEventDestroy(ev); return rc; }
-        GMS_HIP_CHECK(hipEventSynchronize(ev));
-        (void)hipEventDestroy(ev);
-        N = (int64_t)(uint32_t)*slot;
+        if (rc != GMS_OK) return rc;
+        rc = wait_for_count(slot, seq, stream, &N);
+        if (rc != GMS_OK) return rc;
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
             bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
@@ -870,8 +907,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
             if (rc != GMS_OK) return rc;
         }
     } else {
-        GMS_HIP_CHECK(hipStreamSynchronize(stream));
-        N = (int64_t)(uint32_t)*slot;
+        int32_t rc0 = wait_for_count(slot, seq, stream, &N);
+        if (rc0 != GMS_OK) return rc0;
         const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
@@ -879,6 +916,13 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (rc != GMS_OK) return rc;
     }
     return N;
+}
+
+extern "C" void gms_wait_stats(double *total_ms, int64_t *calls, int32_t reset)
+{
+    if (total_ms) *total_ms = (double)g_wait_ns.load() * 1e-6;
+    if (calls) *calls = g_wait_calls.load();
+    if (reset) { g_wait_ns = 0; g_wait_calls = 0; }
 }
 
 extern "C" int32_t gms_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,

@@ -182,8 +182,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             out_color=_lib.ptr(color), out_invdepth=_lib.ptr(invdepth), radii=_lib.ptr(radii),
             geom_alloc=scratch.geom_cb, geom_ctx=None, binning_alloc=scratch.binning_cb, binning_ctx=None,
             image_alloc=scratch.image_cb, image_ctx=None, binning_capacity_hint=hint)
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
+        with _lib.on_device(device):
+            stream = _lib.stream_ptr(device)
             num_rendered = lib.gms_rasterize_forward(C.byref(a), C.c_void_p(stream))
         if num_rendered < 0:
             if scratch.error is not None:
@@ -223,7 +223,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # one zeroed 64-byte gradient record per Gaussian for the blend kernel's atomics.  The buffer is kept per
         # (device, stream, P): the backward kernels leave it zero again (grad_accum_rezero), so there is no
         # 64*P-byte memset per iteration.  Calls on one stream are ordered, so sharing it between them is safe.
-        stream = torch.cuda.current_stream(device).cuda_stream
+        stream = _lib.stream_ptr(device)
         accum_key = (device.index, stream, P)
         grad_accum = _accum_cache.pop(accum_key, None)
         if grad_accum is None:
@@ -255,7 +255,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             dL_dscales=_lib.ptr(dL_dscales),
             dL_drotations=_lib.ptr(dL_drot), grad_accum_rezero=1)
         if P > 0:
-            with torch.cuda.device(device):
+            with _lib.on_device(device):
                 _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
         # only a call that completed hands its (re-zeroed) buffer back; a failed one lets it go
         if len(_accum_cache) >= 8:
@@ -279,8 +279,8 @@ class GaussianRasterizer(nn.Module):
             pos = _f32c(positions)
             present = torch.empty((pos.shape[0],), dtype=torch.uint8, device=pos.device)
             view, proj = _f32c(rs.viewmatrix.to(pos.device)), _f32c(rs.projmatrix.to(pos.device))
-            with torch.cuda.device(pos.device):
-                stream = torch.cuda.current_stream(pos.device).cuda_stream
+            with _lib.on_device(pos.device):
+                stream = _lib.stream_ptr(pos.device)
                 _lib.check(lib.gms_mark_visible(int(pos.shape[0]), _lib.ptr(pos), _lib.ptr(view), _lib.ptr(proj),
                                                 _lib.ptr(present), C.c_void_p(stream)), "gms_mark_visible")
         return present.bool()

@@ -85,7 +85,7 @@ EXPORTS = (
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
-    "gms_l1_ssim_backward", "gms_adam_step",
+    "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats",
 )
 K_COUNT = 15
 
@@ -136,6 +136,8 @@ def load():
         lib.gms_l1_ssim_backward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
         lib.gms_adam_step.restype = C.c_int32
         lib.gms_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib.gms_wait_stats.restype = None
+        lib.gms_wait_stats.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
         lib.gms_profile_enable.argtypes = [C.c_int32]
         lib.gms_profile_enable.restype = None
         lib.gms_profile_reset.restype = None
@@ -165,6 +167,31 @@ def check(rc: int, what: str):
         msg = load().gms_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed ({ERRORS.get(int(rc), rc)}): {msg}")
     return rc
+
+
+class _NullGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NULL_GUARD = _NullGuard()
+
+
+def on_device(device):
+    """Context that makes `device` current for the HIP calls inside: free when it already is (the usual case),
+    torch.cuda.device otherwise (its enter/exit costs ~10 us of host time per call)."""
+    import torch
+    return _NULL_GUARD if torch.cuda.current_device() == device.index else torch.cuda.device(device)
+
+
+def stream_ptr(device):
+    """Raw hipStream_t of torch's current stream on `device` (the ~1 us path; torch.cuda.current_stream() builds a
+    Stream object and costs ~12 us)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(device.index)
 
 
 def ptr(t):

@@ -37,14 +37,14 @@ class _WeightedL1Ssim(torch.autograd.Function):
         y = gt.detach().to(torch.float32).contiguous()
         planes, h, w = _planes(x, y)
         need_grad = img.requires_grad
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             out = torch.empty(3, dtype=torch.float32, device=x.device)
             partials = torch.empty(lib.gms_l1_ssim_partials(planes, h, w), dtype=torch.float32, device=x.device)
             dmaps = torch.empty((3,) + tuple(x.shape), dtype=torch.float32, device=x.device) if need_grad else None
             args = _lib.LossArgs(planes=planes, height=h, width=w, img=_lib.ptr(x), gt=_lib.ptr(y), w_l1=w_l1, w_ssim=w_ssim,
                                  bias=bias)
             rc = lib.gms_l1_ssim_forward(C.byref(args), _lib.ptr(dmaps), _lib.ptr(partials), _lib.ptr(out),
-                                         C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                         C.c_void_p(_lib.stream_ptr(x.device)))
         _lib.check(rc, "gms_l1_ssim_forward")
         ctx.save_for_backward(x, y, dmaps if dmaps is not None else torch.empty(0, device=x.device))
         ctx.meta = (planes, h, w, w_l1, w_ssim, bias, img.dtype)
@@ -57,14 +57,14 @@ class _WeightedL1Ssim(torch.autograd.Function):
         if dmaps.numel() == 0:
             raise RuntimeError("l1_ssim backward called but the forward ran without requires_grad")
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             # only element 0 (the value) is differentiable; l1 / ssim by-products are reported, not trained on
             g = grad_out[0:1].to(torch.float32).contiguous()
             d_img = torch.empty_like(x)
             args = _lib.LossArgs(planes=planes, height=h, width=w, img=_lib.ptr(x), gt=_lib.ptr(y), w_l1=w_l1, w_ssim=w_ssim,
                                  bias=bias)
             rc = lib.gms_l1_ssim_backward(C.byref(args), _lib.ptr(dmaps), _lib.ptr(g), _lib.ptr(d_img),
-                                          C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                          C.c_void_p(_lib.stream_ptr(x.device)))
         _lib.check(rc, "gms_l1_ssim_backward")
         return d_img.to(dtype), None, None, None, None
 

@@ -65,8 +65,8 @@ class _MeshToGaussians(torch.autograd.Function):
         rotation_unit = torch.empty((P, 4), dtype=torch.float32, device=device) if fused else None
         opacity_act = torch.empty_like(_opacity) if _opacity is not None else None
         a = _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused, _opacity)
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
+        with _lib.on_device(device):
+            stream = _lib.stream_ptr(device)
             _lib.check(lib.gms_mesh_to_gaussians_forward(C.byref(a), _lib.ptr(alpha), _lib.ptr(xyz), _lib.ptr(scaling),
                                                          _lib.ptr(rotation), _lib.ptr(scaling_act), _lib.ptr(rotation_unit),
                                                          _lib.ptr(opacity_act), C.c_void_p(stream)),
@@ -108,8 +108,8 @@ class _MeshToGaussians(torch.autograd.Function):
             g_opacity_act = _c(g_opacity_act, torch.float32)
             d_opacity = torch.empty_like(_opacity)
         a = _mesh_args(vertices, faces, _alpha, _scale, ctx.mode, ctx.spf, fso, sf, ctx.fused, _opacity)
-        with torch.cuda.device(device):
-            stream = torch.cuda.current_stream(device).cuda_stream
+        with _lib.on_device(device):
+            stream = _lib.stream_ptr(device)
             _lib.check(lib.gms_mesh_to_gaussians_backward(C.byref(a), _lib.ptr(g_xyz), _lib.ptr(g_scaling), _lib.ptr(g_rotation),
                                                           _lib.ptr(g_opacity_act) if d_opacity is not None else None,
                                                           _lib.ptr(d_vertices), _lib.ptr(d_alpha), _lib.ptr(d_scale),

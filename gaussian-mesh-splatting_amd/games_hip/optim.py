@@ -31,31 +31,39 @@ class FusedAdam(torch.optim.Optimizer):
         keep = []
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
+            lr, eps = float(group["lr"]), float(group["eps"])
             for p in group["params"]:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                if p.grad.is_sparse:
-                    raise RuntimeError("FusedAdam does not support sparse gradients")
-                _lib.require_gpu(p)
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("FusedAdam needs contiguous float32 parameters")
                 state = self.state[p]
                 if len(state) == 0:
-                    state["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    if g.is_sparse:
+                        raise RuntimeError("FusedAdam does not support sparse gradients")
+                    _lib.require_gpu(p)
+                    if p.dtype != torch.float32 or not p.is_contiguous():
+                        raise RuntimeError("FusedAdam needs contiguous float32 parameters")
+                    # `step` is a host-side count (a Python float, as torch.optim.Adam kept it before 1.12): the
+                    # kernel needs it on the host for the bias corrections and a CPU tensor costs ~5 us per update
+                    state["step"] = 0.0
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
-                g = p.grad if p.grad.is_contiguous() and p.grad.dtype == torch.float32 else p.grad.float().contiguous()
+                step = float(state["step"]) + 1.0          # float(): also accepts a tensor from a torch.optim.Adam checkpoint
+                state["step"] = step
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                    keep.append(g)
                 m, v = state["exp_avg"], state["exp_avg_sq"]
                 if not (m.is_contiguous() and v.is_contiguous()):
                     m, v = state["exp_avg"], state["exp_avg_sq"] = m.contiguous(), v.contiguous()
-                keep.append(g)
-                by_hyper.setdefault((p.device, float(beta1), float(beta2), float(group["eps"])), []).append(
-                    _lib.AdamTensor(param=p.data_ptr(), grad=g.data_ptr(), exp_avg=m.data_ptr(), exp_avg_sq=v.data_ptr(),
-                                    n=p.numel(), lr=float(group["lr"]), step=int(state["step"])))
+                key = (p.device, float(beta1), float(beta2), eps)
+                lst = by_hyper.get(key)
+                if lst is None:
+                    lst = by_hyper[key] = []
+                lst.append(_lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step)))
         for (device, beta1, beta2, eps), tensors in by_hyper.items():
             arr = (_lib.AdamTensor * len(tensors))(*tensors)
-            with torch.cuda.device(device):
-                rc = lib.gms_adam_step(arr, len(tensors), beta1, beta2, eps, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            with _lib.on_device(device):
+                rc = lib.gms_adam_step(arr, len(tensors), beta1, beta2, eps, C.c_void_p(_lib.stream_ptr(device)))
             _lib.check(rc, "gms_adam_step")
         return loss

@@ -20,10 +20,10 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     out = torch.empty(n, dtype=torch.float32, device=pts.device)
     if n == 0:
         return out
-    with torch.cuda.device(pts.device):
+    with _lib.on_device(pts.device):
         nbytes = lib.gms_knn_workspace_bytes(n)
         work = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
         rc = lib.gms_knn_mean_dist2(n, _lib.ptr(pts), _lib.ptr(out), _lib.ptr(work), nbytes,
-                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+                                    C.c_void_p(_lib.stream_ptr(pts.device)))
     _lib.check(rc, "gms_knn_mean_dist2")
     return out

@@ -19,9 +19,12 @@ model.training_setup(1e-12, 1e-12, 1e-12, 1e-12, 1e-12, fused=sys.argv[1:] != ["
 acc = {}
 def tick(name, t0):
     t = time.perf_counter(); acc[name] = acc.get(name, 0.0) + (t - t0); return t
+import ctypes as C
+from diff_gaussian_rasterization import _lib
+lib = _lib.load()
 for it in range(220):
     if it == 20:
-        torch.cuda.synchronize(); acc.clear(); wall0 = time.perf_counter()
+        torch.cuda.synchronize(); acc.clear(); wall0 = time.perf_counter(); lib.gms_wait_stats(None, None, 1)
     t = time.perf_counter()
     model.update_alpha(); model.prepare_scaling_rot(); t = tick("k0_fwd", t)
     image = render(cam, model, pipe, bg)["render"]; t = tick("render_fwd", t)
@@ -32,4 +35,6 @@ for it in range(220):
 host = time.perf_counter() - wall0
 torch.cuda.synchronize()
 wall = time.perf_counter() - wall0
+ms, n = C.c_double(0), C.c_int64(0); lib.gms_wait_stats(C.byref(ms), C.byref(n), 0)
+print("wait for N inside forward: %.1f us/iter" % (ms.value * 1e3 / max(n.value, 1)))
 print({k: round(v / 200 * 1e6, 1) for k, v in acc.items()}, "host us/iter", round(host / 200 * 1e6, 1), "wall us/iter", round(wall / 200 * 1e6, 1))
