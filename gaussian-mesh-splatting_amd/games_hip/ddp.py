@@ -41,31 +41,56 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, average: boo
 
 
 class OverlappedGradAllReduce:
-    """Starts each parameter's all-reduce from a post-accumulate-grad hook, i.e. the moment autograd has
-    produced that gradient: the 54 MB SH-rest reduction (ready right after the rasterizer's
-    preprocess-backward kernel) travels over xGMI while the mesh->Gaussian backward still runs.
-    `finish()` waits for the collectives and applies the 1/world averaging.  Semantics are identical to
-    `allreduce_gradients` (tested in tests/test_ddp_cpu.py)."""
+    """Gradient all-reduce driven by post-accumulate-grad hooks, shaped for RCCL over xGMI:
 
-    def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True):
+    * a LARGE gradient (>= `big_numel` elements; here the 54 MB SH-rest block, ready right after the rasterizer's
+      preprocess-backward kernel) starts its own in-place collective the moment autograd has produced it, so it
+      travels while the mesh->Gaussian backward still runs;
+    * the SMALL ones (f_dc, opacity, _alpha, _scale, vertices: ~10 MB together) are packed into ONE flat bucket in
+      `finish()` and reduced with a single collective -- collectives of one communicator run back to back, so five
+      more launches would add their fixed cost to the wire time of the big one; the parameters' `.grad` become views
+      of the reduced bucket (no copy back).
+
+    `finish()` makes the compute stream wait for the collectives and applies the 1/world averaging.  Semantics are
+    identical to `allreduce_gradients` (tested with gloo, world size 2, in tests/test_ddp_cpu.py)."""
+
+    def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22):
         self.params = [p for p in params]
-        self.world, self.average = world, average
-        self._works, self._grads, self._handles = [], [], []
+        self.world, self.average, self.big_numel = world, average, int(big_numel)
+        self._works, self._big, self._small, self._handles = [], [], [], []
         if world > 1 and dist.is_initialized():
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
     def _hook(self, p: torch.Tensor) -> None:
-        if p.grad is not None:
-            self._grads.append(p.grad)
-            self._works.append(dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, async_op=True))
+        g = p.grad
+        if g is None:
+            return
+        if g.numel() >= self.big_numel and g.is_contiguous():
+            self._big.append(g)
+            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            self._small.append(p)
 
     def finish(self) -> None:
+        flat = None
+        if self._small:
+            grads = [p.grad for p in self._small]
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in self._works:
             w.wait()
-        if self.average and self._grads:
-            torch._foreach_div_(self._grads, float(self.world))
-        self._works, self._grads = [], []
+        if self.average:
+            scaled = self._big + ([flat] if flat is not None else [])
+            if scaled:
+                torch._foreach_div_(scaled, float(self.world))
+        if flat is not None:
+            off = 0
+            for p, g in zip(self._small, grads):
+                n = g.numel()
+                p.grad = flat[off:off + n].view(g.shape)
+                off += n
+        self._works, self._big, self._small = [], [], []
 
     def remove(self) -> None:
         for h in self._handles:

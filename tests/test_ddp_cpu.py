@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
         out = [None if p.grad is None else p.grad.clone() for p in params]
         # hook-driven variant: gradients produced by autograd are reduced as they appear
         params2 = [torch.randn(s, generator=torch.Generator().manual_seed(1234)).requires_grad_(True) for s in shapes[:3]]
-        red = OverlappedGradAllReduce(params2, world)
+        red = OverlappedGradAllReduce(params2, world, big_numel=200)     # (50,3) goes to the flat bucket, the others travel alone
         loss = sum((p * l).sum() for p, l in zip(params2, local[:3]))
         loss.backward()
         red.finish()
