@@ -54,6 +54,56 @@ uint32_t unit_run();
 inline uint32_t max_units(uint32_t T, uint64_t instances, uint32_t L) { return T + (uint32_t)(instances / L) + 1u; }
 inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_t)(instances / L) + 2u; }
 
+// ---- device-side helpers shared by the blend kernel files -------------------------------------------------------
+#ifndef GMS_QUEUE
+#define GMS_QUEUE 256
+#endif
+constexpr int QUEUE = GMS_QUEUE;   // LDS splat-queue entries per batch (<= BLOCK)
+constexpr int TLOC_HEAD = 4;       // segments whose transmittance products are always evaluated
+
+struct Unit {
+    int tile, seg, nseg, tx, ty;
+    uint32_t tile_beg;     // first entry of the tile in the sorted list
+    uint32_t beg, end;     // this unit's entries [beg, end)
+    uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
+};
+
+// Block -> unit.  The unit table lists full segments (seg_len entries) first, then the tiles' partial last
+// segments, then the units of empty tiles: blocks are dispatched in index order, so the long-running units
+// start first and the tail of the kernel is made of short ones.  The dispatcher places block b on XCD b % 8 (observed; speed only).  Units are dealt
+// to the XCDs in runs of UNIT_RUN consecutive units: a run is a stretch of neighbouring tiles that
+// gather the same splat records (L2 locality), while successive runs rotate over the eight XCDs so the
+// heavy image centre and the empty border are spread over all of them (units are far from equal work).
+constexpr uint32_t UNIT_RUN_MAX = 64;   // grid padding granularity; the run length itself is g.unit_run
+
+__device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
+{
+    const uint32_t nunits = g.unit_first[g.T];
+    const uint32_t s = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+    const uint32_t run = g.unit_run;
+    const uint32_t idx = ((s / run) * 8u + xcd) * run + (s % run);
+    if (idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
+    const uint2 ts = g.unit_tile[idx];
+    u.tile = (int)ts.x;
+    u.seg = (int)ts.y;
+    u.nseg = (int)(g.unit_first[u.tile + 1] - g.unit_first[u.tile]);
+    u.tx = u.tile % g.gx; u.ty = u.tile / g.gx;
+    u.tile_beg = g.tile_offset[u.tile];
+    const uint32_t tile_end = g.tile_offset[u.tile + 1];
+    u.beg = u.tile_beg + (uint32_t)u.seg * g.seg_len;
+    u.end = min(tile_end, u.beg + g.seg_len);
+    u.slot0 = g.mseg_first[u.tile];
+    return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
+}
+
+// experiment (GMS_DBG timelines): lane 0 of every wave records [start, end] of its wave on every exit path
+struct Stamp {
+    unsigned long long *buf, t0; uint32_t block; bool on;
+    __device__ __forceinline__ Stamp(unsigned long long *b) : buf(b), t0(b ? wall_clock64() : 0ull), block(blockIdx.x),
+        on(b != nullptr && (threadIdx.x & 63) == 0) { if (on) buf = b + 8ull * 65536ull * (threadIdx.x >> 6); }
+    __device__ __forceinline__ ~Stamp() { if (on) { buf[2 * (size_t)block] = t0; buf[2 * (size_t)block + 1] = wall_clock64(); } }
+};
+
 int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream);
 int32_t launch_blend_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream);
 
