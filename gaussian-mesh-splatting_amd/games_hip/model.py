@@ -196,6 +196,56 @@ class HipGaussianMeshModel(HipMeshMixin):
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
+    # ---- checkpoints: the reference's on-disk format (scene/gaussian_model.py:177-268 point_cloud.ply +
+    # games/mesh_splatting/scene/gaussian_mesh_model.py:189-222 model_params.pt), through the plyfile stand-in
+    def construct_list_of_attributes(self):
+        names = ["x", "y", "z", "nx", "ny", "nz"]
+        names += [f"f_dc_{i}" for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        names += [f"f_rest_{i}" for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+        return names
+
+    def save_ply(self, path):
+        import os
+        import numpy as np
+        from plyfile import PlyData, PlyElement
+        self.update_alpha()
+        self.prepare_scaling_rot()
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        xyz = self._xyz.detach().cpu().numpy()
+        cols = [xyz, np.zeros_like(xyz),
+                self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._opacity.detach().cpu().numpy(), self._scaling.detach().cpu().numpy(), self._rotation.detach().cpu().numpy()]
+        elements = np.empty(xyz.shape[0], dtype=[(a, "f4") for a in self.construct_list_of_attributes()])
+        elements[:] = list(map(tuple, np.concatenate(cols, axis=1)))
+        PlyData([PlyElement.describe(elements, "vertex")]).write(path)
+        torch.save({"_alpha": self._alpha, "_scale": self._scale, "point_cloud": None, "triangles": self.triangles,
+                    "vertices": self.vertices, "faces": self.faces}, path.replace("point_cloud.ply", "model_params.pt"))
+
+    def load_ply(self, path, device="cuda"):
+        import numpy as np
+        from plyfile import PlyData
+        el = PlyData.read(path).elements[0]
+        col = lambda n: np.asarray(el[n], dtype=np.float32)
+        P = el.count
+        f_dc = np.stack([col(f"f_dc_{i}") for i in range(3)], axis=1).reshape(P, 3, 1)
+        rest_names = sorted([p.name for p in el.properties if p.name.startswith("f_rest_")], key=lambda x: int(x.split("_")[-1]))
+        assert len(rest_names) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        f_rest = np.stack([col(n) for n in rest_names], axis=1).reshape(P, 3, (self.max_sh_degree + 1) ** 2 - 1)
+        par = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float, device=device).contiguous().requires_grad_(True))
+        self._features_dc = par(np.transpose(f_dc, (0, 2, 1)))
+        self._features_rest = par(np.transpose(f_rest, (0, 2, 1)))
+        self._opacity = par(col("opacity")[:, None])
+        params = torch.load(path.replace("point_cloud.ply", "model_params.pt"), map_location=device, weights_only=False)
+        self.vertices = nn.Parameter(params["vertices"].detach().to(device))
+        self.faces = params["faces"].to(device)
+        self._alpha = nn.Parameter(params["_alpha"].detach().to(device))
+        self._scale = nn.Parameter(params["_scale"].detach().to(device))
+        self.active_sh_degree = self.max_sh_degree
+        self.update_alpha()
+        self.prepare_scaling_rot()
+
     @property
     def get_xyz(self):
         return self._xyz

@@ -34,11 +34,13 @@ def import_reference():
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     # absent third-party deps: only their names are needed at import time
-    for name in ("plyfile", "trimesh", "smplx", "smplx.lbs", "smplx.utils", "simple_knn", "simple_knn._C"):
+    try:                                  # the repo ships a plyfile stand-in (gaussian-mesh-splatting_amd/plyfile.py)
+        import plyfile  # noqa: F401
+    except ImportError:
+        _stub("plyfile", PlyData=object, PlyElement=object)
+    for name in ("trimesh", "smplx", "smplx.lbs", "smplx.utils", "simple_knn", "simple_knn._C"):
         if name not in sys.modules:
             _stub(name)
-    sys.modules["plyfile"].PlyData = object
-    sys.modules["plyfile"].PlyElement = object
     sys.modules["simple_knn._C"].distCUDA2 = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stub"))
     for n in ("lbs", "batch_rodrigues", "vertices2landmarks", "find_dynamic_lmk_idx_and_bcoords", "blend_shapes",
               "vertices2joints"):

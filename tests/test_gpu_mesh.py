@@ -215,3 +215,24 @@ def test_model_getter_falls_back_when_opacity_changes_after_update_alpha():
     with torch.no_grad():
         m._opacity.add_(1.0)                       # e.g. an optimizer step without update_alpha()
     assert float((m.get_opacity - torch.sigmoid(m._opacity)).abs().max()) == 0.0
+
+
+def test_checkpoint_roundtrip_in_the_reference_file_format(tmp_path):
+    """save_ply / load_ply: point_cloud.ply with the reference's attribute list + model_params.pt."""
+    from games_hip.model import HipGaussianMeshModel
+    from games_hip.render import PipelineParams, render
+    from plyfile import PlyData
+    m = HipGaussianMeshModel.from_scene(syn.mesh_scene("tiny"), "cuda")
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    el = PlyData.read(path).elements[0]
+    assert [p.name for p in el.properties][:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    assert el.count == m._xyz.shape[0] and np.allclose(np.asarray(el["scale_1"]), m._scaling[:, 1].detach().cpu().numpy())
+    m2 = HipGaussianMeshModel(3)
+    m2.alpha_mode = m.alpha_mode
+    m2.load_ply(path)
+    for a in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc", "_features_rest"):
+        assert torch.equal(getattr(m, a).detach(), getattr(m2, a).detach()), a
+    cam = syn.orbit_camera(0, width=96, height=96).to("cuda")
+    bg = torch.ones(3, device="cuda")
+    assert torch.equal(render(cam, m, PipelineParams(), bg)["render"], render(cam, m2, PipelineParams(), bg)["render"])
