@@ -17,7 +17,7 @@ struct BlendGrid {
     const uint32_t *tile_offset;   // [T+1]
     const uint32_t *unit_first;    // [T+1] first unit of each tile; unit_first[T] = number of units
     const uint32_t *mseg_first;    // [T+1] first segment-state slot of each multi-segment tile
-    const uint2 *unit_tile;        // [units] (tile, segment) of each unit, heaviest first
+    const uint4 *unit_tile;        // [units][2] {tile, seg, nseg, slot0 | tile_beg, tile_end, -, -}, heaviest first
     const uint64_t *keys;          // sorted (depth, id) keys
     float *seg_state;              // [slots][SEG_FIELDS][256]
     uint32_t *tile_dead;           // [T] set by the tloc check: every pixel finished within the first segments
@@ -83,16 +83,17 @@ __device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
     const uint32_t run = g.unit_run;
     const uint32_t idx = ((s / run) * 8u + xcd) * run + (s % run);
     if (idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
-    const uint2 ts = g.unit_tile[idx];
-    u.tile = (int)ts.x;
-    u.seg = (int)ts.y;
-    u.nseg = (int)(g.unit_first[u.tile + 1] - g.unit_first[u.tile]);
+    // one 32-byte record per unit (written by fill_units): a single round trip instead of unit -> tile tables
+    const uint4 r0 = g.unit_tile[2 * (size_t)idx], r1 = g.unit_tile[2 * (size_t)idx + 1];
+    u.tile = (int)r0.x;
+    u.seg = (int)r0.y;
+    u.nseg = (int)r0.z;
+    u.slot0 = r0.w;
     u.tx = u.tile % g.gx; u.ty = u.tile / g.gx;
-    u.tile_beg = g.tile_offset[u.tile];
-    const uint32_t tile_end = g.tile_offset[u.tile + 1];
+    u.tile_beg = r1.x;
+    const uint32_t tile_end = r1.y;
     u.beg = u.tile_beg + (uint32_t)u.seg * g.seg_len;
     u.end = min(tile_end, u.beg + g.seg_len);
-    u.slot0 = g.mseg_first[u.tile];
     return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
 }
 

@@ -95,13 +95,13 @@ struct ImageState {
 // instance capacity N, the tile count T and the segment length L.
 struct BinningState {
     uint64_t *keys;        // [N]  (depth_bits << 32) | gaussian id ; sorted in place per tile segment
-    uint2 *unit_tile;      // [T + N/L + 1] (tile, segment) of each unit, heaviest units first
+    uint4 *unit_tile;      // [T + N/L + 1][2] unit records {tile, seg, nseg, slot0 | tile_beg, tile_end, -, -}, heaviest first
     float *seg_state;      // [2N/L + 2][7][256]
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
     static __host__ __device__ size_t bytes(size_t N, size_t T, size_t L)
     {
-        return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 8, 256) +
+        return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 32, 256) +
                align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
     }
     static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
@@ -109,7 +109,7 @@ struct BinningState {
         BinningState b;
         char *p = (char *)base;
         b.keys = (uint64_t *)p;      p += align_up((N > 0 ? N : 1) * 8, 256);
-        b.unit_tile = (uint2 *)p;    p += align_up(n_units(N, T, L) * 8, 256);
+        b.unit_tile = (uint4 *)p;    p += align_up(n_units(N, T, L) * 32, 256);
         b.seg_state = (float *)p;
         return b;
     }

@@ -455,23 +455,29 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
 }
 
 // unit table, heaviest first: [all full segments | partial last segments | units of empty tiles]
-__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count, const uint32_t *class_first, uint2 *unit_tile,
-                                                           int T, uint32_t L, uint32_t max_units)
+__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count, const uint32_t *class_first, const uint32_t *offset,
+                                                           const uint32_t *mseg_first, uint4 *unit_tile, int T, uint32_t L,
+                                                           uint32_t max_units)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T) return;
     const uint32_t c = count[t], nfull = c / L;
-    uint32_t u = class_first[t];
-    for (uint32_t s = 0; s < nfull; s++, u++)
-        if (u < max_units) unit_tile[u] = make_uint2((uint32_t)t, s);
     uint32_t q[NSCAN];
     tile_terms(c, L, q);
+    const uint32_t nseg = q[1];                          // units of this tile (>= 1)
+    const uint4 tail = make_uint4(offset[t], offset[t] + c, 0u, 0u);
+    const uint32_t slot0 = mseg_first[t];
+    auto put = [&](uint32_t u, uint32_t seg) {
+        if (u < max_units) {
+            unit_tile[2 * (size_t)u] = make_uint4((uint32_t)t, seg, nseg, slot0);
+            unit_tile[2 * (size_t)u + 1] = tail;
+        }
+    };
+    uint32_t u = class_first[t];
+    for (uint32_t s = 0; s < nfull; s++, u++) put(u, s);
     uint32_t base = class_first[T];                     // all full units come first
     for (int k = 1; k < NCLASS; k++) {
-        if (q[3 + k]) {
-            u = base + class_first[k * (T + 1) + t];
-            if (u < max_units) unit_tile[u] = make_uint2((uint32_t)t, k == NCLASS - 1 ? 0u : nfull);
-        }
+        if (q[3 + k]) put(base + class_first[k * (T + 1) + t], k == NCLASS - 1 ? 0u : nfull);
         base += class_first[k * (T + 1) + T];
     }
 }
@@ -877,7 +883,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                              img.tile_cursor, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
-        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.tile_count, img.class_first, bin.unit_tile, T, L, mu);
+        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.tile_count, img.class_first, img.tile_offset, img.mseg_first,
+                                                                                     bin.unit_tile, T, L, mu);
         GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, capacity));
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity));
