@@ -219,9 +219,9 @@ __global__ void __launch_bounds__(BLOCK) blend_head_kernel(BlendGrid g, BlendFwd
     __shared__ SplatRec recs[QUEUE];
     Unit u;
     if (!load_unit(g, u)) return;
-    Stamp stamp((g.dbg & 256u) ? g.dbg_buf : nullptr);
-    if (u.seg == 0) { if (phase <= 0 && !(g.dbg & 32u)) fwd_unit<NE>(g, o, u, recs); }
-    else if (!(g.dbg & 64u)) tloc_unit<NE>(g, o.rec, u, recs, phase);
+    Stamp stamp(dbg_on(g, 256u) ? g.dbg_buf : nullptr);
+    if (u.seg == 0) { if (phase <= 0 && !dbg_on(g, 32u)) fwd_unit<NE>(g, o, u, recs); }
+    else if (!dbg_on(g, 64u)) tloc_unit<NE>(g, o.rec, u, recs, phase);
 }
 
 // Second launch: segments 1.. of the multi-segment tiles, from the prefix product of the segments in front.
@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdO
     Unit u;
     if (!load_unit(g, u)) return;
     if (u.seg == 0) return;
-    Stamp stamp((g.dbg & 128u) ? g.dbg_buf : nullptr);
+    Stamp stamp(dbg_on(g, 128u) ? g.dbg_buf : nullptr);
     fwd_unit<NE>(g, o, u, recs);
 }
 
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     if (!load_unit(g, u)) return;
     if (u.end <= u.beg) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    Stamp stamp((g.dbg & 16u) ? g.dbg_buf : nullptr);
+    Stamp stamp(dbg_on(g, 16u) ? g.dbg_buf : nullptr);
     const Pix p = pixel_of(g, u);
     const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
@@ -403,7 +403,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     __syncthreads();
     const uint32_t top = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
     if (top == 0) return;
-    if (g.dbg & 2u) return;                              // experiment: prologue only
+    if (dbg_on(g, 2u)) return;                              // experiment: prologue only
 
     for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > QUEUE ? hi - QUEUE : seg_lo) {
         const int cnt = (int)min((uint32_t)QUEUE, hi - seg_lo);
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
-            if (g.dbg & 4u) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
+            if (dbg_on(g, 4u)) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
                 // NE queue entries per trip: loads, exp and the wave reductions of different entries are independent
                 // and interleave; only the per-pixel recurrence is sequential (entry e is behind entry e+1)
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                     act[e] = val[e] && pos < last && pw <= 0.f && al[e] >= ALPHA_MIN;
                     any[e] = __any(act[e]);
                 }
-                const bool noatomics = (g.dbg & 1u) != 0;                           // experiment switch
+                const bool noatomics = dbg_on(g, 1u);                           // experiment switch
 #pragma unroll
                 for (int e = 0; e < NE; e += 2) {
                     const int f = e + 1;
@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                     if (any[e] && any[f]) {
                         bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
                         bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
-                        if (g.dbg & 8u) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
+                        if (dbg_on(g, 8u)) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
                         float y0a, y1a, y0b, y1b;
                         wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
                         if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
@@ -483,7 +483,7 @@ int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
     // two-phase transmittance products pay off when tiles are deep on average (> 2 segments per tile over the
     // whole image); shallow scenes take one launch
     static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = (GMS_EXPERIMENTS && e) ? atoi(e) : 0; }
     BlendGrid g = g_in;
     g.dbg = (uint32_t)dbg;
     g.dbg_buf = nullptr;
@@ -516,7 +516,7 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
 {
     BlendGrid g = g_in;
     static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = e ? atoi(e) : 0; }
+    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = (GMS_EXPERIMENTS && e) ? atoi(e) : 0; }
     g.dbg = (uint32_t)dbg;
     g.dbg_buf = nullptr;
     if (dbg & 16) {

@@ -97,6 +97,13 @@ __device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
     return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
 }
 
+// Experiment switches (env GMS_DBG) exist only in builds made with `make EXPERIMENTS=1`;
+// in the default build every `dbg_on()` is a compile-time false and the branches disappear from the kernels.
+#ifndef GMS_EXPERIMENTS
+#define GMS_EXPERIMENTS 0
+#endif
+__device__ __forceinline__ bool dbg_on(const BlendGrid &g, uint32_t bit) { return GMS_EXPERIMENTS && (g.dbg & bit) != 0; }
+
 // experiment (GMS_DBG timelines): lane 0 of every wave records [start, end] of its wave on every exit path
 struct Stamp {
     unsigned long long *buf, t0; uint32_t block; bool on;

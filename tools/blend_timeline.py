@@ -1,5 +1,5 @@
 """Debug: per-wave start/end timeline of one blend kernel.  GMS_DBG bit: 16 = blend_bwd, 128 = blend_fwd (segments >= 1),
-256 = blend_head (first segments + transmittance products).  Run on the GPU box:  python tools/blend_timeline.py 128"""
+256 = blend_head (first segments + transmittance products).  Needs a library built with `make EXPERIMENTS=1`.  Run on the GPU box:  python tools/blend_timeline.py 128"""
 import ctypes as C, os, sys
 bit = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 os.environ["GMS_DBG"] = str(bit)
