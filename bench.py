@@ -122,6 +122,10 @@ def main():
     ap.add_argument("--loss", default="dense_grad", choices=["dense_grad", "l1_ssim"],
                     help="dense_grad: the headline step of SURVEY 8(d), dL/dcolor = (image-0.5)/(3HW); l1_ssim: the reference's "
                          "training loss (train.py:106-107) through the fused HIP L1+SSIM kernels against a synthetic target")
+    ap.add_argument("--views-per-step", type=int, default=0,
+                    help="views each rank renders (fwd+bwd) per step, their gradients accumulated before the ONE all-reduce of the "
+                         "step; default 1 on one GPU, 4 on several (global batch = 4 x world views: 63.6 MB of gradients cross "
+                         "xGMI once per four views instead of once per view); 1 reproduces the un-amortised collective")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -154,11 +158,13 @@ def main():
     scene = syn.mesh_scene(args.workload, state=args.state)
     size = scene.meta["image"]
     model = HipGaussianMeshModel.from_scene(scene, device)
-    cam = syn.orbit_camera(rank % 8, width=size, height=size).to(device)
+    vps = args.views_per_step if args.views_per_step > 0 else (1 if world == 1 else 4)
+    cams = [syn.orbit_camera((rank * vps + v) % 8, width=size, height=size).to(device) for v in range(vps)]
+    cam = cams[0]
     bg = torch.ones(3, device=device)
     pipe = PipelineParams()
     params = model.parameters()
-    inv_norm = 1.0 / (3.0 * size * size)
+    inv_norm = 1.0 / (3.0 * size * size * vps)          # mean over the views of the step
     neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
     reducer = OverlappedGradAllReduce(params, world) if world > 1 else None
 
@@ -172,15 +178,18 @@ def main():
                              fused=args.optimizer == "fused_adam")
 
     def step():
-        model.update_alpha()
+        model.update_alpha()                             # once per step: the parameters are the same for all its views
         model.prepare_scaling_rot()
-        image = render(cam, model, pipe, bg)["render"]
+        images = [render(c, model, pipe, bg)["render"] for c in cams]
         if args.loss == "l1_ssim":
-            l1_ssim_loss(image, gt_image, 0.2).backward()
+            loss = l1_ssim_loss(images[0], gt_image, 0.2)
+            for im in images[1:]:
+                loss = loss + l1_ssim_loss(im, gt_image, 0.2)
+            (loss / vps if vps > 1 else loss).backward()
         else:
             with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
-                grad = torch.add(neg_half_norm, image, alpha=inv_norm)      # one elementwise kernel
-            image.backward(grad)
+                grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
+            torch.autograd.backward(images, grads)
         if reducer is not None:
             reducer.finish()      # collectives were started from autograd hooks during backward
         if args.optimizer != "none":
@@ -236,7 +245,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1000.0 * elapsed / args.steps
-    value = world * args.steps / elapsed
+    value = world * vps * args.steps / elapsed
     stats = last_stats()
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)
@@ -273,7 +282,7 @@ def main():
         dom = max(kernels, key=lambda k: kernels[k]["avg_us"] * kernels[k]["launches_per_step"])
         kd = kernels[dom]
         sum_kernel_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels.values())
-        whole_bytes = 877 * P + 156 * N + 48 * size * size + 152 * P + 72 * F
+        whole_bytes = vps * (877 * P + 156 * N + 48 * size * size) + 152 * P + 72 * F      # K0 runs once per step
         out = {
             "metric": "train iters/s (fwd+bwd raster) @800x800, 300k Gaussians; HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,8 +291,11 @@ def main():
             "config": {"workload": f"{args.workload}/{args.state}: UV-sphere mesh F={F} x {scene.meta['S']} splats = {P} "
                                    f"mesh-bound Gaussians, SH degree 3, {size}x{size}, orbit camera k=rank%8, white bg",
                        "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
-                       "views_per_step": world, "parallelism": f"view-parallel x{world}" if world > 1 else "single view",
-                       "step": "K0 fwd + render fwd + bwd (+ grad all-reduce when N>1)"
+                       "views_per_step": world * vps, "views_per_rank_per_step": vps,
+                       "parallelism": (f"view-parallel x{world}, {vps} view(s) per rank per step, one gradient all-reduce "
+                                       f"(63.6 MB) per step") if world > 1 else "single view",
+                       "step": (f"K0 fwd + {vps} x (render fwd + bwd)" if vps > 1 else "K0 fwd + render fwd + bwd")
+                               + " (+ grad all-reduce when N>1)"
                                + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")
                                + (f" + optimizer.step() [{args.optimizer}]" if args.optimizer != "none" else "")},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
