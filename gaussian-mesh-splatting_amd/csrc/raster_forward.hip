@@ -364,12 +364,18 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 // One block: exclusive scans over the tiles of (a) instance counts -> tile_offset (offset[T] = N),
 // (b) segments per tile -> unit_first, (c) segments of multi-segment tiles -> mseg_first (slots of
 // the per-unit pixel state).  Also resets the emit cursors.
-constexpr int NSCAN = 9;
+// tile sort (K4) sizes, needed by the scan below
+constexpr int SORT_RUN = 1024;
+constexpr int SORT_RUNS_PER_TILE = 8;
+constexpr int SORT_BIG_CHUNK = SORT_RUN * SORT_RUNS_PER_TILE;    // 8192 keys = 64 KiB LDS
+constexpr int MP_CHUNK = 1024;                                   // output keys per merge-path block
+
+constexpr int NSCAN = 10;
 constexpr int NCLASS = 6;     // dispatch classes: full | partial >=3/4 L | >=1/2 L | >=1/4 L | < 1/4 L | empty
 constexpr int SCAN_THREADS = 1024;
 
 // per-tile quantities scanned: instances, segments, segments of multi-segment tiles, then the dispatch classes
-__device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NSCAN])
+__device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NSCAN], int sort_np = 0)
 {
     const uint32_t ns = max(1u, (c + L - 1) / L);   // empty tiles still get a unit (background)
     t[0] = c; t[1] = ns; t[2] = ns > 1 ? ns : 0;
@@ -380,6 +386,9 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
     t[6] = (r * 2 < L && r * 4 >= L) ? 1u : 0u;
     t[7] = (r * 4 < L && r != 0) ? 1u : 0u;
     t[8] = c == 0 ? 1u : 0u;
+    // merge-path sort chunks: of the tiles deeper than one LDS merge holds, or -- when passes are launched anyway --
+    // of every tile with more than one presorted run
+    t[9] = c > (uint32_t)(sort_np > 0 ? SORT_RUN : SORT_BIG_CHUNK) ? (c + MP_CHUNK - 1) / MP_CHUNK : 0u;
 }
 
 // One block of 1024 threads: NSCAN exclusive scans over the tiles at once.  Each wave scans its 64 per-thread
@@ -387,21 +396,26 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
                                                                  uint32_t *unit_first, uint32_t *mseg_first,
                                                                  uint32_t *class_first, int T, uint32_t L, int32_t *host_slot,
-                                                                 int32_t seq)
+                                                                 int32_t seq, int sort_np)
 {
     __shared__ uint32_t wave_tot[NSCAN][SCAN_THREADS / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
     const int b = tid * per, e = min(T, b + per);
     uint32_t run[NSCAN], own[NSCAN];
+    uint32_t deepest = 0;
 #pragma unroll
     for (int k = 0; k < NSCAN; k++) run[k] = 0;
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
-        tile_terms(count[t], L, q);
+        tile_terms(count[t], L, q, sort_np);
+        deepest = max(deepest, q[0]);
 #pragma unroll
         for (int k = 0; k < NSCAN; k++) run[k] += q[k];
     }
+    for (int d = 32; d >= 1; d >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, d));
+    __shared__ uint32_t wave_deep[SCAN_THREADS / WAVE];
+    if (lane == 0) wave_deep[wave] = deepest;
     // inclusive scan inside the wave
 #pragma unroll
     for (int k = 0; k < NSCAN; k++) {
@@ -434,15 +448,19 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
     // The instance count N goes straight to the host: two system-scope stores into pinned memory (value, then the
     // call's sequence number) that the waiting host thread polls -- no copy-engine hop, no event wake-up latency.
     if (tid == 0 && host_slot) {
+        uint32_t dm = 0;
+        for (int w = 0; w < SCAN_THREADS / WAVE; w++) dm = max(dm, wave_deep[w]);
+        __hip_atomic_store(&host_slot[2], (int32_t)dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // deepest tile
         __hip_atomic_store(&host_slot[0], (int32_t)tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_slot[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
-        tile_terms(count[t], L, q);
+        tile_terms(count[t], L, q, sort_np);
         offset[t] = run[0]; unit_first[t] = run[1]; mseg_first[t] = run[2];
 #pragma unroll
         for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + t] = run[3 + k];
+        class_first[NCLASS * (T + 1) + t] = run[9];
         cursor[t] = 0;
 #pragma unroll
         for (int k = 0; k < NSCAN; k++) run[k] += q[k];
@@ -451,19 +469,20 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
         offset[T] = tot[0]; unit_first[T] = tot[1]; mseg_first[T] = tot[2];
 #pragma unroll
         for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + T] = tot[3 + k];
+        class_first[NCLASS * (T + 1) + T] = tot[9];
     }
 }
 
 // unit table, heaviest first: [all full segments | partial last segments | units of empty tiles]
 __global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count, const uint32_t *class_first, const uint32_t *offset,
                                                            const uint32_t *mseg_first, uint4 *unit_tile, int T, uint32_t L,
-                                                           uint32_t max_units)
+                                                           uint32_t max_units, uint2 *deep_tab, uint32_t max_deep, int sort_np)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= T) return;
     const uint32_t c = count[t], nfull = c / L;
     uint32_t q[NSCAN];
-    tile_terms(c, L, q);
+    tile_terms(c, L, q, sort_np);
     const uint32_t nseg = q[1];                          // units of this tile (>= 1)
     const uint4 tail = make_uint4(offset[t], offset[t] + c, 0u, 0u);
     const uint32_t slot0 = mseg_first[t];
@@ -473,6 +492,8 @@ __global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count
             unit_tile[2 * (size_t)u + 1] = tail;
         }
     };
+    for (uint32_t j = 0, d = class_first[NCLASS * (T + 1) + t]; j < q[9]; j++, d++)
+        if (d < max_deep) deep_tab[d] = make_uint2((uint32_t)t, j);
     uint32_t u = class_first[t];
     for (uint32_t s = 0; s < nfull; s++, u++) put(u, s);
     uint32_t base = class_first[T];                     // all full units come first
@@ -609,36 +630,146 @@ __device__ void lds_bitonic(uint64_t *s, int m, int k0, int j0, bool first_mirro
     __syncthreads();
 }
 
-// Two launches.  (1) presort: grid (T, 8), 256 threads: block (t, c) sorts the c-th run of SORT_RUN keys of
-// tile t in LDS (runs of one tile sort on different CUs).  (2) merge: 1024 threads per tile with more than
-// one run: loads the tile (<= SORT_BIG_CHUNK keys) into LDS and runs only the merge levels above SORT_RUN
-// (25 sub-stages instead of 91 for 8192 keys).  Tiles beyond SORT_BIG_CHUNK keys take the generic path
-// (LDS-sorted 8192-key runs + wide strides in global memory).
-constexpr int SORT_RUN = 1024;
-constexpr int SORT_RUNS_PER_TILE = 8;
-constexpr int SORT_BIG_CHUNK = SORT_RUN * SORT_RUNS_PER_TILE;    // 8192 keys = 64 KiB LDS
+// Per-tile sort in three stages.
+//  (1) presort: grid (T, 8), 256 threads: block (t, c) sorts runs c, c+8, ... of SORT_RUN keys of tile t in LDS (the
+//      runs of one tile sort on different CUs).
+//  (2) when some tile is deeper than SORT_BIG_CHUNK keys: merge-path passes for every multi-run tile, run width
+//      doubling per pass; every block produces one 1024-key chunk of the output from the co-ranks of its two ends
+//      (found by a wave-wide 64-ary search), so a deep tile's merge is spread over as many CUs as it has chunks and
+//      each pass is a streaming read + write of the keys that still need merging.  Data ping-pongs between `keys` and a scratch buffer (the segment-state area, unused until
+//      compositing); the presort writes a tile's runs to the side that makes its LAST pass land in `keys`.  The host
+//      launches as many passes as the deepest tile of the PREVIOUS frame needs (the count travels back with N);
+//  (3) merge: 1024 threads per tile with 2..8 runs: loads the tile (<= SORT_BIG_CHUNK keys) into LDS and runs only the
+//      bitonic merge levels above SORT_RUN.  A tile deeper than the launched passes cover (scene changed since the last
+//      frame) is sorted from scratch here by one block: slow, but correct, and the next frame launches enough passes.
 
-__global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+enum { SORT_SINGLE = 0, SORT_LDS, SORT_MERGEPATH, SORT_FALLBACK };
+
+__host__ __device__ __forceinline__ int sort_passes(uint64_t n)       // merge levels above SORT_RUN-key runs
+{
+    const uint64_t runs = (n + SORT_RUN - 1) / SORT_RUN;
+    int q = 0;
+    while ((1ull << q) < runs) q++;
+    return q;
+}
+
+__device__ __forceinline__ int sort_class(uint64_t n, int passes_launched, int &q)
+{
+    q = 0;
+    if (n <= (uint64_t)SORT_RUN) return SORT_SINGLE;
+    q = sort_passes(n);
+    if (q <= passes_launched) return SORT_MERGEPATH;      // passes are launched: every multi-run tile they cover takes them
+    return n <= (uint64_t)SORT_BIG_CHUNK ? SORT_LDS : SORT_FALLBACK;
+}
+
+__global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
+                                                           int passes_launched)
 {
     __shared__ uint64_t s[SORT_RUN];
     const int tid = threadIdx.x;
     const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
     if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
     const long n = (long)(end64 - beg);
-    if (n <= 1 || n > SORT_BIG_CHUNK) return;
-    const long c0 = (long)blockIdx.y * SORT_RUN;
-    if (c0 >= n) return;
-    const int cn = (int)min((long)SORT_RUN, n - c0);
-    if (cn <= 1) return;
-    uint64_t *g = keys + beg + c0;
-    int m = 2;
-    while (m < cn) m <<= 1;
-    for (int i = tid; i < m; i += 256) s[i] = i < cn ? g[i] : ~0ull;
-    lds_bitonic<256>(s, m, 2, 0, true, tid);
-    for (int i = tid; i < cn; i += 256) g[i] = s[i];
+    if (n <= 1) return;
+    int q;
+    const int cls = sort_class((uint64_t)n, passes_launched, q);
+    if (cls == SORT_FALLBACK) return;
+    uint64_t *dst_base = (cls == SORT_MERGEPATH && (q & 1)) ? tmp : keys;
+    for (long c0 = (long)blockIdx.y * SORT_RUN; c0 < n; c0 += (long)SORT_RUNS_PER_TILE * SORT_RUN) {
+        const int cn = (int)min((long)SORT_RUN, n - c0);
+        const uint64_t *g = keys + beg + c0;
+        uint64_t *d = dst_base + beg + c0;
+        if (cn <= 1) { if (cn == 1 && tid == 0) d[0] = g[0]; continue; }
+        int m = 2;
+        while (m < cn) m <<= 1;
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) s[i] = i < cn ? g[i] : ~0ull;
+        lds_bitonic<256>(s, m, 2, 0, true, tid);
+        for (int i = tid; i < cn; i += 256) d[i] = s[i];
+    }
 }
 
-__global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity)
+// number of elements taken from A among the first o outputs of merge(A, B) (keys are unique)
+template <typename PA, typename PB>
+__device__ __forceinline__ int co_rank(int o, PA A, int la, PB B, int lb)
+{
+    int lo = max(0, o - lb), hi = min(o, la);
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (A[mid] < B[o - mid - 1]) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// The same co-rank found by a whole wave: 64 probes per round instead of one, so a 16 k-wide search takes three memory
+// round trips instead of fourteen (the block cannot start loading before it knows both ends of its chunk).
+__device__ __forceinline__ int co_rank_wave(int o, const uint64_t *A, int la, const uint64_t *B, int lb)
+{
+    const int lane = threadIdx.x & 63;
+    int lo = max(0, o - lb), hi = min(o, la);
+    while (lo < hi) {
+        const int step = (hi - lo + 63) / 64;
+        const int mid = lo + lane * step;
+        const bool need_more = mid < hi && A[mid] < B[o - mid - 1];      // monotone in mid: true ... true false ... false
+        const int cnt = __builtin_popcountll(__ballot(need_more));
+        const int nlo = cnt > 0 ? lo + (cnt - 1) * step + 1 : lo;
+        const int nhi = (cnt < 64 && lo + cnt * step < hi) ? lo + cnt * step : hi;
+        lo = nlo; hi = nhi;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) tile_mergepath_kernel(const uint32_t *tile_offset, const uint32_t *deep_first, const uint2 *deep_tab,
+                                                             uint32_t max_deep, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
+                                                             int passes_launched, int pass)
+{
+    __shared__ uint64_t s[MP_CHUNK];
+    __shared__ int s_rank[2];
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= deep_first[0] || blockIdx.x >= max_deep) return;      // deep_first[0] here = total number of chunks
+    const uint2 tc = deep_tab[blockIdx.x];
+    const uint64_t beg = tile_offset[tc.x], end64 = tile_offset[tc.x + 1];
+    if (end64 > capacity) return;
+    const long n = (long)(end64 - beg);
+    int q;
+    if (sort_class((uint64_t)n, passes_launched, q) != SORT_MERGEPATH || pass >= q) return;
+    const bool src_is_tmp = ((q - pass) & 1) != 0;
+    const uint64_t *src = (src_is_tmp ? tmp : keys) + beg;
+    uint64_t *dst = (src_is_tmp ? keys : tmp) + beg;
+    const long w = (long)SORT_RUN << pass;
+    const long j0 = (long)tc.y * MP_CHUNK;
+    const long base = (j0 / (2 * w)) * (2 * w);
+    const long a1 = min(n, base + w), b1 = min(n, base + 2 * w);
+    const int la = (int)(a1 - base), lb = (int)(b1 - a1);
+    const uint64_t *A = src + base, *B = src + a1;
+    const int o0 = (int)(j0 - base), o1 = (int)min((long)(o0 + MP_CHUNK), (long)(la + lb));
+    if (tid < 64) { const int r = co_rank_wave(o0, A, la, B, lb); if (tid == 0) s_rank[0] = r; }
+    else if (tid < 128) { const int r = co_rank_wave(o1, A, la, B, lb); if (tid == 64) s_rank[1] = r; }
+    __syncthreads();
+    const int ra0 = s_rank[0], ra1 = s_rank[1];
+    const int rb0 = o0 - ra0, rb1 = o1 - ra1;
+    const int na = ra1 - ra0, nb = rb1 - rb0;
+    for (int i = tid; i < na; i += 256) s[i] = A[ra0 + i];
+    for (int i = tid; i < nb; i += 256) s[na + i] = B[rb0 + i];
+    __syncthreads();
+    // each thread merges four consecutive outputs from its own co-rank inside the LDS pieces
+    const int cnt = o1 - o0;
+    const int lo = tid * 4;
+    if (lo < cnt) {
+        const uint64_t *LA = s, *LB = s + na;
+        int ia = co_rank(lo, LA, na, LB, nb), ib = lo - ia;
+        uint64_t out[4];
+        const int m = min(4, cnt - lo);
+        for (int k = 0; k < m; k++) {
+            const bool takeA = ib >= nb || (ia < na && LA[ia] < LB[ib]);
+            out[k] = takeA ? LA[ia++] : LB[ib++];
+        }
+        for (int k = 0; k < m; k++) dst[base + o0 + lo + k] = out[k];
+    }
+}
+
+__global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity, int passes_launched)
 {
     constexpr int THREADS = 1024, CHUNK = SORT_BIG_CHUNK;
     __shared__ uint64_t s[CHUNK];
@@ -646,20 +777,23 @@ __global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_o
     const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
     if (end64 > capacity) return;
     const long n = (long)(end64 - beg);
-    if (n <= SORT_RUN) return;                    // a single presorted run
+    int q;
+    const int cls = sort_class((uint64_t)n, passes_launched, q);
+    if (cls == SORT_SINGLE || cls == SORT_MERGEPATH) return;
     uint64_t *g = keys + beg;
     long np2 = 2;
     while (np2 < n) np2 <<= 1;
     const uint64_t INF = ~0ull;
 
-    if (np2 <= CHUNK) {                           // runs of SORT_RUN keys are sorted: merge levels only
+    if (cls == SORT_LDS) {                        // runs of SORT_RUN keys are sorted: merge levels only
         const int m = (int)np2;
         for (int i = tid; i < m; i += THREADS) s[i] = i < n ? g[i] : INF;
         lds_bitonic<THREADS>(s, m, 2 * SORT_RUN, 0, true, tid);
         for (int i = tid; i < n; i += THREADS) g[i] = s[i];
         return;
     }
-    // very long segment: sort CHUNK-sized runs in LDS, then merge with wide strides in global memory
+    // fallback (deeper than the launched merge-path passes cover): sort CHUNK-sized runs in LDS, then merge with
+    // wide strides in global memory, all by this one block
     for (long c = 0; c < n; c += CHUNK) {
         for (int i = tid; i < CHUNK; i += THREADS) s[i] = (c + i) < n ? g[c + i] : INF;
         lds_bitonic<THREADS>(s, CHUNK, 2, 0, true, tid);
@@ -749,6 +883,7 @@ static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, in
     *N = (int64_t)(uint32_t)__atomic_load_n(&slot[0], __ATOMIC_RELAXED);
     return GMS_OK;
 }
+static uint32_t deepest_tile(const int32_t *slot) { return (uint32_t)__atomic_load_n(&slot[2], __ATOMIC_RELAXED); }
 
 uint32_t seg_len()
 {
@@ -866,11 +1001,16 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const uint32_t L = seg_len();
     int32_t *slot = pinned_slot();
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
+    // merge-path passes for tiles deeper than SORT_BIG_CHUNK keys: as many as the deepest tile of the previous frame
+    // (+25 %) needs; a deeper tile than that falls back to the one-block sort and raises the count for the next frame
+    static thread_local uint32_t deepest_seen = 0;
+    int sort_np = 0;
+    if (deepest_seen > (uint32_t)SORT_BIG_CHUNK) sort_np = sort_passes((uint64_t)deepest_seen + deepest_seen / 4);
     static thread_local int32_t seq_counter = 0;
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
                                                                                    img.unit_first, img.mseg_first, img.class_first, T, L,
-                                                                                   slot, seq));
+                                                                                   slot, seq, sort_np));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
 
     BlendFwdOut bo;
@@ -884,10 +1024,17 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
                                                                                              img.tile_cursor, bin.keys, capacity));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.tile_count, img.class_first, img.tile_offset, img.mseg_first,
-                                                                                     bin.unit_tile, T, L, mu);
+                                                                                     bin.unit_tile, T, L, mu, bin.deep_tab,
+                                                                                     (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T), sort_np);
         GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, capacity));
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity));
+        uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
+        if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, sort_tmp, capacity, sort_np));
+        const uint32_t max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
+        for (int pass = 0; pass < sort_np; pass++)
+            GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, img.class_first + NCLASS * ((size_t)T + 1) + T, bin.deep_tab,
+                                                                                                   max_deep, bin.keys, sort_tmp, capacity, sort_np, pass));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity, sort_np));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
@@ -906,6 +1053,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (rc != GMS_OK) return rc;
         rc = wait_for_count(slot, seq, stream, &N);
         if (rc != GMS_OK) return rc;
+        deepest_seen = deepest_tile(slot);
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
             bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
@@ -916,6 +1064,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     } else {
         int32_t rc0 = wait_for_count(slot, seq, stream, &N);
         if (rc0 != GMS_OK) return rc0;
+        deepest_seen = deepest_tile(slot);
         const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }

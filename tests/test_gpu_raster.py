@@ -272,3 +272,28 @@ def test_repeated_backward_reuses_the_rezeroed_gradient_records():
             h, ref = U.hip_render(inputs, kw, grad_color=-2.0 * gc, grad_invdepth=gdm), ref_b
         for k, v in U.grad_report(h["grads"], ref["grads"], q=0.999).items():
             assert v["q_rel"] <= GRAD_REL, (which, k, v)
+
+
+@pytest.mark.parametrize("P", [9000, 30000])
+def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
+    """Tiles deeper than 8192 keys: frame 1 sorts them with the one-block fallback (no history), later frames with
+    the multi-block merge-path passes sized from the previous frame's deepest tile.  Every frame must match the oracle
+    (depth ties by id included), and a shallow frame in between must not disturb anything."""
+    g = torch.Generator().manual_seed(2)
+    means = torch.randn(P, 3, generator=g) * 0.015
+    means[: P // 3, 1] = 0.0                                      # exact depth ties
+    sc = syn.random_scene(P, seed=13, scale_lo=0.002, scale_hi=0.008, opacity_lo=0.005, opacity_hi=0.03)
+    cam = syn.look_at_camera((0.0, -3.0, 0.0), width=48, height=48, fovx=0.5)
+    kw = U.settings_kwargs(cam, torch.zeros(3))
+    inputs = dict(means3D=means, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    o = U.oracle_render(inputs, kw)
+    rng = o["details"]["ranges"]
+    assert (rng[:, 1] - rng[:, 0]).max() > 8192
+    shallow = syn.random_scene(500, seed=3)
+    sh_in, sh_kw = _inputs(shallow), U.settings_kwargs(syn.orbit_camera(0, width=48, height=48), torch.zeros(3))
+    for frame in range(4):
+        if frame == 2:
+            U.hip_render(sh_in, sh_kw, need_grad=False)           # a shallow frame resets the pass count
+        h = U.hip_render(inputs, kw, need_grad=False)
+        rep = U.forward_report(h, o, 48, 48)
+        assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, (frame, rep)
