@@ -35,14 +35,16 @@ def algorithmic_bytes(P, N, F, W, H):
         "tile_scan": 8 * ((W + 15) // 16) * ((H + 15) // 16),
         "emit_instances": 12 * N,                  # binning lower bound 28*N = emit 12 + sort 16
         "tile_sort": 16 * N,
-        "blend_fwd": 44 * N + 24 * HW,             # id 4 + gathered record 40 per instance; 24 B per pixel
+        "blend_fwd": 0,         # (segments 1.. of the walk: part of blend_head's algorithmic bytes, see below)
         "blend_bwd": 84 * N + 24 * HW,             # 44 + one reduced 40-B gradient record per instance
         "preprocess_bwd": 569 * P,                 # read 321 + write 248 per Gaussian
         "mesh_fwd": 36 * F + 56 * P,               # tri 36/face; alpha 12 + scale 4 in, 40 out per splat
         "mesh_bwd_splat": 56 * P,
         "mesh_bwd_face": 40 * P + 36 * F,
-        "blend_tloc": 0,        # implementation passes of the segment-parallel compositing: their traffic is
-        "blend_finalize": 0,    # overhead on top of blend_fwd's algorithmic bytes, not extra algorithmic work
+        # forward compositing = blend_head (first segments + products) + blend_fwd (later segments) + blend_finalize: the
+        # algorithmic bytes of the whole forward walk are booked on the first launch, the other two are implementation passes
+        "blend_head": 44 * N + 24 * HW,            # id 4 + gathered record 40 per instance; 24 B per pixel
+        "blend_finalize": 0,
         "l1_ssim_fwd": 20 * 3 * HW,   # --loss l1_ssim only: read image + gt, write three derivative maps
         "l1_ssim_bwd": 24 * 3 * HW,   # read image + gt + three maps, write dL/dimage
         "adam": 28 * (3 * F // 2 + 6 + 52 * P),   # --optimizer fused_adam: 16 B read + 12 B written per parameter element

@@ -6,22 +6,25 @@
 // a heavy tile (thousands of splats around mesh poles / silhouettes) run on different CUs instead
 // of serialising behind one block:
 //
-//   tloc     (multi-segment tiles only) per unit and pixel: T_loc = prod(1 - alpha) over the
-//            segment, no termination.  Not needed for a tile's last segment.
-//   fwd      per unit: T_start = prod_{k<seg} T_loc_k; a pixel whose T_start < 1e-4 is finished
-//            (any further contributing splat fails the T*(1-a) < 1e-4 test).  Exact front-to-back
-//            walk with the reference's skip/stop tests from T_start.  Single-segment tiles write
-//            the final image directly; multi-segment units write (C, D, T_end, last) partials.
+//   head     first launch, every unit that depends on nothing: the exact front-to-back walk of each tile's FIRST
+//            segment (reference skip/stop tests; single-segment tiles are finished by it, and the T it ends with is
+//            that segment's transmittance product) and, for the middle segments of multi-segment tiles,
+//            T_loc = prod(1 - alpha) over the segment without termination.  On deep scenes the products run in two
+//            phases with a per-tile check in between, so they stop where the tile is already opaque.
+//   fwd      second launch, segments 1..: T_start = prod_{k<seg} T_loc_k; a pixel whose T_start < 1e-4 is finished
+//            (any further contributing splat fails the T*(1-a) < 1e-4 test); exact walk from T_start.  Multi-segment
+//            units write (C, D, T_end, last) partials.
 //   finalize (multi-segment tiles) sums the partials in segment order and writes image / final_T /
 //            n_contrib; the partials stay in place for the backward pass.
 //   bwd      per unit, back-to-front from (T_end, suffix colour / T_end): the reference's recurrence
-//            restarted at a segment boundary.  Ten partial gradients per (wave, splat) are summed
-//            over the 64 lanes with DPP row operations and leave the wave as ONE hardware float
-//            atomic each.
+//            restarted at a segment boundary.  Ten partial sums per (wave, splat) -- moments of q = dL/dG*G and the
+//            colour weights -- are reduced over the 64 lanes with a transposing DPP / permlane network and leave the
+//            wave as ONE atomic instruction into the splat's 64-byte record.
 //
 // Inside a unit the splat records are gathered 256 at a time into an LDS queue; every wave tests
 // 64 queue entries at once against its quadrant (bounding box of the alpha >= 1/255 ellipse --
-// exact: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors.
+// exact: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors,
+// NE (= 4) entries per trip: their alpha evaluations are independent, only the recurrence is serial.
 #include <stdlib.h>
 
 #include "gms_common.h"
@@ -498,13 +501,13 @@ int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
     auto head = trip == 2 ? blend_head_kernel<2> : blend_head_kernel<4>;
     auto fwd2 = trip == 2 ? blend_fwd_kernel<2> : blend_fwd_kernel<4>;
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, blend_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, blend_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_TLOC, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, -1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, -1));
     }
-    GMS_KERNEL_CHECK(debug, stream, "blend_tloc");
+    GMS_KERNEL_CHECK(debug, stream, "blend_head");
     GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<blocks, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, blend_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));

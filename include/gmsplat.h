@@ -249,7 +249,7 @@ int32_t gms_adam_step(const GmsAdamTensor *tensors /* HOST array */, int32_t cou
 #define GMS_K_MESH_FWD 7
 #define GMS_K_MESH_BWD_SPLAT 8
 #define GMS_K_MESH_BWD_FACE 9
-#define GMS_K_BLEND_TLOC 10
+#define GMS_K_BLEND_HEAD 10
 #define GMS_K_BLEND_FINALIZE 11
 #define GMS_K_LOSS_FWD 12
 #define GMS_K_LOSS_BWD 13
