@@ -297,3 +297,27 @@ def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
         h = U.hip_render(inputs, kw, need_grad=False)
         rep = U.forward_report(h, o, 48, 48)
         assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, (frame, rep)
+
+
+@pytest.mark.parametrize("env", [{"GMS_SEG_LEN": "128"}, {"GMS_SEG_LEN": "512"}, {"GMS_TRIP": "2", "GMS_TRIP_BWD": "2"},
+                                 {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}])
+def test_tuning_knobs_do_not_change_results(env):
+    """The knobs of INTEGRATION.md section 6 are read once per process: run the parity check in a child process per
+    setting (segment lengths other than the default, 2-entry trips, no XCD run interleave, synchronous binning)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, torch\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import conftest\n"
+        "import test_gpu_raster as T\n"
+        "from games_hip import synthetic as syn\n"
+        "import _util as U\n"
+        "sc, cam = syn.random_scene(6000, seed=21, scale_lo=0.01, scale_hi=0.15), syn.orbit_camera(2, width=144, height=112, radius=2.5)\n"
+        "T._check(T._inputs(sc), U.settings_kwargs(cam, torch.tensor([0.3, 0.1, 0.2])), 144, 112)\n"
+        "print('knob ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "knob ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
