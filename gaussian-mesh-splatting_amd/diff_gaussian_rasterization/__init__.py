@@ -74,8 +74,10 @@ class GaussianRasterizationSettings(NamedTuple):
     antialiasing: bool
 
 
-# (device index, W, H, P) -> instances rendered last time: lets the next call size the binning
-# buffer up-front and enqueue the whole forward without a pipeline bubble.
+# (device index, W, H, P) -> slowly decaying maximum of the instances rendered by recent calls: lets the next call
+# size the binning buffer up-front and enqueue the whole forward without a pipeline bubble.  Training visits cameras
+# in random order, so the estimate follows the heaviest recent view, not just the last one (an overflow re-runs the
+# tail of the pipeline; memory is 64 bytes per instance).
 _capacity_cache = {}
 _last_stats = {}
 
@@ -189,7 +191,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if scratch.error is not None:
                 raise scratch.error
             _lib.check(num_rendered, "gms_rasterize_forward")
-        _capacity_cache[key] = int(num_rendered)
+        _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
         _last_stats.update(num_rendered=int(num_rendered), capacity_hint=hint, P=P, width=W, height=H)
 
         ctx.raster_settings = rs
