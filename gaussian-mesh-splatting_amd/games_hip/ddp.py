@@ -12,6 +12,8 @@ first because the backward produces it last-but-largest and it dominates the wir
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Iterable, List
 
 import torch
@@ -52,19 +54,32 @@ class OverlappedGradAllReduce:
       of the reduced bucket (no copy back).
 
     `finish()` makes the compute stream wait for the collectives and applies the 1/world averaging.  Semantics are
-    identical to `allreduce_gradients` (tested with gloo, world size 2, in tests/test_ddp_cpu.py)."""
+    identical to `allreduce_gradients` (tested with gloo, world size 2, in tests/test_ddp_cpu.py).
+
+    Gradient accumulation over several `backward()` calls: run all but the last under `with reducer.no_sync():` (as
+    with torch's DistributedDataParallel) so that the collectives start once, on the accumulated gradients."""
 
     def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22):
         self.params = [p for p in params]
         self.world, self.average, self.big_numel = world, average, int(big_numel)
         self._works, self._big, self._small, self._handles = [], [], [], []
+        self._enabled = True
         if world > 1 and dist.is_initialized():
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside this context only accumulate `.grad`; no collective is started."""
+        prev, self._enabled = self._enabled, False
+        try:
+            yield
+        finally:
+            self._enabled = prev
+
     def _hook(self, p: torch.Tensor) -> None:
         g = p.grad
-        if g is None:
+        if g is None or not self._enabled:
             return
         if g.numel() >= self.big_numel and g.is_contiguous():
             self._big.append(g)

@@ -42,11 +42,20 @@ def _worker(rank, world, port, q):
         red.finish()
         red.remove()
         out2 = [p.grad.clone() for p in params2]
+        # gradient accumulation: two backward passes, collectives only on the second (accumulated) one
+        params3 = [torch.randn(s, generator=torch.Generator().manual_seed(1234)).requires_grad_(True) for s in shapes[:3]]
+        red3 = OverlappedGradAllReduce(params3, world, big_numel=200)
+        with red3.no_sync():
+            sum((p * l).sum() for p, l in zip(params3, local[:3])).backward()
+        sum((2.0 * p * l).sum() for p, l in zip(params3, local[:3])).backward()
+        red3.finish()
+        red3.remove()
+        out3 = [p.grad.clone() for p in params3]
         # camera sharding: same permutation everywhere, disjoint cover of the views within an epoch
         views = [shard_views(8, step, rank, world, seed=7) for step in range(4)]
         # numpy copies: a torch tensor would travel as a shared-memory file descriptor that dies with this process
         npy = lambda ts: [None if t is None else t.detach().numpy().copy() for t in ts]
-        q.put((rank, npy(local), npy(out), views, npy(out2)))
+        q.put((rank, npy(local), npy(out), views, npy(out2), npy(out3)))
     finally:
         dist.destroy_process_group()
 
@@ -61,7 +70,7 @@ def _run_world(world):
     try:
         res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
         tt = lambda xs: [None if x is None else torch.from_numpy(x) for x in xs]
-        res = [(r, tt(l), tt(o), v, tt(o2)) for r, l, o, v, o2 in res]
+        res = [(r, tt(l), tt(o), v, tt(o2), tt(o3)) for r, l, o, v, o2, o3 in res]
     finally:
         for p in procs:
             p.join(timeout=120)
@@ -77,10 +86,13 @@ def test_allreduce_equals_mean_of_single_view_gradients():
         res = _run_world(world)
     except Exception:          # e.g. the probed rendezvous port was taken in between: one retry
         res = _run_world(world)
-    (_, l0, o0, v0, h0), (_, l1, o1, v1, h1) = res
+    (_, l0, o0, v0, h0, a0), (_, l1, o1, v1, h1, a1) = res
     for k in range(3):
         torch.testing.assert_close(h0[k], (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(h1[k], (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-7)
+        # accumulated over two backward passes (1x + 2x), then averaged over the two ranks
+        torch.testing.assert_close(a0[k], 3 * (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(a1[k], 3 * (l0[k] + l1[k]) / 2, rtol=1e-6, atol=1e-6)
     for k in range(len(l0)):
         if k == 3:
             assert o0[k] is None and o1[k] is None
