@@ -60,12 +60,25 @@ __global__ void __launch_bounds__(BLOCK) l1_ssim_fwd_kernel(int H, int W, const 
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, plane = blockIdx.z;
     const size_t pbase = (size_t)plane * H * W;
 
-    for (int idx = tid; idx < LH * LH; idx += BLOCK) {
-        const int r = idx / LH, c = idx - r * LH;
-        const int gy = y0 + r - LR, gx = x0 + c - LR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sx[r][c] = in ? img[pbase + (size_t)gy * W + gx] : 0.f;
-        sy[r][c] = in ? gt[pbase + (size_t)gy * W + gx] : 0.f;
+    {
+        // halo tile: every global load of this thread is issued before the first LDS store (the loop would otherwise
+        // be seven dependent load -> store round trips; the block's duration is mostly this latency)
+        constexpr int NIT = (LH * LH + BLOCK - 1) / BLOCK;
+        float vx[NIT], vy[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * BLOCK;
+            const int r = idx / LH, c = idx - r * LH;
+            const int gy = y0 + r - LR, gx = x0 + c - LR;
+            const bool in = idx < LH * LH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            vx[it] = in ? img[pbase + (size_t)gy * W + gx] : 0.f;
+            vy[it] = in ? gt[pbase + (size_t)gy * W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * BLOCK;
+            if (idx < LH * LH) { const int r = idx / LH, c = idx - r * LH; sx[r][c] = vx[it]; sy[r][c] = vy[it]; }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < LH * LT; idx += BLOCK) {
@@ -146,14 +159,25 @@ __global__ void __launch_bounds__(BLOCK) l1_ssim_bwd_kernel(int H, int W, const 
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * LT, y0 = blockIdx.y * LT, plane = blockIdx.z;
     const size_t pbase = (size_t)plane * H * W;
-    for (int idx = tid; idx < LH * LH; idx += BLOCK) {
-        const int r = idx / LH, c = idx - r * LH;
-        const int gy = y0 + r - LR, gx = x0 + c - LR;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = pbase + (size_t)gy * W + gx;
-        sm[0][r][c] = in ? dmaps[o] : 0.f;
-        sm[1][r][c] = in ? dmaps[map_stride + o] : 0.f;
-        sm[2][r][c] = in ? dmaps[2 * map_stride + o] : 0.f;
+    {
+        constexpr int NIT = (LH * LH + BLOCK - 1) / BLOCK;      // all loads first, then the LDS stores (see forward)
+        float v0[NIT], v1[NIT], v2[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * BLOCK;
+            const int r = idx / LH, c = idx - r * LH;
+            const int gy = y0 + r - LR, gx = x0 + c - LR;
+            const bool in = idx < LH * LH && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            const size_t o = pbase + (size_t)gy * W + gx;
+            v0[it] = in ? dmaps[o] : 0.f;
+            v1[it] = in ? dmaps[map_stride + o] : 0.f;
+            v2[it] = in ? dmaps[2 * map_stride + o] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int idx = tid + it * BLOCK;
+            if (idx < LH * LH) { const int r = idx / LH, c = idx - r * LH; sm[0][r][c] = v0[it]; sm[1][r][c] = v1[it]; sm[2][r][c] = v2[it]; }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < LH * LT; idx += BLOCK) {
