@@ -1,0 +1,44 @@
+"""bench.py contract on the GPU box: the one-line JSON at N=1, and the multi-rank code path (two ranks sharing cuda:0
+over gloo -- RCCL itself needs one GPU per rank, the driver exercises that at round end)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline"}
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--workload", "small",
+                        "--profile-steps", "3"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and "workload" in d["config"]
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"]) / d["value"] < 0.02
+
+
+def test_two_ranks_sharing_the_gpu_run_the_distributed_step():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GMS_BENCH_SHARED_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--workload", "small", "--profile-steps", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_rank_per_step"] == 4
+    assert d["config"]["views_per_step"] == 8 and d["value"] > 0
