@@ -450,9 +450,12 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
     if (tid == 0 && host_slot) {
         uint32_t dm = 0;
         for (int w = 0; w < SCAN_THREADS / WAVE; w++) dm = max(dm, wave_deep[w]);
-        __hip_atomic_store(&host_slot[2], (int32_t)dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // deepest tile
-        __hip_atomic_store(&host_slot[0], (int32_t)tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_slot[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // two self-tagged 64-bit words {sequence number : value}: each is ONE relaxed system-scope store, so no release
+        // fence (= write-back of the XCD's dirty L2 lines) is needed to order a value before its flag
+        unsigned long long *hs = reinterpret_cast<unsigned long long *>(host_slot);
+        const unsigned long long tag = (unsigned long long)(uint32_t)seq << 32;
+        __hip_atomic_store(&hs[1], tag | dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           // deepest tile
+        __hip_atomic_store(&hs[0], tag | tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // N
     }
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
@@ -844,13 +847,13 @@ __global__ void mark_visible_kernel(int P, const float *means3D, const float *vi
     present[i] = vz > NEAR_Z ? 1 : 0;
 }
 
-// pinned, device-visible read-back slot, one per host thread: {N, sequence number of the call that wrote it}
+// pinned, device-visible read-back slot, one per host thread: two 64-bit words {call sequence number : N}, {.. : deepest tile}
 static int32_t *pinned_slot()
 {
     static thread_local int32_t *slot = nullptr;
     if (!slot) {
         if (hipHostMalloc((void **)&slot, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) slot = nullptr;
-        else { slot[0] = 0; slot[1] = 0; }
+        else { for (int k = 0; k < 16; k++) slot[k] = 0; }
     }
     return slot;
 }
@@ -867,23 +870,31 @@ static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, in
         std::chrono::steady_clock::time_point t0;
         ~Tally() { g_wait_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); g_wait_calls++; }
     } tally{t0};
+    const unsigned long long *hs = reinterpret_cast<const unsigned long long *>(slot);
+    const unsigned long long tag = (unsigned long long)(uint32_t)seq;
+    auto ready = [&]() {                       // both self-tagged words of this call have arrived
+        return (__atomic_load_n(&hs[0], __ATOMIC_ACQUIRE) >> 32) == tag && (__atomic_load_n(&hs[1], __ATOMIC_ACQUIRE) >> 32) == tag;
+    };
     for (uint32_t spins = 0;; spins++) {
-        if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) == seq) break;
+        if (ready()) break;
         __builtin_ia32_pause();
         if ((spins & 0xffffu) == 0xffffu &&
             std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
             GMS_HIP_CHECK(hipStreamSynchronize(stream));
-            if (__atomic_load_n(&slot[1], __ATOMIC_ACQUIRE) != seq) {
+            if (!ready()) {
                 set_error("tile_scan did not publish the instance count");
                 return GMS_ERR_HIP;
             }
             break;
         }
     }
-    *N = (int64_t)(uint32_t)__atomic_load_n(&slot[0], __ATOMIC_RELAXED);
+    *N = (int64_t)(uint32_t)(__atomic_load_n(&hs[0], __ATOMIC_RELAXED) & 0xffffffffull);
     return GMS_OK;
 }
-static uint32_t deepest_tile(const int32_t *slot) { return (uint32_t)__atomic_load_n(&slot[2], __ATOMIC_RELAXED); }
+static uint32_t deepest_tile(const int32_t *slot)
+{
+    return (uint32_t)(__atomic_load_n(reinterpret_cast<const unsigned long long *>(slot) + 1, __ATOMIC_RELAXED) & 0xffffffffull);
+}
 
 uint32_t seg_len()
 {
