@@ -144,6 +144,13 @@ def main():
     dev_index = 0 if shared_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    # GMS_BENCH_FORCE_DDP=1 on one GPU: a one-rank RCCL process group with the gradient all-reduce in the step (exercises
+    # the nccl code path -- communicator creation, async collectives from autograd hooks, stream waits -- without peers)
+    force_ddp = world == 1 and os.environ.get("GMS_BENCH_FORCE_DDP") == "1"
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared_gpu:
@@ -168,7 +175,7 @@ def main():
     params = model.parameters()
     inv_norm = 1.0 / (3.0 * size * size * vps)          # mean over the views of the step
     neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
-    reducer = OverlappedGradAllReduce(params, world) if world > 1 else None
+    reducer = OverlappedGradAllReduce(params, world, force=force_ddp) if (world > 1 or force_ddp) else None
 
     if args.loss == "l1_ssim":
         from games_hip.loss import l1_ssim_loss
@@ -202,7 +209,7 @@ def main():
                 p.grad = None
 
     def sync():
-        if world > 1:
+        if world > 1 or force_ddp:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -316,7 +323,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 

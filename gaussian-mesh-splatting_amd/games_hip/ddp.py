@@ -59,12 +59,14 @@ class OverlappedGradAllReduce:
     Gradient accumulation over several `backward()` calls: run all but the last under `with reducer.no_sync():` (as
     with torch's DistributedDataParallel) so that the collectives start once, on the accumulated gradients."""
 
-    def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22):
+    def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22,
+                 force: bool = False):
         self.params = [p for p in params]
         self.world, self.average, self.big_numel = world, average, int(big_numel)
         self._works, self._big, self._small, self._handles = [], [], [], []
         self._enabled = True
-        if world > 1 and dist.is_initialized():
+        # `force`: run the collectives even in a world of one (exercises the backend on a single GPU)
+        if (world > 1 or force) and dist.is_initialized():
             for p in self.params:
                 self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
 

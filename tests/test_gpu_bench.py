@@ -42,3 +42,16 @@ def test_two_ranks_sharing_the_gpu_run_the_distributed_step():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_rank_per_step"] == 4
     assert d["config"]["views_per_step"] == 8 and d["value"] > 0
+
+
+def test_one_rank_rccl_process_group_runs_the_allreduce_step():
+    """GMS_BENCH_FORCE_DDP=1: RCCL communicator, collectives started from autograd hooks, stream waits -- on one GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, GMS_BENCH_FORCE_DDP="1", MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--workload", "small",
+                        "--profile-steps", "0", "--views-per-step", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 1 and d["config"]["views_per_rank_per_step"] == 2 and d["value"] > 0
