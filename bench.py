@@ -173,9 +173,11 @@ def main():
     bg = torch.ones(3, device=device)
     pipe = PipelineParams()
     params = model.parameters()
-    inv_norm = 1.0 / (3.0 * size * size * vps)          # mean over the views of the step
+    # mean over ALL views of the step (this rank's and the other ranks'): the 1/world of the gradient average is folded
+    # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
+    inv_norm = 1.0 / (3.0 * size * size * vps * world)
     neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
-    reducer = OverlappedGradAllReduce(params, world, force=force_ddp) if (world > 1 or force_ddp) else None
+    reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp) if (world > 1 or force_ddp) else None
 
     if args.loss == "l1_ssim":
         from games_hip.loss import l1_ssim_loss
@@ -194,7 +196,7 @@ def main():
             loss = l1_ssim_loss(images[0], gt_image, 0.2)
             for im in images[1:]:
                 loss = loss + l1_ssim_loss(im, gt_image, 0.2)
-            (loss / vps if vps > 1 else loss).backward()
+            (loss / (vps * world) if vps * world > 1 else loss).backward()
         else:
             with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
                 grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
