@@ -11,7 +11,7 @@ One forward kernel, two backward kernels; autograd sees a single node.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

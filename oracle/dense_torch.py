@@ -17,7 +17,6 @@ SH (utils/sh_utils.py:57-112).  O(P*H*W) memory: small scenes only.
 """
 from __future__ import annotations
 
-import math
 
 import torch
 

@@ -5,7 +5,6 @@ import math
 import numpy as np
 import torch
 
-from games_hip import synthetic as syn
 from oracle import gs_oracle
 
 

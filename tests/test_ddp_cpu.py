@@ -4,7 +4,6 @@ Parity statement: all-reduced gradient == sum of the ranks' sin
 import os
 import socket
 
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
