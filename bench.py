@@ -302,6 +302,8 @@ def main():
             "config": {"workload": f"{args.workload}/{args.state}: UV-sphere mesh F={F} x {scene.meta['S']} splats = {P} "
                                    f"mesh-bound Gaussians, SH degree 3, {size}x{size}, orbit camera k=rank%8, white bg",
                        "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
+                       "visible_gaussians": stats.get("visible"), "deepest_tile": stats.get("deepest_tile"),
+                       "mean_instances_per_tile": round(N / max(1, ((size + 15) // 16) ** 2), 1),
                        "views_per_step": world * vps, "views_per_rank_per_step": vps,
                        "parallelism": (f"view-parallel x{world}, {vps} view(s) per rank per step, one gradient all-reduce "
                                        f"(63.6 MB) per step") if world > 1 else "single view",

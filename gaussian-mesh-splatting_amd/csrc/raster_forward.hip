@@ -862,6 +862,7 @@ static int32_t *pinned_slot()
 // is at most one forward + one backward away); after 10 s without an answer the stream is synchronised so a
 // faulted kernel surfaces as an error instead of a hang.
 static std::atomic<int64_t> g_wait_ns{0}, g_wait_calls{0};
+static thread_local uint32_t t_last_deepest = 0;     // deepest tile of this thread's most recent forward
 
 static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, int64_t *N)
 {
@@ -1065,6 +1066,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         rc = wait_for_count(slot, seq, stream, &N);
         if (rc != GMS_OK) return rc;
         deepest_seen = deepest_tile(slot);
+        t_last_deepest = deepest_seen;
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
             bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
@@ -1076,6 +1078,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         int32_t rc0 = wait_for_count(slot, seq, stream, &N);
         if (rc0 != GMS_OK) return rc0;
         deepest_seen = deepest_tile(slot);
+        t_last_deepest = deepest_seen;
         const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
@@ -1084,6 +1087,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     }
     return N;
 }
+
+extern "C" int64_t gms_last_deepest_tile(void) { return (int64_t)t_last_deepest; }
 
 extern "C" void gms_wait_stats(double *total_ms, int64_t *calls, int32_t reset)
 {

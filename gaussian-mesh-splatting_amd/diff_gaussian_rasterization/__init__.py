@@ -83,8 +83,13 @@ _last_stats = {}
 
 
 def last_stats() -> dict:
-    """Counters of the most recent forward call (num_rendered, capacity hint used, ...)."""
-    return dict(_last_stats)
+    """Counters of the most recent forward call: num_rendered (N), capacity hint used, deepest_tile (instances in the
+    deepest tile) and `visible` (Gaussians with radius > 0; computed on request: one device sync)."""
+    d = dict(_last_stats)
+    radii = d.pop("radii", None)
+    if radii is not None:
+        d["visible"] = int((radii > 0).sum())
+    return d
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -192,7 +197,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise scratch.error
             _lib.check(num_rendered, "gms_rasterize_forward")
         _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
-        _last_stats.update(num_rendered=int(num_rendered), capacity_hint=hint, P=P, width=W, height=H)
+        _last_stats.update(num_rendered=int(num_rendered), capacity_hint=hint, P=P, width=W, height=H,
+                           deepest_tile=int(lib.gms_last_deepest_tile()), radii=radii)
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)

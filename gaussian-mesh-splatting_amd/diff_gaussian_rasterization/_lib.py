@@ -85,7 +85,7 @@ EXPORTS = (
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
-    "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats",
+    "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile",
 )
 K_COUNT = 15
 
@@ -136,6 +136,7 @@ def load():
         lib.gms_l1_ssim_backward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
         lib.gms_adam_step.restype = C.c_int32
         lib.gms_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib.gms_last_deepest_tile.restype = C.c_int64
         lib.gms_wait_stats.restype = None
         lib.gms_wait_stats.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
         lib.gms_profile_enable.argtypes = [C.c_int32]

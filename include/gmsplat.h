@@ -264,6 +264,8 @@ const char *gms_profile_kernel_name(int32_t kernel_id);
 /* Host time gms_rasterize_forward spent waiting for the instance count N since the last reset (the one place the
  * host blocks on the device): near zero when the host is the bottleneck, about one step when the GPU is. */
 void gms_wait_stats(double *total_ms, int64_t *calls, int32_t reset);
+/* Instances in the deepest tile of the calling thread's most recent gms_rasterize_forward (drives the sort's pass count). */
+int64_t gms_last_deepest_tile(void);
 int32_t gms_abi_version(void);
 /* Text of the last error on the calling thread ("" if none). */
 const char *gms_last_error(void);
