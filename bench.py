@@ -102,8 +102,37 @@ def cpu_baseline(workload, state, max_seconds=12.0):
             pieces = {"k0_fwd_s": t1 - t0, "raster_fwd_s": t2 - t1, "raster_bwd_s": t3 - t2, "k0_bwd_s": t4 - t3}
         if time.time() - t_start > max_seconds:
             break
+    # north_star: "the reference's pure-PyTorch/CPU covariance-projection path timed on the host cores": the python stages the
+    # reference runs with --compute_cov3D_python / --convert_SHs_python (scene/gaussian_model.py:27-31, utils/sh_utils.py:57-112)
+    # and its only pure-PyTorch projection (utils/graphics_utils.py:22-29), restated device-agnostically in games_hip.render
+    from games_hip.render import covariance_python, eval_sh
+    torch.set_num_threads(k0_threads)
+
+    def med(fn, n=5):
+        ts = []
+        for _ in range(n):
+            t0 = time.time(); fn(); ts.append(time.time() - t0)
+        return sorted(ts)[n // 2]
+
+    sa, ra = cal[1].clone().requires_grad_(True), cal[2].clone().requires_grad_(True)
+    shs_v = cal[4].transpose(1, 2).clone().requires_grad_(True)                     # [P,3,16] as the reference views it
+    dirs = torch.nn.functional.normalize(cal[0] - cam.camera_center, dim=1)
+    ones = torch.ones(cal[0].shape[0], 1)
+
+    def cov_path():
+        covariance_python(sa, 1.0, ra).sum().backward()
+
+    def sh_path():
+        torch.clamp_min(eval_sh(3, shs_v, dirs) + 0.5, 0.0).sum().backward()
+
+    def project_path():
+        h = torch.cat([cal[0], ones], dim=1) @ cam.full_proj_transform
+        return h[:, :3] / (h[:, 3:4] + 0.0000001)
+
+    stages = {"cov3D_python_fwd_bwd_s": round(med(cov_path), 4), "sh_python_fwd_bwd_s": round(med(sh_path), 4),
+              "geom_transform_points_s": round(med(project_path), 4), "threads": k0_threads}
     t = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / t, "unit": "iters/s", "cores": oracle_threads, "kind": "port",
+    return {"pytorch_cov_project_path": stages, "value": 1.0 / t, "unit": "iters/s", "cores": oracle_threads, "kind": "port",
             "sample": f"{len(times)} full fwd+bwd iteration(s) of the same workload ({workload}/{state}, "
                       f"{sc.num_gaussians} Gaussians, {cam.image_width}x{cam.image_height}); C oracle with OpenMP "
                       f"({oracle_threads} threads, fastest of 16/32/64/128) + torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
