@@ -477,11 +477,22 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
 }
 
 // unit table, heaviest first: [all full segments | partial last segments | units of empty tiles]
-__global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count, const uint32_t *class_first, const uint32_t *offset,
-                                                           const uint32_t *mseg_first, uint4 *unit_tile, int T, uint32_t L,
-                                                           uint32_t max_units, uint2 *deep_tab, uint32_t max_deep, int sort_np)
+struct FillUnitsArgs {
+    const uint32_t *count, *class_first, *offset, *mseg_first;
+    uint4 *unit_tile;
+    uint2 *deep_tab;
+    int T, sort_np;
+    uint32_t L, max_units, max_deep;
+};
+
+__device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t *count = f.count, *class_first = f.class_first, *offset = f.offset, *mseg_first = f.mseg_first;
+    uint4 *unit_tile = f.unit_tile;
+    uint2 *deep_tab = f.deep_tab;
+    const int T = f.T, sort_np = f.sort_np;
+    const uint32_t L = f.L, max_units = f.max_units, max_deep = f.max_deep;
+    const int t = block * BLOCK + threadIdx.x;
     if (t >= T) return;
     const uint32_t c = count[t], nfull = c / L;
     uint32_t q[NSCAN];
@@ -507,10 +518,13 @@ __global__ void __launch_bounds__(BLOCK) fill_units_kernel(const uint32_t *count
 }
 
 // ------------------------------------------------------------------------------------ K3
+// The grid's extra blocks (beyond the Gaussians') write the unit table: it only depends on the tile scan, like this
+// kernel, so it rides along instead of costing a launch of its own.
 __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, int gy, const int *radii, GeomState geom,
                                                                const uint32_t *tile_offset, uint32_t *tile_cursor,
-                                                               uint64_t *keys, uint64_t capacity)
+                                                               uint64_t *keys, uint64_t capacity, unsigned emit_blocks, FillUnitsArgs fu)
 {
+    if (blockIdx.x >= emit_blocks) { fill_units(fu, (int)(blockIdx.x - emit_blocks)); return; }
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int r = i < P ? radii[i] : 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
@@ -1032,13 +1046,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     auto enqueue_tail = [&](void *bin_mem, uint64_t capacity) -> int32_t {
         BinningState bin = BinningState::carve(bin_mem, (size_t)capacity, (size_t)T, L);
         const uint32_t mu = (uint32_t)BinningState::n_units((size_t)capacity, (size_t)T, L);
-        GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
-                                                                                             img.tile_cursor, bin.keys, capacity));
+        FillUnitsArgs fu;
+        fu.count = img.tile_count; fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
+        fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.T = T; fu.sort_np = sort_np; fu.L = L; fu.max_units = mu;
+        fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
+        const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
+        GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
+                                                                                                       img.tile_cursor, bin.keys, capacity, pblocks, fu));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
-        fill_units_kernel<<<(unsigned)((T + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(img.tile_count, img.class_first, img.tile_offset, img.mseg_first,
-                                                                                     bin.unit_tile, T, L, mu, bin.deep_tab,
-                                                                                     (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T), sort_np);
-        GMS_KERNEL_CHECK(A->debug, stream, "fill_units");
         uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
         if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, sort_tmp, capacity, sort_np));
