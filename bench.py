@@ -307,6 +307,8 @@ def main():
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
                 traffic = json.load(f).get(f"{args.workload}/{args.state}", {})
+        if ktimes.get("mesh_bwd_splat", (0, 0))[1] == 0:       # K0 backward ran as one fused launch (booked as mesh_bwd_face)
+            ab["mesh_bwd_face"] += ab["mesh_bwd_splat"]
         kernels = {}
         for name, (ms, n) in ktimes.items():
             if n == 0:

@@ -135,9 +135,15 @@ __device__ __forceinline__ void barycentric(int mode, const float *raw, float al
 
 __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *alpha_out, float *xyz, float *scaling,
                                                          float *rotation, float *scaling_act, float *rotation_unit,
-                                                         float *opacity_act)
+                                                         float *opacity_act, unsigned splat_blocks)
 {
 #pragma clang fp contract(off)
+    if (blockIdx.x >= splat_blocks) {             // ride-along blocks: clear the scratch the backward will accumulate into
+        const int64_t i = ((int64_t)(blockIdx.x - splat_blocks) * BLOCK + threadIdx.x) * 4;
+        for (int k = 0; k < 4; k++)
+            if (i + k < a.prezero_count) a.prezero[i + k] = 0.f;
+        return;
+    }
     const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (p >= a.P) return;
     if (opacity_act) opacity_act[p] = 1.f / (1.f + expf(-a._opacity[p]));      // get_opacity: torch.sigmoid
@@ -169,14 +175,10 @@ __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *a
 }
 
 // ------------------------------------------------------------------ backward, per splat
-__global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
-                                                               float *dL_dalpha, float *dL_dscale, float *dL_dvertices,
-                                                               const float *dL_dopacity_act, float *dL_d_opacity)
+__device__ __forceinline__ void bwd_splat_body(const GmsMeshArgs &a, unsigned block, const float *dL_dxyz, const float *dL_dscaling,
+                                               float *dL_dalpha, float *dL_dscale, const float *dL_dopacity_act, float *dL_d_opacity)
 {
-    // the vertex gradient is accumulated with atomics by the face kernel that follows on the stream: clear it here
-    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < 3 * (int64_t)a.V; e += (int64_t)gridDim.x * BLOCK)
-        dL_dvertices[e] = 0.f;
-    const int64_t p = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t p = (int64_t)block * BLOCK + threadIdx.x;
     if (p >= a.P) return;
     if (dL_d_opacity) {                             // sigmoid backward: g * (1 - y) * y
         const float y = 1.f / (1.f + expf(-a._opacity[p]));
@@ -209,6 +211,16 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, co
         if (u > 0.f) acc += dL_dscaling[3 * p + j] * sj[j] * (a.fused_activations ? 1.f : 1.f / (u + EPS));
     }
     dL_dscale[p] = acc;
+}
+
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                               float *dL_dalpha, float *dL_dscale, float *dL_dvertices,
+                                                               const float *dL_dopacity_act, float *dL_d_opacity)
+{
+    // the vertex gradient is accumulated with atomics by the face kernel that follows on the stream: clear it here
+    for (int64_t e = (int64_t)blockIdx.x * BLOCK + threadIdx.x; e < 3 * (int64_t)a.V; e += (int64_t)gridDim.x * BLOCK)
+        dL_dvertices[e] = 0.f;
+    bwd_splat_body(a, blockIdx.x, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale, dL_dopacity_act, dL_d_opacity);
 }
 
 // ------------------------------------------------------------------ backward, per face
@@ -324,12 +336,10 @@ __device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, in
 }
 
 // few splats per face: one thread per face
-__global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
-                                                                     const float *dL_drot, float *dL_dvertices)
+__device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsigned block, const float *dL_dxyz, const float *dL_dscaling,
+                                                     const float *dL_drot, float *dL_dvertices, float *lds9, int *ldsi)
 {
-    __shared__ float lds9[4 * WAVE * 9];
-    __shared__ int ldsi[4 * WAVE * 3];
-    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    const int f = (int)(block * BLOCK + threadIdx.x);
     const bool valid = f < a.F;
     float out[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (valid) {
@@ -360,6 +370,28 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs
         const int vi = wi[fl * 3 + r / 3];
         if (vi >= 0) unsafeAtomicAdd(dL_dvertices + 3 * (size_t)vi + (r % 3), w9[e]);
     }
+}
+
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                                     const float *dL_drot, float *dL_dvertices)
+{
+    __shared__ float lds9[4 * WAVE * 9];
+    __shared__ int ldsi[4 * WAVE * 3];
+    bwd_face_thread_body(a, blockIdx.x, dL_dxyz, dL_dscaling, dL_drot, dL_dvertices, lds9, ldsi);
+}
+
+// One launch for the whole backward when the vertex gradient buffer was cleared ahead of time (by the forward's
+// ride-along blocks): the per-splat and the per-face parts are independent then and share the grid.
+__global__ void __launch_bounds__(BLOCK) mesh_bwd_fused_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
+                                                               const float *dL_drot, float *dL_dvertices, float *dL_dalpha,
+                                                               float *dL_dscale, const float *dL_dopacity_act, float *dL_d_opacity,
+                                                               unsigned face_blocks)
+{
+    __shared__ float lds9[4 * WAVE * 9];
+    __shared__ int ldsi[4 * WAVE * 3];
+    // face blocks first: they are the longer ones
+    if (blockIdx.x < face_blocks) bwd_face_thread_body(a, blockIdx.x, dL_dxyz, dL_dscaling, dL_drot, dL_dvertices, lds9, ldsi);
+    else bwd_splat_body(a, blockIdx.x - face_blocks, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale, dL_dopacity_act, dL_d_opacity);
 }
 
 // many splats per face (FLAME-like, 50-100): one wave per face, lanes stride over the splats
@@ -420,7 +452,9 @@ extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *al
     if (A->P == 0) return GMS_OK;
     if (!xyz || !scaling || !rotation) { set_error("mesh forward: null output"); return GMS_ERR_INVALID_ARGUMENT; }
     if (opacity_act && !A->_opacity) { set_error("mesh forward: opacity_activated requested without _opacity"); return GMS_ERR_INVALID_ARGUMENT; }
-    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation, scaling_act, rotation_unit, opacity_act));
+    const unsigned sblocks = (unsigned)((A->P + BLOCK - 1) / BLOCK);
+    const unsigned zblocks = (A->prezero && A->prezero_count > 0) ? (unsigned)((A->prezero_count + 4 * BLOCK - 1) / (4 * BLOCK)) : 0u;
+    GMS_LAUNCH(GMS_K_MESH_FWD, stream, mesh_fwd_kernel<<<sblocks + zblocks, BLOCK, 0, stream>>>(*A, alpha, xyz, scaling, rotation, scaling_act, rotation_unit, opacity_act, sblocks));
     GMS_KERNEL_CHECK(0, stream, "mesh_fwd");
     return GMS_OK;
 }
@@ -442,6 +476,14 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
     if (dL_d_opacity && (!A->_opacity || !dL_dopacity_act)) {
         set_error("mesh backward: dL_d_opacity requested without _opacity / dL_dopacity_activated");
         return GMS_ERR_INVALID_ARGUMENT;
+    }
+    const double avg_splats = (double)A->P / (double)(A->F > 0 ? A->F : 1);
+    if (A->vertex_grad_prezeroed && avg_splats < 16.0) {
+        const unsigned fb = (unsigned)((A->F + BLOCK - 1) / BLOCK), sb = (unsigned)((A->P + BLOCK - 1) / BLOCK);
+        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_fused_kernel<<<fb + sb, BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices,
+                                                                                                   dL_dalpha, dL_dscale, dL_dopacity_act, dL_d_opacity, fb));
+        GMS_KERNEL_CHECK(0, stream, "mesh_bwd_fused");
+        return GMS_OK;
     }
     GMS_LAUNCH(GMS_K_MESH_BWD_SPLAT, stream, mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale, dL_dvertices, dL_dopacity_act, dL_d_opacity));
     GMS_KERNEL_CHECK(0, stream, "mesh_bwd_splat");

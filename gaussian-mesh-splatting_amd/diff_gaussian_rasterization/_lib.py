@@ -62,6 +62,7 @@ class MeshArgs(C.Structure):
         ("F", C.c_int32), ("V", C.c_int32), ("P", C.c_int64), ("splats_per_face", C.c_int32), ("alpha_mode", C.c_int32),
         ("vertices", C.c_void_p), ("faces", C.c_void_p), ("face_splat_offset", C.c_void_p), ("splat_face", C.c_void_p),
         ("_alpha", C.c_void_p), ("_scale", C.c_void_p), ("fused_activations", C.c_int32), ("_opacity", C.c_void_p),
+        ("prezero", C.c_void_p), ("prezero_count", C.c_int64), ("vertex_grad_prezeroed", C.c_int32),
     ]
 
 

@@ -27,13 +27,15 @@ def _c(t, dtype):
 
 
 def _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused=False,
-               _opacity=None):
+               _opacity=None, prezero=None, prezeroed=False):
     P = _alpha.shape[0] if _alpha.dim() == 2 else _alpha.shape[0] * _alpha.shape[1]
     return _lib.MeshArgs(F=int(faces.shape[0]), V=int(vertices.shape[0]), P=int(P), splats_per_face=int(splats_per_face),
                          alpha_mode=int(mode), vertices=_lib.ptr(vertices), faces=_lib.ptr(faces),
                          face_splat_offset=_lib.ptr(face_splat_offset), splat_face=_lib.ptr(splat_face),
                          _alpha=_lib.ptr(_alpha), _scale=_lib.ptr(_scale), fused_activations=int(bool(fused)),
-                         _opacity=_lib.ptr(_opacity))
+                         _opacity=_lib.ptr(_opacity), prezero=_lib.ptr(prezero),
+                         prezero_count=int(prezero.numel()) if prezero is not None else 0,
+                         vertex_grad_prezeroed=int(bool(prezeroed)))
 
 
 class _MeshToGaussians(torch.autograd.Function):
@@ -64,7 +66,11 @@ class _MeshToGaussians(torch.autograd.Function):
         scaling_act = torch.empty((P, 3), dtype=torch.float32, device=device) if fused else None
         rotation_unit = torch.empty((P, 4), dtype=torch.float32, device=device) if fused else None
         opacity_act = torch.empty_like(_opacity) if _opacity is not None else None
-        a = _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused, _opacity)
+        # the vertex-gradient buffer of the coming backward is cleared by spare blocks of this launch, so the backward's
+        # per-splat and per-face parts can share one launch (a second backward through the same graph allocates afresh)
+        ctx.vertex_grad = torch.empty_like(vertices) if ctx.needs_input_grad[0] else None
+        a = _mesh_args(vertices, faces, _alpha, _scale, mode, splats_per_face, face_splat_offset, splat_face, fused, _opacity,
+                       prezero=ctx.vertex_grad)
         with _lib.on_device(device):
             stream = _lib.stream_ptr(device)
             _lib.check(lib.gms_mesh_to_gaussians_forward(C.byref(a), _lib.ptr(alpha), _lib.ptr(xyz), _lib.ptr(scaling),
@@ -100,14 +106,17 @@ class _MeshToGaussians(torch.autograd.Function):
             return torch.zeros(shape, dtype=torch.float32, device=device) if g is None else _c(g, torch.float32)
 
         g_xyz, g_scaling, g_rotation = grad_or_zero(g_xyz, (P, 3)), grad_or_zero(g_scaling, (P, 3)), grad_or_zero(g_rotation, (P, 4))
-        d_vertices = torch.empty_like(vertices)      # cleared by the first backward kernel
+        d_vertices, prezeroed = ctx.vertex_grad, ctx.vertex_grad is not None
+        ctx.vertex_grad = None                       # handed to autograd: never reused
+        if d_vertices is None:
+            d_vertices = torch.empty_like(vertices)  # cleared by the first backward kernel
         d_alpha = torch.empty_like(_alpha)
         d_scale = torch.empty_like(_scale)
         d_opacity = None
         if _opacity is not None and g_opacity_act is not None:
             g_opacity_act = _c(g_opacity_act, torch.float32)
             d_opacity = torch.empty_like(_opacity)
-        a = _mesh_args(vertices, faces, _alpha, _scale, ctx.mode, ctx.spf, fso, sf, ctx.fused, _opacity)
+        a = _mesh_args(vertices, faces, _alpha, _scale, ctx.mode, ctx.spf, fso, sf, ctx.fused, _opacity, prezeroed=prezeroed)
         with _lib.on_device(device):
             stream = _lib.stream_ptr(device)
             _lib.check(lib.gms_mesh_to_gaussians_backward(C.byref(a), _lib.ptr(g_xyz), _lib.ptr(g_scaling), _lib.ptr(g_rotation),

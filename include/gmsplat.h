@@ -167,6 +167,11 @@ typedef struct GmsMeshArgs {
                                      the gradients w.r.t. THOSE instead of (scaling, rotation) */
     const float *_opacity;        /* [P] raw opacities or NULL: fuses get_opacity = sigmoid(_opacity)
                                      (scene/gaussian_model.py:113-115) and its backward into the same kernels */
+    float *prezero;               /* forward only, optional: scratch of prezero_count floats that extra blocks of the
+                                     forward launch clear (the [V,3] buffer the backward will accumulate into) */
+    int64_t prezero_count;
+    int32_t vertex_grad_prezeroed;/* backward only: dL_dvertices is already all zero (cleared through `prezero`), so the
+                                     per-splat and per-face parts run as ONE launch */
 } GmsMeshArgs;
 
 /* Outputs: alpha [P,3] (normalised barycentrics, kept because save_ply / the animated renderer

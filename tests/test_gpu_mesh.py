@@ -236,3 +236,27 @@ def test_checkpoint_roundtrip_in_the_reference_file_format(tmp_path):
     cam = syn.orbit_camera(0, width=96, height=96).to("cuda")
     bg = torch.ones(3, device="cuda")
     assert torch.equal(render(cam, m, PipelineParams(), bg)["render"], render(cam, m2, PipelineParams(), bg)["render"])
+
+
+def test_backward_twice_through_one_graph_and_without_vertex_gradient():
+    """The forward pre-clears the vertex-gradient buffer for ONE backward (fused single launch); a second backward through
+    a retained graph takes the two-launch path with its own clearing, and a graph without vertex gradient needs none."""
+    from games_hip.mesh_op import mesh_to_gaussians
+    scene = syn.mesh_scene("tiny")
+    f = scene.faces.cuda()
+    v = scene.vertices.cuda().requires_grad_(True)
+    a, s = scene._alpha.cuda().requires_grad_(True), scene._scale.cuda().requires_grad_(True)
+    out = mesh_to_gaussians(v, f, a, s, "relu", fused_activations=True)
+    loss = out[1].sum() + (out[4] * out[4]).sum() + out[5][:, 1].sum()
+    loss.backward(retain_graph=True)
+    g1 = [t.grad.clone() for t in (v, a, s)]
+    for t in (v, a, s):
+        t.grad = None
+    loss.backward()
+    for x, y in zip(g1, (v.grad, a.grad, s.grad)):
+        _close(y, x, rtol=1e-5)
+    v2 = scene.vertices.cuda()                       # no gradient for the vertices
+    a2 = scene._alpha.cuda().requires_grad_(True)
+    out2 = mesh_to_gaussians(v2, f, a2, scene._scale.cuda(), "relu", fused_activations=True)
+    (out2[1].sum() + (out2[4] * out2[4]).sum() + out2[5][:, 1].sum()).backward()
+    _close(a2.grad, g1[1], rtol=1e-5)

@@ -11,7 +11,7 @@ t = json.load(open(src))
 names = {"preprocess_fwd": ["preprocess_fwd"], "tile_scan": ["tile_scan"], "emit_instances": ["emit_instances"],
          "tile_sort": ["tile_presort", "tile_merge"], "blend_head": ["blend_head"], "blend_fwd": ["blend_fwd"],
          "blend_finalize": ["blend_finalize"], "blend_bwd": ["blend_bwd"], "preprocess_bwd": ["preprocess_bwd"],
-         "mesh_fwd": ["mesh_fwd"], "mesh_bwd_splat": ["mesh_bwd_splat"], "mesh_bwd_face": ["mesh_bwd_face_thread", "mesh_bwd_face_wave"]}
+         "mesh_fwd": ["mesh_fwd"], "mesh_bwd_splat": ["mesh_bwd_splat"], "mesh_bwd_face": ["mesh_bwd_face_thread", "mesh_bwd_face_wave", "mesh_bwd_fused"]}
 out = {}
 for k, srcs in names.items():
     vals = [t[s]["hbm_bytes_corrected"] for s in srcs if s in t]
