@@ -62,7 +62,9 @@ def eval_sh(deg, sh, dirs):
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    # the reference writes `torch.zeros_like(...) + 0` and retain_grad() (renderer/gaussian_renderer/__init__.py:33-37); a
+    # leaf tensor receives `.grad` just the same and saves the extra elementwise kernel
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
     try:
         screenspace_points.retain_grad()
     except Exception:
