@@ -53,6 +53,7 @@ struct PreArgs {
     float mod, tanx, tany;
     int aa;
     int *radii;
+    uint8_t *visible;        // optional: radii > 0 as bytes
     GeomState geom;
     uint32_t *tile_count;
 };
@@ -307,6 +308,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     }
 
     if (valid && !vis) a.radii[i] = 0;
+    if (valid && a.visible) a.visible[i] = vis ? 1 : 0;
     if (vis) {
         // half extents of the bounding box of {alpha >= 1/255}: |dx| <= sqrt(2 * cov_xx * ln(255 op)).
         // ln is inflated by 1e-3 so float rounding can never cull a pair the per-pixel test would keep.
@@ -1001,7 +1003,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.means3D = A->means3D; pa.shs = A->shs; pa.shs_rest = A->shs_rest; pa.colors = A->colors_precomp; pa.opac = A->opacities;
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
-    pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.geom = geom; pa.tile_count = img.tile_count;
+    pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.visible = A->visible; pa.geom = geom; pa.tile_count = img.tile_count;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
     const bool split = A->shs_rest != nullptr;
     const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&

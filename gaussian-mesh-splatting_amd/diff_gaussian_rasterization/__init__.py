@@ -123,14 +123,15 @@ class _Scratch:
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                        raster_settings):
+                        raster_settings, visible_out=None):
+    """`visible_out`: optional bool[P] tensor the preprocess kernel fills with radii > 0 (saves the elementwise pass)."""
     if isinstance(sh, SplitSH):
         if sh.dc.shape[1] == 1 and sh.rest.shape[1] == 15 and sh.dc.is_cuda:
             return _RasterizeGaussians.apply(means3D, means2D, sh.dc, colors_precomp, opacities, scales, rotations,
-                                             cov3Ds_precomp, raster_settings, sh.rest)
+                                             cov3Ds_precomp, raster_settings, sh.rest, visible_out)
         sh = sh.full()
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings, None)
+                                     cov3Ds_precomp, raster_settings, None, visible_out)
 
 
 _accum_cache = {}      # (device index, stream, P) -> zeroed [P,16] gradient-record buffer
@@ -139,7 +140,7 @@ _accum_cache = {}      # (device index, stream, P) -> zeroed [P,16] gradient-rec
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, sh_rest=None):
+                raster_settings, sh_rest=None, visible_out=None):
         rs = raster_settings
         lib = _lib.load()
         _lib.require_gpu(means3D, rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos)
@@ -187,6 +188,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             tan_fovx=float(rs.tanfovx), tan_fovy=float(rs.tanfovy), prefiltered=int(bool(rs.prefiltered)),
             antialiasing=int(bool(rs.antialiasing)), debug=int(bool(rs.debug)),
             out_color=_lib.ptr(color), out_invdepth=_lib.ptr(invdepth), radii=_lib.ptr(radii),
+            visible=_lib.ptr(visible_out) if visible_out is not None else None,
             geom_alloc=scratch.geom_cb, geom_ctx=None, binning_alloc=scratch.binning_cb, binning_ctx=None,
             image_alloc=scratch.image_cb, image_ctx=None, binning_capacity_hint=hint)
         with _lib.on_device(device):
@@ -270,7 +272,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _accum_cache.clear()
         _accum_cache[accum_key] = grad_accum
         return (dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drot,
-                dL_dcov3D, None, dL_dsh_rest)
+                dL_dcov3D, None, dL_dsh_rest, None)
 
 
 class GaussianRasterizer(nn.Module):
@@ -307,4 +309,9 @@ class GaussianRasterizer(nn.Module):
         scales = e if scales is None else scales
         rotations = e if rotations is None else rotations
         cov3D_precomp = e if cov3D_precomp is None else cov3D_precomp
-        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs)
+        # `visibility_filter` (radii > 0, renderer/gaussian_renderer/__init__.py:108) comes out of the preprocess kernel;
+        # callers that know about it read `rasterizer.visibility_filter` instead of launching the comparison
+        vis = torch.empty((means3D.shape[0],), dtype=torch.bool, device=means3D.device) if means3D.is_cuda and means3D.shape[0] else None
+        out = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, rs, vis)
+        self.visibility_filter = vis
+        return out

@@ -33,7 +33,7 @@ class RasterForwardArgs(C.Structure):
         ("geom_alloc", ALLOC_FN), ("geom_ctx", C.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
         ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
-        ("binning_capacity_hint", C.c_int64),
+        ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p),
     ]
 
 

@@ -98,7 +98,9 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     rendered_image, radii, depth_image = rasterizer(
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+    visible = getattr(rasterizer, "visibility_filter", None)      # written by the preprocess kernel (this drop-in only)
+    return {"render": rendered_image, "viewspace_points": screenspace_points,
+            "visibility_filter": visible if visible is not None else radii > 0,
             "radii": radii, "depth": depth_image}
 
 

@@ -97,6 +97,9 @@ typedef struct GmsRasterForwardArgs {
      * instances and the whole pipeline is enqueued before the host looks at the real count
      * (no pipeline bubble); on overflow the tail of the pipeline is re-run after a resize. */
     int64_t binning_capacity_hint;
+    /* Optional output [P] bytes: 1 where radii > 0 -- the `visibility_filter` of renderer/gaussian_renderer/__init__.py:108
+     * written by the preprocess kernel instead of a separate elementwise pass.  NULL = not wanted. */
+    uint8_t *visible;
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */

@@ -321,3 +321,17 @@ def test_tuning_knobs_do_not_change_results(env):
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0 and "knob ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_visibility_filter_from_the_preprocess_kernel_equals_radii_positive():
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    sc, cam = syn.random_scene(5000, seed=31, scale_lo=0.01, scale_hi=0.1), syn.orbit_camera(3, width=128, height=96, radius=1.2)
+    kw = U.settings_kwargs(cam, torch.zeros(3))
+    for k in ("bg", "viewmatrix", "projmatrix", "campos"):
+        kw[k] = kw[k].cuda().float()
+    r = GaussianRasterizer(GaussianRasterizationSettings(**kw))
+    t = {k: v.cuda().float() for k, v in _inputs(sc).items()}
+    _, radii, _ = r(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["shs"],
+                    scales=t["scales"], rotations=t["rotations"])
+    assert r.visibility_filter.dtype == torch.bool and torch.equal(r.visibility_filter, radii > 0)
+    assert 0 < int(r.visibility_filter.sum()) < 5000          # the close camera culls some Gaussians behind the near plane
