@@ -60,7 +60,8 @@ struct GeomState {
 struct ImageState {
     float *final_T;         // [H*W]
     uint32_t *n_contrib;    // [H*W]
-    uint32_t *tile_count;   // [T]     instances per tile (atomically counted in preprocess)
+    uint32_t *tile_count;   // [T]     instances per tile (atomically counted in preprocess); points at a library-owned,
+                            //          always-zero-between-frames buffer (the slot carved here is unused)
     uint32_t *tile_cursor;  // [T]     emit cursors
     uint32_t *tile_offset;  // [T+1]   exclusive scan of tile_count; tile_offset[T] = N
     uint32_t *unit_first;   // [T+1]   exclusive scan of segments per tile; unit_first[T] = #units

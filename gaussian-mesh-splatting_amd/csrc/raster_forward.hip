@@ -27,6 +27,7 @@
 
 #include "gms_blend.h"
 #include <atomic>
+#include <vector>
 #include <chrono>
 
 #include "gms_common.h"
@@ -395,7 +396,7 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
 
 // One block of 1024 threads: NSCAN exclusive scans over the tiles at once.  Each wave scans its 64 per-thread
 // sums with DPP-free shuffles, the 16 wave totals are scanned by the first wave: two block barriers in all.
-__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t *count, uint32_t *offset, uint32_t *cursor,
+__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count, uint32_t *offset, uint32_t *cursor,
                                                                  uint32_t *unit_first, uint32_t *mseg_first,
                                                                  uint32_t *class_first, int T, uint32_t L, int32_t *host_slot,
                                                                  int32_t seq, int sort_np)
@@ -467,6 +468,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
         for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + t] = run[3 + k];
         class_first[NCLASS * (T + 1) + t] = run[9];
         cursor[t] = 0;
+        count[t] = 0;          // the counter array is library-owned and stays all zero between frames (no memset per frame)
 #pragma unroll
         for (int k = 0; k < NSCAN; k++) run[k] += q[k];
     }
@@ -480,7 +482,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(const uint32_t 
 
 // unit table, heaviest first: [all full segments | partial last segments | units of empty tiles]
 struct FillUnitsArgs {
-    const uint32_t *count, *class_first, *offset, *mseg_first;
+    const uint32_t *class_first, *offset, *mseg_first;
     uint4 *unit_tile;
     uint2 *deep_tab;
     int T, sort_np;
@@ -489,14 +491,14 @@ struct FillUnitsArgs {
 
 __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
 {
-    const uint32_t *count = f.count, *class_first = f.class_first, *offset = f.offset, *mseg_first = f.mseg_first;
+    const uint32_t *class_first = f.class_first, *offset = f.offset, *mseg_first = f.mseg_first;
     uint4 *unit_tile = f.unit_tile;
     uint2 *deep_tab = f.deep_tab;
     const int T = f.T, sort_np = f.sort_np;
     const uint32_t L = f.L, max_units = f.max_units, max_deep = f.max_deep;
     const int t = block * BLOCK + threadIdx.x;
     if (t >= T) return;
-    const uint32_t c = count[t], nfull = c / L;
+    const uint32_t c = offset[t + 1] - offset[t], nfull = c / L;      // (the counters were cleared by the scan)
     uint32_t q[NSCAN];
     tile_terms(c, L, q, sort_np);
     const uint32_t nseg = q[1];                          // units of this tile (>= 1)
@@ -996,7 +998,23 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     GeomState geom = GeomState::carve(geom_mem, (size_t)P);
     ImageState img = ImageState::carve(img_mem, (size_t)W, (size_t)H);
 
-    GMS_HIP_CHECK(hipMemsetAsync(img.tile_count, 0, (size_t)T * 4, stream));
+    // Per-tile instance counters: a library-owned buffer per (host thread, stream) that is all zero between frames --
+    // tile_scan clears each counter after reading it -- so a frame starts without a memset.  `dirty` covers a frame that
+    // failed between the preprocess launch and the scan launch.
+    struct Counters { hipStream_t stream; uint32_t *buf; size_t cap; bool dirty; };
+    static thread_local std::vector<Counters> t_counters;
+    Counters *ctr = nullptr;
+    for (auto &c : t_counters) if (c.stream == stream) ctr = &c;
+    if (!ctr) { t_counters.push_back({stream, nullptr, 0, true}); ctr = &t_counters.back(); }
+    if (ctr->cap < (size_t)T) {
+        if (ctr->buf) (void)hipFree(ctr->buf);
+        ctr->buf = nullptr; ctr->cap = 0;
+        GMS_HIP_CHECK(hipMalloc((void **)&ctr->buf, (size_t)T * 4));
+        ctr->cap = (size_t)T; ctr->dirty = true;
+    }
+    if (ctr->dirty) GMS_HIP_CHECK(hipMemsetAsync(ctr->buf, 0, ctr->cap * 4, stream));
+    ctr->dirty = true;                              // until this frame's scan has been enqueued
+    img.tile_count = ctr->buf;
 
     PreArgs pa;
     pa.P = P; pa.D = A->D; pa.M = A->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
@@ -1040,6 +1058,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
                                                                                    img.unit_first, img.mseg_first, img.class_first, T, L,
                                                                                    slot, seq, sort_np));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
+    ctr->dirty = false;
 
     BlendFwdOut bo;
     bo.rec = geom.rec; bo.bg = A->background; bo.final_T = img.final_T; bo.n_contrib = img.n_contrib;
@@ -1049,7 +1068,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         BinningState bin = BinningState::carve(bin_mem, (size_t)capacity, (size_t)T, L);
         const uint32_t mu = (uint32_t)BinningState::n_units((size_t)capacity, (size_t)T, L);
         FillUnitsArgs fu;
-        fu.count = img.tile_count; fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
+        fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
         fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.T = T; fu.sort_np = sort_np; fu.L = L; fu.max_units = mu;
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
