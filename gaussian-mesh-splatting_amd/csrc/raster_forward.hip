@@ -806,10 +806,35 @@ __global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_o
     while (np2 < n) np2 <<= 1;
     const uint64_t INF = ~0ull;
 
-    if (cls == SORT_LDS) {                        // runs of SORT_RUN keys are sorted: merge levels only
-        const int m = (int)np2;
+    if (cls == SORT_LDS) {
+        // The runs of SORT_RUN keys are sorted: merge them level by level inside LDS with merge path -- every thread
+        // finds the co-rank of its K consecutive outputs by binary search, merges them into registers, and the level
+        // is written back after a barrier (no second buffer).  ~30 dependent LDS reads per level instead of the
+        // 11-13 compare-exchange sub-stages of a bitonic merge level.
+        const int m = (int)np2;                   // 2048, 4096 or 8192: runs padded with +inf
         for (int i = tid; i < m; i += THREADS) s[i] = i < n ? g[i] : INF;
-        lds_bitonic<THREADS>(s, m, 2 * SORT_RUN, 0, true, tid);
+        __syncthreads();
+        const int K = m / THREADS;                // 2, 4 or 8 outputs per thread
+        for (int w = SORT_RUN; w < m; w <<= 1) {
+            const int o = tid * K;
+            const int base = (o / (2 * w)) * (2 * w);
+            const uint64_t *LA = s + base, *LB = s + base + w;
+            const int lo = o - base;
+            int ia = co_rank(lo, LA, w, LB, w), ib = lo - ia;
+            uint64_t out[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (k < K) {
+                    const bool takeA = ib >= w || (ia < w && LA[ia] < LB[ib]);
+                    out[k] = takeA ? LA[ia++] : LB[ib++];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (k < K) s[o + k] = out[k];
+            __syncthreads();
+        }
         for (int i = tid; i < n; i += THREADS) g[i] = s[i];
         return;
     }
