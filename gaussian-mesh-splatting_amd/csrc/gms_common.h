@@ -66,14 +66,14 @@ struct ImageState {
     uint32_t *tile_offset;  // [T+1]   exclusive scan of tile_count; tile_offset[T] = N
     uint32_t *unit_first;   // [T+1]   exclusive scan of segments per tile; unit_first[T] = #units
     uint32_t *mseg_first;   // [T+1]   exclusive scan of segments of multi-segment tiles only
-    uint32_t *class_first;  // [7][T+1] exclusive scans per dispatch class (full, 4 partial size classes, empty) and of the
-                            //          1024-key sort chunks of the tiles deeper than 8192 keys (row 6)
+    uint32_t *class_first;  // [8][T+1] exclusive scans per dispatch class (full, 4 partial size classes, empty), of the
+                            //          1024-key sort runs of every tile (row 6) and of the tiles with more than one run (row 7)
     uint32_t *tile_dead;    // [T]     all pixels of the tile finished within the first few segments
     static __host__ __device__ size_t bytes(size_t W, size_t H)
     {
         size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + 3 * align_up((T + 1) * 4, 256) +
-               align_up(7 * (T + 1) * 4, 256) + align_up(T * 4, 256);
+               align_up(8 * (T + 1) * 4, 256) + align_up(T * 4, 256);
     }
     static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
     {
@@ -87,7 +87,7 @@ struct ImageState {
         s.tile_offset = (uint32_t *)p; p += align_up((T + 1) * 4, 256);
         s.unit_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
         s.mseg_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
-        s.class_first = (uint32_t *)p; p += align_up(7 * (T + 1) * 4, 256);
+        s.class_first = (uint32_t *)p; p += align_up(8 * (T + 1) * 4, 256);
         s.tile_dead = (uint32_t *)p;
         return s;
     }
@@ -99,14 +99,16 @@ struct BinningState {
     uint64_t *keys;        // [N]  (depth_bits << 32) | gaussian id ; sorted in place per tile segment
     uint4 *unit_tile;      // [T + N/L + 1][2] unit records {tile, seg, nseg, slot0 | tile_beg, tile_end, -, -}, heaviest first
     float *seg_state;      // [2N/L + 2][7][256]
-    uint2 *deep_tab;       // [N/512 + T + 2] (tile, 1024-key chunk) of every sort chunk of the tiles merged by merge-path passes
+    uint2 *deep_tab;       // [N/1024 + T + 2] (tile, run): every 1024-key sort run / merge chunk of every tile with >= 2 keys
+    uint32_t *multi_tab;   // [N/1024 + 2] tiles with more than one run (they need merging)
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
-    static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 512 + T + 2; }
+    static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 1024 + T + 2; }
+    static __host__ __device__ size_t n_multi(size_t N) { return N / 1024 + 2; }
     static __host__ __device__ size_t bytes(size_t N, size_t T, size_t L)
     {
         return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 32, 256) +
-               align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256);
+               align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256) + align_up(n_multi(N) * 4, 256);
     }
     static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
     {
@@ -115,7 +117,8 @@ struct BinningState {
         b.keys = (uint64_t *)p;      p += align_up((N > 0 ? N : 1) * 8, 256);
         b.unit_tile = (uint4 *)p;    p += align_up(n_units(N, T, L) * 32, 256);
         b.seg_state = (float *)p;    p += align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
-        b.deep_tab = (uint2 *)p;
+        b.deep_tab = (uint2 *)p;     p += align_up(n_deep(N, T) * 8, 256);
+        b.multi_tab = (uint32_t *)p;
         return b;
     }
 };

@@ -373,7 +373,7 @@ constexpr int SORT_RUNS_PER_TILE = 8;
 constexpr int SORT_BIG_CHUNK = SORT_RUN * SORT_RUNS_PER_TILE;    // 8192 keys = 64 KiB LDS
 constexpr int MP_CHUNK = 1024;                                   // output keys per merge-path block
 
-constexpr int NSCAN = 10;
+constexpr int NSCAN = 11;
 constexpr int NCLASS = 6;     // dispatch classes: full | partial >=3/4 L | >=1/2 L | >=1/4 L | < 1/4 L | empty
 constexpr int SCAN_THREADS = 1024;
 
@@ -389,9 +389,9 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
     t[6] = (r * 2 < L && r * 4 >= L) ? 1u : 0u;
     t[7] = (r * 4 < L && r != 0) ? 1u : 0u;
     t[8] = c == 0 ? 1u : 0u;
-    // merge-path sort chunks: of the tiles deeper than one LDS merge holds, or -- when passes are launched anyway --
-    // of every tile with more than one presorted run
-    t[9] = c > (uint32_t)(sort_np > 0 ? SORT_RUN : SORT_BIG_CHUNK) ? (c + MP_CHUNK - 1) / MP_CHUNK : 0u;
+    t[9] = c > 1 ? (c + MP_CHUNK - 1) / MP_CHUNK : 0u;      // 1024-key sort runs (= merge-path chunks) of the tile
+    t[10] = c > (uint32_t)SORT_RUN ? 1u : 0u;               // tile needs merging
+    (void)sort_np;
 }
 
 // One block of 1024 threads: NSCAN exclusive scans over the tiles at once.  Each wave scans its 64 per-thread
@@ -467,6 +467,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
 #pragma unroll
         for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + t] = run[3 + k];
         class_first[NCLASS * (T + 1) + t] = run[9];
+        class_first[(NCLASS + 1) * (T + 1) + t] = run[10];
         cursor[t] = 0;
         count[t] = 0;          // the counter array is library-owned and stays all zero between frames (no memset per frame)
 #pragma unroll
@@ -477,6 +478,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
 #pragma unroll
         for (int k = 0; k < NCLASS; k++) class_first[k * (T + 1) + T] = tot[3 + k];
         class_first[NCLASS * (T + 1) + T] = tot[9];
+        class_first[(NCLASS + 1) * (T + 1) + T] = tot[10];
     }
 }
 
@@ -485,8 +487,9 @@ struct FillUnitsArgs {
     const uint32_t *class_first, *offset, *mseg_first;
     uint4 *unit_tile;
     uint2 *deep_tab;
+    uint32_t *multi_tab;
     int T, sort_np;
-    uint32_t L, max_units, max_deep;
+    uint32_t L, max_units, max_deep, max_multi;
 };
 
 __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
@@ -512,6 +515,7 @@ __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
     };
     for (uint32_t j = 0, d = class_first[NCLASS * (T + 1) + t]; j < q[9]; j++, d++)
         if (d < max_deep) deep_tab[d] = make_uint2((uint32_t)t, j);
+    if (q[10]) { const uint32_t d = class_first[(NCLASS + 1) * (T + 1) + t]; if (d < f.max_multi) f.multi_tab[d] = (uint32_t)t; }
     uint32_t u = class_first[t];
     for (uint32_t s = 0; s < nfull; s++, u++) put(u, s);
     uint32_t base = class_first[T];                     // all full units come first
@@ -683,31 +687,31 @@ __device__ __forceinline__ int sort_class(uint64_t n, int passes_launched, int &
     return n <= (uint64_t)SORT_BIG_CHUNK ? SORT_LDS : SORT_FALLBACK;
 }
 
-__global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
+__global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, const uint32_t *run_total, const uint2 *run_tab,
+                                                           uint32_t max_runs, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
                                                            int passes_launched)
 {
     __shared__ uint64_t s[SORT_RUN];
     const int tid = threadIdx.x;
-    const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
+    if (blockIdx.x >= run_total[0] || blockIdx.x >= max_runs) return;      // one block per (tile, run) of the run table
+    const uint2 tr = run_tab[blockIdx.x];
+    const uint64_t beg = tile_offset[tr.x], end64 = tile_offset[tr.x + 1];
     if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
     const long n = (long)(end64 - beg);
-    if (n <= 1) return;
     int q;
     const int cls = sort_class((uint64_t)n, passes_launched, q);
     if (cls == SORT_FALLBACK) return;
     uint64_t *dst_base = (cls == SORT_MERGEPATH && (q & 1)) ? tmp : keys;
-    for (long c0 = (long)blockIdx.y * SORT_RUN; c0 < n; c0 += (long)SORT_RUNS_PER_TILE * SORT_RUN) {
-        const int cn = (int)min((long)SORT_RUN, n - c0);
-        const uint64_t *g = keys + beg + c0;
-        uint64_t *d = dst_base + beg + c0;
-        if (cn <= 1) { if (cn == 1 && tid == 0) d[0] = g[0]; continue; }
-        int m = 2;
-        while (m < cn) m <<= 1;
-        __syncthreads();
-        for (int i = tid; i < m; i += 256) s[i] = i < cn ? g[i] : ~0ull;
-        lds_bitonic<256>(s, m, 2, 0, true, tid);
-        for (int i = tid; i < cn; i += 256) d[i] = s[i];
-    }
+    const long c0 = (long)tr.y * SORT_RUN;
+    const int cn = (int)min((long)SORT_RUN, n - c0);
+    const uint64_t *g = keys + beg + c0;
+    uint64_t *d = dst_base + beg + c0;
+    if (cn <= 1) { if (cn == 1 && tid == 0) d[0] = g[0]; return; }
+    int m = 2;
+    while (m < cn) m <<= 1;
+    for (int i = tid; i < m; i += 256) s[i] = i < cn ? g[i] : ~0ull;
+    lds_bitonic<256>(s, m, 2, 0, true, tid);
+    for (int i = tid; i < cn; i += 256) d[i] = s[i];
 }
 
 // number of elements taken from A among the first o outputs of merge(A, B) (keys are unique)
@@ -790,12 +794,15 @@ __global__ void __launch_bounds__(256) tile_mergepath_kernel(const uint32_t *til
     }
 }
 
-__global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, uint64_t *keys, uint64_t capacity, int passes_launched)
+__global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, const uint32_t *multi_total, const uint32_t *multi_tab,
+                                                          uint32_t max_multi, uint64_t *keys, uint64_t capacity, int passes_launched)
 {
     constexpr int THREADS = 1024, CHUNK = SORT_BIG_CHUNK;
     __shared__ uint64_t s[CHUNK];
     const int tid = threadIdx.x;
-    const uint64_t beg = tile_offset[blockIdx.x], end64 = tile_offset[blockIdx.x + 1];
+    if (blockIdx.x >= multi_total[0] || blockIdx.x >= max_multi) return;     // one block per tile with more than one run
+    const uint32_t tile = multi_tab[blockIdx.x];
+    const uint64_t beg = tile_offset[tile], end64 = tile_offset[tile + 1];
     if (end64 > capacity) return;
     const long n = (long)(end64 - beg);
     int q;
@@ -1094,7 +1101,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         const uint32_t mu = (uint32_t)BinningState::n_units((size_t)capacity, (size_t)T, L);
         FillUnitsArgs fu;
         fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
-        fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.T = T; fu.sort_np = sort_np; fu.L = L; fu.max_units = mu;
+        fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.multi_tab = bin.multi_tab;
+        fu.max_multi = (uint32_t)BinningState::n_multi((size_t)capacity); fu.T = T; fu.sort_np = sort_np; fu.L = L; fu.max_units = mu;
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
@@ -1102,12 +1110,17 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
         if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<dim3((unsigned)T, SORT_RUNS_PER_TILE), 256, 0, stream>>>(img.tile_offset, bin.keys, sort_tmp, capacity, sort_np));
         const uint32_t max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
+        const uint32_t max_multi = (uint32_t)BinningState::n_multi((size_t)capacity);
+        const uint32_t *run_total = img.class_first + NCLASS * ((size_t)T + 1) + T;
+        const uint32_t *multi_total = img.class_first + (NCLASS + 1) * ((size_t)T + 1) + T;
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
+                                                                                             sort_tmp, capacity, sort_np));
         for (int pass = 0; pass < sort_np; pass++)
-            GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, img.class_first + NCLASS * ((size_t)T + 1) + T, bin.deep_tab,
-                                                                                                   max_deep, bin.keys, sort_tmp, capacity, sort_np, pass));
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<(unsigned)T, 1024, 0, stream>>>(img.tile_offset, bin.keys, capacity, sort_np));
+            GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
+                                                                                                   sort_tmp, capacity, sort_np, pass));
+        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<max_multi, 1024, 0, stream>>>(img.tile_offset, multi_total, bin.multi_tab, max_multi, bin.keys,
+                                                                                             capacity, sort_np));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
