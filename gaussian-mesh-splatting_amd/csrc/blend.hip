@@ -495,7 +495,7 @@ int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
         if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
     }
     const bool deep = g.capacity > 2ull * g.seg_len * (uint64_t)g.T;
-    const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
+    const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 4; }
     auto head = trip == 2 ? blend_head_kernel<2> : blend_head_kernel<4>;
@@ -526,7 +526,7 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
         if (!g_dbg_buf) (void)hipMalloc((void **)&g_dbg_buf, DBG_BYTES);
         if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
     }
-    const unsigned blocks = 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX));
+    const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 4; }
     const bool invd = a.has_invd && a.dL_dinvd;

@@ -418,7 +418,8 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
         b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.accum = A->grad_accum;
         b.has_invd = A->dL_dout_invdepth != nullptr;
-        const uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
+        uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
+        if (A->num_units > 0 && (uint64_t)A->num_units < mu) mu = (uint32_t)A->num_units;      // exact count from the forward
         int32_t rc = launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
     }

@@ -457,6 +457,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
         // fence (= write-back of the XCD's dirty L2 lines) is needed to order a value before its flag
         unsigned long long *hs = reinterpret_cast<unsigned long long *>(host_slot);
         const unsigned long long tag = (unsigned long long)(uint32_t)seq << 32;
+        __hip_atomic_store(&hs[2], tag | tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // work units
         __hip_atomic_store(&hs[1], tag | dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           // deepest tile
         __hip_atomic_store(&hs[0], tag | tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // N
     }
@@ -897,7 +898,8 @@ __global__ void mark_visible_kernel(int P, const float *means3D, const float *vi
     present[i] = vz > NEAR_Z ? 1 : 0;
 }
 
-// pinned, device-visible read-back slot, one per host thread: two 64-bit words {call sequence number : N}, {.. : deepest tile}
+// pinned, device-visible read-back slot, one per host thread: 64-bit words {call sequence number : N}, {.. : deepest tile},
+// {.. : work units}
 static int32_t *pinned_slot()
 {
     static thread_local int32_t *slot = nullptr;
@@ -924,7 +926,8 @@ static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, in
     const unsigned long long *hs = reinterpret_cast<const unsigned long long *>(slot);
     const unsigned long long tag = (unsigned long long)(uint32_t)seq;
     auto ready = [&]() {                       // both self-tagged words of this call have arrived
-        return (__atomic_load_n(&hs[0], __ATOMIC_ACQUIRE) >> 32) == tag && (__atomic_load_n(&hs[1], __ATOMIC_ACQUIRE) >> 32) == tag;
+        return (__atomic_load_n(&hs[0], __ATOMIC_ACQUIRE) >> 32) == tag && (__atomic_load_n(&hs[1], __ATOMIC_ACQUIRE) >> 32) == tag &&
+               (__atomic_load_n(&hs[2], __ATOMIC_ACQUIRE) >> 32) == tag;
     };
     for (uint32_t spins = 0;; spins++) {
         if (ready()) break;
@@ -941,6 +944,10 @@ static int32_t wait_for_count(int32_t *slot, int32_t seq, hipStream_t stream, in
     }
     *N = (int64_t)(uint32_t)(__atomic_load_n(&hs[0], __ATOMIC_RELAXED) & 0xffffffffull);
     return GMS_OK;
+}
+static uint32_t unit_count(const int32_t *slot)
+{
+    return (uint32_t)(__atomic_load_n(reinterpret_cast<const unsigned long long *>(slot) + 2, __ATOMIC_RELAXED) & 0xffffffffull);
 }
 static uint32_t deepest_tile(const int32_t *slot)
 {
@@ -1096,9 +1103,18 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     bo.rec = geom.rec; bo.bg = A->background; bo.final_T = img.final_T; bo.n_contrib = img.n_contrib;
     bo.out_color = A->out_color; bo.out_invdepth = A->out_invdepth;
 
-    auto enqueue_tail = [&](void *bin_mem, uint64_t capacity) -> int32_t {
+    // Blend launches are sized from the previous frame's unit count (+25 %) instead of the table's capacity (thousands of
+    // blocks that only find out they have nothing to do); a frame with more units than launched is re-run like a
+    // capacity overflow.
+    static thread_local uint32_t units_seen = 0;      // this frame's count once known
+    static thread_local uint32_t units_hint = 0;      // slowly decaying maximum over recent frames (views differ)
+    uint32_t launched_units = 0;
+    auto enqueue_tail = [&](void *bin_mem, uint64_t capacity, bool exact_fit) -> int32_t {
         BinningState bin = BinningState::carve(bin_mem, (size_t)capacity, (size_t)T, L);
         const uint32_t mu = (uint32_t)BinningState::n_units((size_t)capacity, (size_t)T, L);
+        uint32_t mu_launch = mu;
+        if (!exact_fit && units_hint > 0) mu_launch = min(mu, units_hint + units_hint / 4u + 64u);
+        launched_units = blend_grid_units(mu_launch);
         FillUnitsArgs fu;
         fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
         fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.multi_tab = bin.multi_tab;
@@ -1126,7 +1142,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
-        return launch_blend_forward(g, bo, mu, A->debug != 0, stream);
+        return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);
     };
 
     int64_t N;
@@ -1135,17 +1151,24 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
-        int32_t rc = enqueue_tail(bin_mem, cap);
+        int32_t rc = enqueue_tail(bin_mem, cap, false);
         if (rc != GMS_OK) return rc;
         rc = wait_for_count(slot, seq, stream, &N);
         if (rc != GMS_OK) return rc;
         deepest_seen = deepest_tile(slot);
         t_last_deepest = deepest_seen;
+        units_seen = unit_count(slot);
+        units_hint = max(units_seen, (uint32_t)(0.97 * units_hint));
+        if ((uint64_t)N <= cap && units_seen > launched_units) {       // enough memory, too few blocks: same buffers, full-size launches
+            GMS_HIP_CHECK(hipMemsetAsync(img.tile_cursor, 0, (size_t)T * 4, stream));
+            rc = enqueue_tail(bin_mem, cap, true);
+            if (rc != GMS_OK) return rc;
+        }
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
             bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
             GMS_HIP_CHECK(hipMemsetAsync(img.tile_cursor, 0, (size_t)T * 4, stream));
-            rc = enqueue_tail(bin_mem, (uint64_t)N);
+            rc = enqueue_tail(bin_mem, (uint64_t)N, true);
             if (rc != GMS_OK) return rc;
         }
     } else {
@@ -1153,12 +1176,15 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (rc0 != GMS_OK) return rc0;
         deepest_seen = deepest_tile(slot);
         t_last_deepest = deepest_seen;
+        units_seen = unit_count(slot);
+        units_hint = max(units_seen, (uint32_t)(0.97 * units_hint));
         const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
         void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
-        int32_t rc = enqueue_tail(bin_mem, cap);
+        int32_t rc = enqueue_tail(bin_mem, cap, true);         // N is exact here, so the table-sized launch is tight
         if (rc != GMS_OK) return rc;
     }
+    if (A->num_units_out) *A->num_units_out = (int64_t)units_seen;
     return N;
 }
 

@@ -179,6 +179,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             prev = _capacity_cache.get(key)
             if prev is not None:
                 hint = int(prev * 1.25) + 4096
+        num_units = C.c_int64(0)
         a = _lib.RasterForwardArgs(
             P=P, D=int(rs.sh_degree), M=M, width=W, height=H,
             background=_lib.ptr(bg), means3D=_lib.ptr(means3D), shs=_lib.ptr(sh), shs_rest=_lib.ptr(sh_rest),
@@ -189,6 +190,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             antialiasing=int(bool(rs.antialiasing)), debug=int(bool(rs.debug)),
             out_color=_lib.ptr(color), out_invdepth=_lib.ptr(invdepth), radii=_lib.ptr(radii),
             visible=_lib.ptr(visible_out) if visible_out is not None else None,
+            num_units_out=C.addressof(num_units),
             geom_alloc=scratch.geom_cb, geom_ctx=None, binning_alloc=scratch.binning_cb, binning_ctx=None,
             image_alloc=scratch.image_cb, image_ctx=None, binning_capacity_hint=hint)
         with _lib.on_device(device):
@@ -204,6 +206,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)
+        ctx.num_units = int(num_units.value)
         ctx.binning_capacity = hint if (hint > 0 and num_rendered <= hint) else max(int(num_rendered), 1)
         ctx.M = M
         empty = torch.empty(0, device=device)
@@ -263,7 +266,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             dL_dcolors=_lib.ptr(dL_dcolors), dL_dmeans3D=_lib.ptr(dL_dmeans3D),
             dL_dcov3D=_lib.ptr(dL_dcov3D), dL_dsh=_lib.ptr(dL_dsh), dL_dsh_rest=_lib.ptr(dL_dsh_rest),
             dL_dscales=_lib.ptr(dL_dscales),
-            dL_drotations=_lib.ptr(dL_drot), grad_accum_rezero=1)
+            dL_drotations=_lib.ptr(dL_drot), grad_accum_rezero=1, num_units=ctx.num_units)
         if P > 0:
             with _lib.on_device(device):
                 _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")

@@ -33,7 +33,7 @@ class RasterForwardArgs(C.Structure):
         ("geom_alloc", ALLOC_FN), ("geom_ctx", C.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
         ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
-        ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p),
+        ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p), ("num_units_out", C.c_void_p),
     ]
 
 
@@ -53,7 +53,7 @@ class RasterBackwardArgs(C.Structure):
         ("grad_accum", C.c_void_p),
         ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
         ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
-        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("grad_accum_rezero", C.c_int32),
+        ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("grad_accum_rezero", C.c_int32), ("num_units", C.c_int64),
     ]
 
 

@@ -100,6 +100,9 @@ typedef struct GmsRasterForwardArgs {
     /* Optional output [P] bytes: 1 where radii > 0 -- the `visibility_filter` of renderer/gaussian_renderer/__init__.py:108
      * written by the preprocess kernel instead of a separate elementwise pass.  NULL = not wanted. */
     uint8_t *visible;
+    /* Optional HOST pointer: receives the number of (tile, segment) work units of this frame; pass it back to
+     * gms_rasterize_backward (num_units) so its launch is sized exactly.  NULL = not wanted. */
+    int64_t *num_units_out;
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */
@@ -141,6 +144,8 @@ typedef struct GmsRasterBackwardArgs {
     /* 1: the call leaves grad_accum all zero again (the consuming kernel clears each record it read), so a caller
      * that keeps the buffer per (device, stream, P) never pays a 64*P-byte memset per backward; 0: left dirty. */
     int32_t grad_accum_rezero;
+    /* work units reported by the forward (num_units_out), or 0: the backward launch is then sized from binning_capacity */
+    int64_t num_units;
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);
