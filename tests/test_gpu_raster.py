@@ -335,3 +335,26 @@ def test_visibility_filter_from_the_preprocess_kernel_equals_radii_positive():
                     scales=t["scales"], rotations=t["rotations"])
     assert r.visibility_filter.dtype == torch.bool and torch.equal(r.visibility_filter, radii > 0)
     assert 0 < int(r.visibility_filter.sum()) < 5000          # the close camera culls some Gaussians behind the near plane
+
+
+def test_unit_count_overflow_reruns_with_full_size_launches():
+    """The forward sizes its blend launches from a decaying maximum of recent frames' unit counts.  After many tiny frames
+    that estimate has decayed, so a large frame on the capacity-hint path has more units than blocks were launched for:
+    it must be re-run transparently and still match the oracle (image and gradients)."""
+    big, cam = syn.random_scene(6000, seed=41, scale_lo=0.01, scale_hi=0.12), syn.orbit_camera(1, width=416, height=400, radius=2.5)   # 650 tiles > the 512-unit launch granule
+    kw = U.settings_kwargs(cam, torch.tensor([0.2, 0.3, 0.1]))
+    inputs = _inputs(big)
+    o = U.oracle_render(inputs, kw)
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
+    o = U.oracle_render(inputs, kw, gc, None)
+    U.hip_render(inputs, kw, need_grad=False)                         # first call: exact sizes, sets the capacity hint for this shape
+    tiny, tcam = syn.random_scene(8, seed=2), syn.orbit_camera(0, width=16, height=16)
+    tkw = U.settings_kwargs(tcam, torch.zeros(3))
+    tin = _inputs(tiny)
+    for _ in range(160):                                              # 0.97^160 < 1 %: the unit estimate is down to the tiny frames'
+        U.hip_render(tin, tkw, need_grad=False)
+    h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
+    rep = U.forward_report(h, o, 416, 400)
+    assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, rep
+    for k, v in U.grad_report(h["grads"], o["grads"], q=0.999).items():
+        assert v["q_rel"] <= GRAD_REL, (k, v)
