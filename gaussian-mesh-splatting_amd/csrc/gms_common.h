@@ -206,6 +206,15 @@ __device__ __forceinline__ void wave_reduce10x2(float *a, float *b, float &y0a, 
     y0a = dpp_add<0x4E>(y0a); y0b = dpp_add<0x4E>(y0b); y1a = dpp_add<0x4E>(y1a); y1b = dpp_add<0x4E>(y1b);
 }
 
+// ordering point for LDS data that only ONE wave touches (its own rows / its own sort span): LDS operations of a wave
+// execute in order, so no block barrier -- and no waiting for the block's other waves -- is needed
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // Tile rectangle of a splat: identical code in preprocess (count) and emit, so both agree.

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();      // the rows are this wave's own
     } else if (use_sh) {
         if (vec_ok) {
             if (__any(vis)) {
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
         } else if (vis) {
             for (int k = 0; k < nb * 3; k++) wl[lane * SH_PITCH_B + k] = a.shs[(size_t)i * rowf + k];
         }
-        __syncthreads();
+        wave_sync();      // the rows are this wave's own
     }
 
     float dmean[3] = {0.f, 0.f, 0.f};
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     if (use_sh && split) {
         for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < 12; q++)
             *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-        __syncthreads();
+        wave_sync();      // the rows are this wave's own
         if (rows > 0) {
             for (int e = lane; e < rows * 3; e += WAVE) a.dL_dsh[(size_t)g0 * 3 + e] = wl[(e / 3) * SH_PITCH_B + (e % 3)];
             float *dp = a.dL_dsh_rest + (size_t)g0 * RESTF;
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
             const int rowq = rowf / 4;
             for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < rowq; q++)
                 *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-            __syncthreads();
+            wave_sync();      // the rows are this wave's own
             if (rows > 0) {
                 float4 *dst = reinterpret_cast<float4 *>(a.dL_dsh + (size_t)g0 * rowf);
                 for (int idx = lane; idx < rows * rowq; idx += WAVE) {

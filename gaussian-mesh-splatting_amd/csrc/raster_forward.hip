@@ -266,7 +266,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
                 }
             }
         }
-        __syncthreads();
+        wave_sync();                               // the rows are this wave's own
         if (vis) {
             float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
             float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         } else if (vis) {   // generic storage width (M != 16): plain per-lane loads into the lane's row
             for (int k = 0; k < nb * 3; k++) wl[lane * SH_PITCH + k] = a.shs[(size_t)i * rowf + k];
         }
-        __syncthreads();
+        wave_sync();
         if (vis) {
             float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
             float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
@@ -611,12 +611,6 @@ __device__ __forceinline__ void ce(uint64_t &x, uint64_t &y)
     if (x > y) { uint64_t t = x; x = y; y = t; }
 }
 
-__device__ __forceinline__ void wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 constexpr int WAVE_SPAN = 128;   // keys covered by one wave's 64 compare-exchanges
 
