@@ -362,7 +362,7 @@ __device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsig
     for (int k = 0; k < 9; k++) w9[lane * 9 + k] = out[k];
 #pragma unroll
     for (int k = 0; k < 3; k++) wi[lane * 3 + k] = valid ? (int)a.faces[3 * (size_t)f + k] : -1;
-    __syncthreads();
+    wave_sync();                                   // w9 / wi are this wave's own
 #pragma unroll
     for (int j = 0; j < 9; j++) {
         const int e = j * WAVE + lane;          // e = face_in_wave * 9 + vertex * 3 + component
