@@ -138,12 +138,20 @@ def cpu_baseline(workload, state, max_seconds=12.0):
                       f"({oracle_threads} threads, fastest of 16/32/64/128) + torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
 
 
-def main():
+BASELINE_METRIC = "train iters/s (fwd+bwd raster) @800×800, 300k Gaussians; HBM GB/s vs roofline"
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-op/s (MI355X_MICROARCH.md)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks (one GPU each).  Without a launcher (WORLD_SIZE unset) and N > 1, bench.py starts the N ranks "
+                         "itself through torch.distributed.run on 127.0.0.1")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2_hotdog_like")
+    ap.add_argument("--workload", default=None,
+                    help="default: c2_hotdog_like (gs_mesh, BASELINE configs[1]/[2]) on one GPU, c4_ficus_like (gs_multi_mesh, "
+                         "BASELINE configs[3]: 8 views sharded one per GPU) on several")
     ap.add_argument("--state", default="trained", choices=["trained", "init"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
@@ -153,15 +161,59 @@ def main():
     ap.add_argument("--loss", default="dense_grad", choices=["dense_grad", "l1_ssim"],
                     help="dense_grad: the headline step of SURVEY 8(d), dL/dcolor = (image-0.5)/(3HW); l1_ssim: the reference's "
                          "training loss (train.py:106-107) through the fused HIP L1+SSIM kernels against a synthetic target")
-    ap.add_argument("--views-per-step", type=int, default=0,
-                    help="views each rank renders (fwd+bwd) per step, their gradients accumulated before the ONE all-reduce of the "
-                         "step; default 1 on one GPU, 4 on several (global batch = 4 x world views: 63.6 MB of gradients cross "
-                         "xGMI once per four views instead of once per view); 1 reproduces the un-amortised collective")
+    ap.add_argument("--views-per-step", type=int, default=1,
+                    help="views each rank renders (fwd+bwd) per step, gradients accumulated before the ONE all-reduce of the step. "
+                         "The headline is 1 at every N (config 4: one view per GPU per step); on several GPUs the 4-view amortised "
+                         "figure is measured too and reported under `amortised`")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
                          "the scene, and with it the work per step, stays fixed")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU, RCCL) through torch.distributed.run.
+    On a box with fewer than N GPUs (the 1-GPU test box) the ranks share cuda:0 over gloo -- flagged in the JSON."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env["GMS_BENCH_SHARED_GPU"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(workload, state, device):
+    """(model, size, description dict).  c4_* / multi_* workloads are gs_multi_mesh, everything else gs_mesh."""
+    from games_hip import synthetic as syn
+    from games_hip.model import HipGaussianMeshModel, HipGaussianMultiMeshModel
+    if workload in syn.MULTI_MESH_CONFIGS:
+        scenes = syn.multi_mesh_scenes(workload, state=state)
+        model = HipGaussianMultiMeshModel.from_scenes(scenes, device)
+        F = sum(int(s.faces.shape[0]) for s in scenes)
+        P = sum(s.num_gaussians for s in scenes)
+        desc = {"model": "gs_multi_mesh", "gaussians": P, "faces": F, "meshes": [[int(s.faces.shape[0]), s.meta["S"]] for s in scenes],
+                "text": f"{workload}/{state}: {len(scenes)} UV-sphere meshes (faces x splats: "
+                        + ", ".join(f"{int(s.faces.shape[0])}x{s.meta['S']}" for s in scenes) + f") = {P} mesh-bound Gaussians"}
+        return model, scenes[0].meta["image"], desc
+    scene = syn.mesh_scene(workload, state=state)
+    model = HipGaussianMeshModel.from_scene(scene, device)
+    F, P = int(scene.faces.shape[0]), scene.num_gaussians
+    desc = {"model": "gs_mesh", "gaussians": P, "faces": F,
+            "text": f"{workload}/{state}: UV-sphere mesh F={F} x {scene.meta['S']} splats = {P} mesh-bound Gaussians"}
+    return model, scene.meta["image"], desc
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and os.environ.get("GMS_BENCH_FORCE_DDP") != "1":
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -176,37 +228,32 @@ def main():
     # GMS_BENCH_FORCE_DDP=1 on one GPU: a one-rank RCCL process group with the gradient all-reduce in the step (exercises
     # the nccl code path -- communicator creation, async collectives from autograd hooks, stream waits -- without peers)
     force_ddp = world == 1 and os.environ.get("GMS_BENCH_FORCE_DDP") == "1"
+    backend = None
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
+        backend = "nccl"
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "gloo" if shared_gpu else "nccl"
         if shared_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+    distributed = world > 1 or force_ddp
 
     from diff_gaussian_rasterization import _lib, last_stats
     from games_hip import synthetic as syn
     from games_hip.ddp import OverlappedGradAllReduce
-    from games_hip.model import HipGaussianMeshModel
     from games_hip.render import PipelineParams, render
 
-    scene = syn.mesh_scene(args.workload, state=args.state)
-    size = scene.meta["image"]
-    model = HipGaussianMeshModel.from_scene(scene, device)
-    vps = args.views_per_step if args.views_per_step > 0 else (1 if world == 1 else 4)
-    cams = [syn.orbit_camera((rank * vps + v) % 8, width=size, height=size).to(device) for v in range(vps)]
-    cam = cams[0]
+    workload = args.workload or ("c2_hotdog_like" if world == 1 else "c4_ficus_like")
+    model, size, desc = build_model(workload, args.state, device)
     bg = torch.ones(3, device=device)
     pipe = PipelineParams()
     params = model.parameters()
-    # mean over ALL views of the step (this rank's and the other ranks'): the 1/world of the gradient average is folded
-    # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
-    inv_norm = 1.0 / (3.0 * size * size * vps * world)
-    neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
-    reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp) if (world > 1 or force_ddp) else None
+    all_cams = [syn.orbit_camera(k, width=size, height=size).to(device) for k in range(8)]
 
     if args.loss == "l1_ssim":
         from games_hip.loss import l1_ssim_loss
@@ -217,76 +264,129 @@ def main():
         model.training_setup(vertices_lr=1e-12, alpha_lr=1e-12, feature_lr=1e-12, opacity_lr=1e-12, scaling_lr=1e-12,
                              fused=args.optimizer == "fused_adam")
 
-    def step():
-        model.update_alpha()                             # once per step: the parameters are the same for all its views
-        model.prepare_scaling_rot()
-        images = [render(c, model, pipe, bg)["render"] for c in cams]
-        if args.loss == "l1_ssim":
-            loss = l1_ssim_loss(images[0], gt_image, 0.2)
-            for im in images[1:]:
-                loss = loss + l1_ssim_loss(im, gt_image, 0.2)
-            (loss / (vps * world) if vps * world > 1 else loss).backward()
-        else:
-            with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
-                grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
-            torch.autograd.backward(images, grads)
-        if reducer is not None:
-            reducer.finish()      # collectives were started from autograd hooks during backward
-        if args.optimizer != "none":
-            model.optimizer.step()
-            model.optimizer.zero_grad(set_to_none=True)
-        else:
-            for p in params:
-                p.grad = None
+    def make_step(vps, reduce_grads):
+        """One step = K0 forward (once: the parameters are the same for all its views) + vps x (render fwd + bwd) on this rank's
+        views + [reduce_grads] ONE gradient all-reduce.  Rank r renders cameras (r*vps + v) % 8 (config 4: 8 views)."""
+        cams = [all_cams[(rank * vps + v) % 8] for v in range(vps)]
+        # mean over ALL views of the step (this rank's and the other ranks'): the 1/world of the gradient average is folded
+        # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
+        inv_norm = 1.0 / (3.0 * size * size * vps * world)
+        neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
+        reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp) if (reduce_grads and distributed) else None
+
+        def step():
+            model.update_alpha()
+            model.prepare_scaling_rot()
+            images = [render(c, model, pipe, bg)["render"] for c in cams]
+            if args.loss == "l1_ssim":
+                loss = l1_ssim_loss(images[0], gt_image, 0.2)
+                for im in images[1:]:
+                    loss = loss + l1_ssim_loss(im, gt_image, 0.2)
+                (loss / (vps * world) if vps * world > 1 else loss).backward()
+            else:
+                with torch.no_grad():                        # SURVEY 8(d): dL/dcolor = (image - 0.5) / (3HW), dense
+                    grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
+                torch.autograd.backward(images, grads)
+            if reducer is not None:
+                reducer.finish()      # collectives were started from autograd hooks during backward
+            if args.optimizer != "none":
+                model.optimizer.step()
+                model.optimizer.zero_grad(set_to_none=True)
+            else:
+                for p in params:
+                    p.grad = None
+        return step, reducer
 
     def sync():
-        if world > 1 or force_ddp:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    def timed(step, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(warmup):
+            step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
     if args.mode == "animate":
         from games_hip.render import render_animated
+        cam = all_cams[rank % 8]
         frame = [0]
+        verts = torch.cat(list(model.vertices)) if isinstance(model.vertices, (list, tuple)) else model.vertices
+        faces = model._hip_topology()[0] if isinstance(model.faces, (list, tuple)) else model.faces
 
         def animate_step():
             with torch.no_grad():
                 t = 0.05 * frame[0]
                 frame[0] += 1
-                new_v = model.vertices * (1.0 + 0.05 * math.sin(t))           # scripts/render_time_animated.py:68-87 style
-                render_animated(None, new_v[model.faces], cam, model, pipe, bg)
-        for _ in range(args.warmup):
-            animate_step()
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            animate_step()
-        sync()
-        el = time.perf_counter() - t0
+                new_v = verts * (1.0 + 0.05 * math.sin(t))           # scripts/render_time_animated.py:68-87 style
+                render_animated(None, new_v[faces], cam, model, pipe, bg)
+        el = timed(animate_step, args.steps, args.warmup)
         if rank == 0:
             print(json.dumps({"metric": "renders/s (fwd only, per-frame vertex animation + fused face->Gaussian + raster)",
                               "value": round(world * args.steps / el, 2), "unit": "renders/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 4),
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{args.workload}/{args.state} animate, {scene.num_gaussians} Gaussians, {size}x{size}"}}), flush=True)
-        if world > 1:
+                              "config": {"workload": f"{desc['text']}, animate, {size}x{size}"}}), flush=True)
+        if distributed:
             dist.destroy_process_group()
         return
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    vps = max(1, args.views_per_step)
+    step, reducer = make_step(vps, True)
+    elapsed = timed(step, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * vps * args.steps / elapsed
     stats = last_stats()
+
+    # ---- several ranks: what the collective costs, measured in the same job
+    extra = {}
+    if distributed:
+        ones = torch.ones(1, device=device)
+        dist.all_reduce(ones)
+        extra["ranks_seen"] = int(ones.item())
+        extra["backend"] = backend + ("/shared-gpu (test path: every rank on cuda:0)" if shared_gpu else "/RCCL over xGMI" if backend == "nccl" else "")
+        if reducer is not None:
+            reducer.remove()
+        # (a) the same step without the gradient exchange (= N independent replicas): the per-GPU rate the weak-scaling
+        #     efficiency is measured against, same workload, same job
+        s_nc, _ = make_step(vps, False)
+        el_nc = timed(s_nc, args.steps, 2)
+        extra["no_comm"] = {"value": round(world * vps * args.steps / el_nc, 2), "ms_per_step": round(1000 * el_nc / args.steps, 4),
+                            "note": "same step without the gradient all-reduce (independent replicas)"}
+        extra["efficiency_vs_no_comm"] = round(el_nc / elapsed, 4)
+        # (b) four views per rank per step, one all-reduce per step ("fewer, larger collectives"): the amortised figure
+        if vps == 1:
+            s_am, r_am = make_step(4, True)
+            el_am = timed(s_am, max(1, args.steps // 2), 2)
+            extra["amortised"] = {"views_per_rank_per_step": 4, "value": round(world * 4 * max(1, args.steps // 2) / el_am, 2),
+                                  "ms_per_step": round(1000 * el_am / max(1, args.steps // 2), 4)}
+            r_am.remove()
+        # (c) the collectives alone on gradient-sized buffers (one large + one flat bucket, as the reducer issues them)
+        big = [torch.zeros_like(p) for p in params if p.numel() >= (1 << 22)]
+        small_n = sum(p.numel() for p in params if p.numel() < (1 << 22))
+        flat = torch.zeros(max(small_n, 1), device=device)
+        sync()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            works = [dist.all_reduce(b, async_op=True) for b in big] + [dist.all_reduce(flat, async_op=True)]
+            for w in works:
+                w.wait()
+        sync()
+        extra["allreduce_ms"] = round(1000 * (time.perf_counter() - t0) / reps, 4)
+        extra["allreduce_bytes"] = 4 * (sum(b.numel() for b in big) + flat.numel())
+        step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)
     lib = _lib.load()
@@ -299,14 +399,15 @@ def main():
     ktimes = _lib.kernel_times()
 
     if rank == 0:
-        P, F = scene.num_gaussians, scene.faces.shape[0]
+        P, F = desc["gaussians"], desc["faces"]
         N = int(stats.get("num_rendered", 0))
         ab = algorithmic_bytes(P, N, F, size, size)
-        traffic = {}
+        pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                traffic = json.load(f).get(f"{args.workload}/{args.state}", {})
+                pmc = json.load(f).get(f"{workload}/{args.state}", {})
+        sq = pmc.get("_sq", {})
         if ktimes.get("mesh_bwd_splat", (0, 0))[1] == 0:       # K0 backward ran as one fused launch (booked as mesh_bwd_face)
             ab["mesh_bwd_face"] += ab["mesh_bwd_splat"]
         kernels = {}
@@ -317,7 +418,11 @@ def main():
             gbs = ab[name] / (avg_us * 1e-6) / 1e9
             kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
                              "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
-                             "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": traffic.get(name)}
+                             "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": pmc.get(name)}
+            if name in sq and sq[name].get("SQ_INSTS_VALU"):
+                lane_ops = sq[name]["SQ_INSTS_VALU"] * 64.0
+                kernels[name]["valu_wave_insts"] = sq[name]["SQ_INSTS_VALU"]
+                kernels[name]["valu_issue_frac"] = round(lane_ops / (avg_us * 1e-6) / 1e12 / VALU_PEAK_TLANEOPS, 4)
         if not kernels:     # --profile-steps 0: no per-kernel timing requested
             kernels = {"(not profiled)": {"avg_us": 0.0, "launches_per_step": 0, "algorithmic_bytes": 0, "achieved_GBps": 0.0,
                                           "frac_of_8TBps": 0.0, "traffic": None}}
@@ -325,40 +430,59 @@ def main():
         kd = kernels[dom]
         sum_kernel_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels.values())
         whole_bytes = vps * (877 * P + 156 * N + 48 * size * size) + 152 * P + 72 * F      # K0 runs once per step
+        interactions = stats.get("interactions")
+        roofline = {"kernel": dom, "avg_launch_us": kd["avg_us"]}
+        if dom.startswith("blend"):
+            # the compositing kernels have no dense contraction and gather 48-byte records out of L2: they are bound by VALU
+            # issue, not by HBM.  achieved = vector lane-operations per second (SQ_INSTS_VALU x 64 lanes from the committed
+            # rocprofv3 --pmc pass of this workload / the HIP-event duration measured here); peak = 256 CU x 4 SIMD-32 x 2.4 GHz
+            vi = kd.get("valu_wave_insts")
+            ach = vi * 64.0 / (kd["avg_us"] * 1e-6) / 1e12 if vi else None
+            pairs = sq.get(dom, {}).get("active_pairs")
+            roofline.update({"bound": "valu", "achieved": round(ach, 2) if ach else None, "peak": round(VALU_PEAK_TLANEOPS, 1),
+                             "unit": "Tlane-op/s", "frac": round(ach / VALU_PEAK_TLANEOPS, 4) if ach else None,
+                             "traffic": kd["traffic"], "interactions_sum_n_contrib": interactions,
+                             "active_lane_frac": sq.get(dom, {}).get("active_lane_frac"), "active_pairs": pairs,
+                             "hbm": {"achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": kd["frac_of_8TBps"],
+                                     "algorithmic_bytes": kd["algorithmic_bytes"], "traffic": kd["traffic"]},
+                             "note": "VALU wave-instruction counts come from profiles/pmc_traffic.json (separate --pmc pass, same "
+                                     "workload); HBM-bound kernels are listed under `kernels` with their own fractions"})
+        else:
+            roofline.update({"bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                             "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"]})
+        std = workload in ("c2_hotdog_like", "c4_ficus_like") and size == 800
         out = {
-            "metric": "train iters/s (fwd+bwd raster) @800x800, 300k Gaussians; HBM GB/s vs roofline",
+            "metric": BASELINE_METRIC if std else f"train iters/s (fwd+bwd raster) @{size}×{size}, {round(P / 1000)}k Gaussians; HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}/{args.state}: UV-sphere mesh F={F} x {scene.meta['S']} splats = {P} "
-                                   f"mesh-bound Gaussians, SH degree 3, {size}x{size}, orbit camera k=rank%8, white bg",
-                       "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
+            "config": {"workload": f"{desc['text']}, SH degree 3, {size}x{size}, orbit camera k=(rank*views+v)%8, white bg",
+                       "model": desc["model"], "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
+                       "interactions": interactions,
                        "visible_gaussians": stats.get("visible"), "deepest_tile": stats.get("deepest_tile"),
                        "mean_instances_per_tile": round(N / max(1, ((size + 15) // 16) ** 2), 1),
                        "views_per_step": world * vps, "views_per_rank_per_step": vps,
                        "parallelism": (f"view-parallel x{world}, {vps} view(s) per rank per step, one gradient all-reduce "
-                                       f"(63.6 MB) per step") if world > 1 else "single view",
+                                       f"per step") if world > 1 else "single view",
                        "step": (f"K0 fwd + {vps} x (render fwd + bwd)" if vps > 1 else "K0 fwd + render fwd + bwd")
-                               + " (+ grad all-reduce when N>1)"
+                               + (" + gradient all-reduce" if distributed else "")
                                + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")
                                + (f" + optimizer.step() [{args.optimizer}]" if args.optimizer != "none" else "")},
-            "roofline": {"kernel": dom, "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                         "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"], "avg_launch_us": kd["avg_us"],
-                         "note": "blend kernels are VALU/LDS-bound (no dense contraction, no MFMA); HBM-bound kernels "
-                                 "are listed under `kernels`"},
+            "roofline": roofline,
             "kernels": kernels,
             "whole_iteration": {"algorithmic_bytes": whole_bytes, "sum_kernel_us": round(sum_kernel_us, 1),
                                 "achieved_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                 "frac_of_8TBps": round(whole_bytes / (ms_per_step * 1e-3) / 8e12, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline and desc["model"] == "gs_mesh":
             try:
-                out["cpu_baseline"] = cpu_baseline(args.workload, args.state)
+                out["cpu_baseline"] = cpu_baseline(workload, args.state)
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1 or force_ddp:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -1,22 +1,24 @@
-// raster_forward.hip -- forward pass of the gfx950 Gaussian rasterizer.
+// raster_forward.hip -- forward pass of the gfx950 Gaussian rasterizer: preprocess, binning, host orchestration.
 //
 // Pipeline (one HIP stream, no MFMA anywhere: there is no dense contraction on this path):
-//   K1  preprocess_fwd   1 thread / Gaussian.  SH coefficients are staged through LDS with
-//                        wave-cooperative float4 loads (coalesced 1 KiB per wave instruction)
-//                        and read back conflict-free with a 52-dword row pitch.  Emits the
-//                        48-byte splat record, depth, clamp bits, radius and counts tile
-//                        coverage with one atomic per (Gaussian, tile).
-//   K2  tile_scan        exclusive scan of the per-tile counts (single block), N -> pinned host.
-//   K3  emit_instances   one 64-bit key (depth bits << 32 | id) per (Gaussian, tile) into the
-//                        tile's segment (slot from a per-tile cursor atomic).
-//   K4  tile_sort        one block per tile: all-ascending bitonic network on (depth,id) keys in
-//                        LDS (global fallback for segments > 4096) -- the total order makes the
-//                        result independent of the atomic emission order (== stable radix sort
-//                        of the reference: ties in depth resolve by ascending Gaussian id).
-//   K6  blend_fwd        one block (4 waves) per 16x16 tile, each wave owns an 8x8 quadrant.
-//                        Splat records are gathered into an LDS queue 256 at a time; each wave
-//                        tests 64 queue entries at once against its quadrant (exact conservative
-//                        test on the alpha>=1/255 ellipse) and walks only the ballot survivors.
+//   K1  preprocess_fwd   1 thread / Gaussian.  SH rows staged through LDS by wave-cooperative float4 loads, read back
+//                        conflict-free at a 52-dword pitch.  Writes the 48-byte splat record, depth, clamp bits, radius,
+//                        visibility byte; counts tile coverage in a block-level LDS tile table (one global atomic per
+//                        distinct tile per block; footprints > 64 tiles are expanded by the whole wave).
+//   K2  tile_scan        ONE block of 1024: eleven exclusive scans over the tiles in one pass (instances, work units,
+//                        multi-segment slots, six heaviest-first unit classes, sort runs, multi-run tiles); publishes
+//                        N / deepest tile / unit count to the host through the pinned slot, clears the tile counters.
+//   K3  emit_instances   one 64-bit key (depth bits << 32 | id) per (Gaussian, tile): per-block LDS tile table, ONE
+//                        cursor atomic per distinct tile per block; spare blocks write the (tile, segment) unit records
+//                        (heaviest first) and the sort's run tables.
+//   K4  tile_sort        presort of 1024-key runs (one block per run, wave-local bitonic sub-stages), then merge-path
+//                        levels in LDS per multi-run tile (<= 8192 keys) or multi-block merge-path passes for deeper
+//                        tiles.  Total order on (depth, id): independent of the emission order == the reference's
+//                        stable radix sort.
+//   K5/K6 compositing    blend.hip (segment-parallel: head / fwd / finalize).
+//
+// Library state: everything that outlives a call (tile counters, launch-size hints) is keyed by
+// (device, stream[, W, H, P]); see FrameState / Counters below.
 //
 // Behavioural contract: SURVEY.md appendix A (constants, skip/stop tests, pixel-centre
 // convention); reference call site renderer/gaussian_renderer/__init__.py:94-102.
@@ -980,6 +982,12 @@ extern "C" int32_t gms_abi_version(void) { return GMS_ABI_VERSION; }
 extern "C" const char *gms_last_error(void) { return gms::g_err; }
 extern "C" size_t gms_geom_bytes(int32_t P) { return GeomState::bytes((size_t)(P > 0 ? P : 1)); }
 extern "C" size_t gms_image_bytes(int32_t w, int32_t h) { return ImageState::bytes((size_t)w, (size_t)h); }
+extern "C" size_t gms_image_n_contrib_offset(int32_t w, int32_t h)
+{
+    char *const base = reinterpret_cast<char *>(uintptr_t(1) << 20);
+    ImageState s = ImageState::carve(base, (size_t)w, (size_t)h);
+    return (size_t)(reinterpret_cast<char *>(s.n_contrib) - base);
+}
 extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 {
     const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
@@ -1031,16 +1039,19 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     GeomState geom = GeomState::carve(geom_mem, (size_t)P);
     ImageState img = ImageState::carve(img_mem, (size_t)W, (size_t)H);
 
-    // Per-tile instance counters: a library-owned buffer per (host thread, stream) that is all zero between frames --
-    // tile_scan clears each counter after reading it -- so a frame starts without a memset.  `dirty` covers a frame that
-    // failed between the preprocess launch and the scan launch.
-    struct Counters { hipStream_t stream; uint32_t *buf; size_t cap; bool dirty; };
+    // Per-tile instance counters: a library-owned buffer per (host thread, DEVICE, stream) that is all zero between
+    // frames -- tile_scan clears each counter after reading it -- so a frame starts without a memset.  `dirty` covers a
+    // frame that failed between the preprocess launch and the scan launch.  (torch's default stream has the raw
+    // handle 0 on every device, so the device is part of the key.)
+    int device = 0;
+    GMS_HIP_CHECK(hipGetDevice(&device));
+    struct Counters { int device; hipStream_t stream; uint32_t *buf; size_t cap; bool dirty; };
     static thread_local std::vector<Counters> t_counters;
     Counters *ctr = nullptr;
-    for (auto &c : t_counters) if (c.stream == stream) ctr = &c;
-    if (!ctr) { t_counters.push_back({stream, nullptr, 0, true}); ctr = &t_counters.back(); }
+    for (auto &c : t_counters) if (c.device == device && c.stream == stream) ctr = &c;
+    if (!ctr) { t_counters.push_back({device, stream, nullptr, 0, true}); ctr = &t_counters.back(); }
     if (ctr->cap < (size_t)T) {
-        if (ctr->buf) (void)hipFree(ctr->buf);
+        if (ctr->buf) (void)hipFree(ctr->buf);       // `device` is current: the buffer was allocated under it
         ctr->buf = nullptr; ctr->cap = 0;
         GMS_HIP_CHECK(hipMalloc((void **)&ctr->buf, (size_t)T * 4));
         ctr->cap = (size_t)T; ctr->dirty = true;
@@ -1048,6 +1059,18 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     if (ctr->dirty) GMS_HIP_CHECK(hipMemsetAsync(ctr->buf, 0, ctr->cap * 4, stream));
     ctr->dirty = true;                              // until this frame's scan has been enqueued
     img.tile_count = ctr->buf;
+    // Launch-size hints learnt from earlier frames, per (device, stream, W, H, P): two scenes of different size
+    // interleaved on one thread (or one scene on two devices) do not disturb each other's hints
+    struct FrameState { int device; hipStream_t stream; int W, H, P; uint32_t deepest_seen, units_hint; };
+    static thread_local std::vector<FrameState> t_frames;
+    FrameState *fs = nullptr;
+    for (auto &f : t_frames) if (f.device == device && f.stream == stream && f.W == W && f.H == H && f.P == P) fs = &f;
+    if (!fs) {
+        if (t_frames.size() >= 64) t_frames.erase(t_frames.begin());
+        t_frames.push_back({device, stream, W, H, P, 0u, 0u}); fs = &t_frames.back();
+    }
+    uint32_t &deepest_seen = fs->deepest_seen;      // deepest tile of the previous frame of this shape
+    uint32_t &units_hint = fs->units_hint;          // slowly decaying maximum of its work-unit counts (views differ)
 
     PreArgs pa;
     pa.P = P; pa.D = A->D; pa.M = A->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
@@ -1082,7 +1105,6 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
     // merge-path passes for tiles deeper than SORT_BIG_CHUNK keys: as many as the deepest tile of the previous frame
     // (+25 %) needs; a deeper tile than that falls back to the one-block sort and raises the count for the next frame
-    static thread_local uint32_t deepest_seen = 0;
     int sort_np = 0;
     if (deepest_seen > (uint32_t)SORT_BIG_CHUNK) sort_np = sort_passes((uint64_t)deepest_seen + deepest_seen / 4);
     static thread_local int32_t seq_counter = 0;
@@ -1100,8 +1122,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     // Blend launches are sized from the previous frame's unit count (+25 %) instead of the table's capacity (thousands of
     // blocks that only find out they have nothing to do); a frame with more units than launched is re-run like a
     // capacity overflow.
-    static thread_local uint32_t units_seen = 0;      // this frame's count once known
-    static thread_local uint32_t units_hint = 0;      // slowly decaying maximum over recent frames (views differ)
+    uint32_t units_seen = 0;                          // this frame's count once known
     uint32_t launched_units = 0;
     auto enqueue_tail = [&](void *bin_mem, uint64_t capacity, bool exact_fit) -> int32_t {
         BinningState bin = BinningState::carve(bin_mem, (size_t)capacity, (size_t)T, L);

@@ -89,6 +89,12 @@ def last_stats() -> dict:
     radii = d.pop("radii", None)
     if radii is not None:
         d["visible"] = int((radii > 0).sum())
+    image = d.pop("image", None)
+    if image is not None and image.numel():
+        # sum over pixels of the 1-based list position of the last splat each pixel composited: the number of
+        # (pixel, splat) steps a per-pixel front-to-back walk takes ("interactions")
+        off = int(_lib.load().gms_image_n_contrib_offset(d["width"], d["height"]))
+        d["interactions"] = int(image[off:off + 4 * d["width"] * d["height"]].view(torch.int32).sum(dtype=torch.int64))
     return d
 
 
@@ -201,8 +207,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise scratch.error
             _lib.check(num_rendered, "gms_rasterize_forward")
         _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
-        _last_stats.update(num_rendered=int(num_rendered), capacity_hint=hint, P=P, width=W, height=H,
-                           deepest_tile=int(lib.gms_last_deepest_tile()), radii=radii)
+        _last_stats.update(num_rendered=int(num_rendered), num_units=int(num_units.value), capacity_hint=hint, P=P, width=W, height=H,
+                           deepest_tile=int(lib.gms_last_deepest_tile()), radii=radii,
+                           image=scratch.tensors.get("image"))
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)

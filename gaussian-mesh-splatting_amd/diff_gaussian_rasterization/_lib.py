@@ -86,7 +86,7 @@ EXPORTS = (
     "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
-    "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile",
+    "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
 )
 K_COUNT = 15
 
@@ -120,10 +120,11 @@ def load():
         lib.gms_mesh_to_gaussians_backward.argtypes = [C.POINTER(MeshArgs)] + [C.c_void_p] * 9
         lib.gms_abi_version.restype = C.c_int32
         lib.gms_last_error.restype = C.c_char_p
-        for n in ("gms_geom_bytes", "gms_image_bytes", "gms_binning_bytes"):
+        for n in ("gms_geom_bytes", "gms_image_bytes", "gms_binning_bytes", "gms_image_n_contrib_offset"):
             getattr(lib, n).restype = C.c_size_t
         lib.gms_geom_bytes.argtypes = [C.c_int32]
         lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
+        lib.gms_image_n_contrib_offset.argtypes = [C.c_int32, C.c_int32]
         lib.gms_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.gms_knn_workspace_bytes.restype = C.c_size_t
         lib.gms_knn_workspace_bytes.argtypes = [C.c_int32]

@@ -1,12 +1,20 @@
-"""Mesh-bound Gaussian model on the fused HIP op: the attribute / method surface of the reference's
-GaussianMeshModel that the render path touches, without the reference's dataset / PLY / optimizer code.
+"""Mesh-bound Gaussian models on the fused HIP op.
 
-Mirrors (same names, same meaning):
-  scene/gaussian_model.py:95-115       get_scaling / get_rotation / get_xyz / get_features / get_opacity
-  games/mesh_splatting/scene/gaussian_mesh_model.py:153-169  update_alpha()
-  games/mesh_splatting/scene/gaussian_mesh_model.py:103-151  prepare_scaling_rot()
-  games/mesh_splatting/scene/gaussian_mesh_model.py:171-183  training_setup() parameter groups
-`HipMeshMixin` can also be mixed into the reference's own classes (see games_hip.install).
+Three mixins override, with identical results, the K0 methods of the reference's three mesh-bound model classes and
+nothing else (dataset readers, optimizer groups, PLY I/O stay the host class's):
+
+  HipMeshMixin       GaussianMeshModel        games/mesh_splatting/scene/gaussian_mesh_model.py:86-169
+  HipMultiMeshMixin  GaussianMultiMeshModel   games/multi_mesh_splatting/scene/gaussian_multi_mesh_model.py:99-199
+  HipFlameMixin      GaussianFlameModel       games/flame_splatting/scene/gaussian_flame_model.py:123-207
+
+`install()` puts them into both registries of games/__init__.py:35-51 (`gaussianModel` used by train.py,
+`gaussianModelRender` used by scripts/render.py:22,41).  The stand-alone classes at the bottom
+(`HipGaussianMeshModel`, `HipGaussianMultiMeshModel`, `HipGaussianFlameModel`) carry the same mixins on minimal hosts
+for bench.py / the GPU tests, where the reference tree is absent.
+
+Property getters fused into the op (scene/gaussian_model.py:95-115): get_scaling / get_rotation / get_opacity.
+Caches are validated against the identity AND autograd version of every tensor they were derived from, so editing
+`vertices`, `_scale`, `_alpha` or `_opacity` (an optimizer step, a checkpoint load) can never serve stale values.
 """
 from __future__ import annotations
 
@@ -16,81 +24,50 @@ from torch import nn
 from .mesh_op import mesh_to_gaussians, triangles_to_gaussians
 
 
-class HipMeshMixin:
-    """Overrides only update_alpha / prepare_scaling_rot.  Host class must provide: vertices, faces,
-    _alpha [F,S,3], _scale [P,1]; optional `alpha_mode` ("relu" default, "softmax" for FLAME)."""
+class _Stamp:
+    """The tensors a cached value was derived from, with their in-place versions.  Holds the tensors themselves
+    (not their ids: an id can be reused once a tensor is freed), compared by identity + version."""
 
-    alpha_mode = "relu"
+    __slots__ = ("items",)
 
-    def update_alpha(self):
-        opa = getattr(self, "_opacity", None)
-        fuse_opacity = torch.is_tensor(opa) and opa.is_cuda and opa.numel() == self._scale.numel()
-        out = mesh_to_gaussians(self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True,
-                                _opacity=opa if fuse_opacity else None)
-        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = out[:6]
-        # get_opacity (scene/gaussian_model.py:113-115) from the same kernel; valid while _opacity is unchanged
-        self._hip_opacity = (opa, opa._version, out[6]) if fuse_opacity else None
-        self.alpha = alpha
-        self._xyz = xyz
-        # `triangles` is only read by save_ply and the animated renderers: gathered on first access
-        self.__dict__.pop("_hip_tri", None)
-        self._hip_tri_external = None
-        self._hip_cached = (scaling, rotation, scaling_act, rotation_unit)
+    def __init__(self, *tensors):
+        self.items = tuple((t, t._version if torch.is_tensor(t) else -1) for t in tensors)
 
-    @property
-    def triangles(self):
-        ext = self.__dict__.get("_hip_tri_external")
-        if ext is not None:
-            return ext
-        tri = self.__dict__.get("_hip_tri")
-        if tri is None and getattr(self, "vertices", None) is not None and getattr(self, "faces", None) is not None \
-                and torch.is_tensor(self.faces) and self.faces.numel():
-            with torch.no_grad():
-                tri = self.vertices[self.faces]
-            self.__dict__["_hip_tri"] = tri
-        return tri
+    def __eq__(self, other):
+        return (isinstance(other, _Stamp) and len(self.items) == len(other.items)
+                and all(a is b and va == vb for (a, va), (b, vb) in zip(self.items, other.items)))
 
-    @triangles.setter
-    def triangles(self, value):
-        # a renderer / loader replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72)
-        self.__dict__["_hip_tri_external"] = value
+    def __ne__(self, other):
+        return not self.__eq__(other)
 
-    def prepare_scaling_rot(self, *unused):
-        tri = self.__dict__.get("_hip_tri_external")
-        cached = getattr(self, "_hip_cached", None)
-        if tri is not None:
-            # a renderer replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72-73):
-            # derive scale / rotation from those triangles
-            _, _, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
-                tri, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
-        elif cached is not None:
-            scaling, rotation, scaling_act, rotation_unit = cached
-        else:
-            _, _, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
-                self.vertices, self.faces, self._alpha, self._scale, self.alpha_mode, fused_activations=True)
-        self._scaling = scaling
-        self._rotation = rotation
-        self._hip_activated = (scaling, rotation, scaling_act, rotation_unit)
+    __hash__ = None
 
-    # Property getters (scene/gaussian_model.py:95-101): exp / normalize were computed by the fused
-    # kernel; fall back to the reference's formula if somebody replaced _scaling / _rotation.
+
+def _stamp(*tensors):
+    return _Stamp(*tensors)
+
+
+class _HipGetters:
+    """get_scaling / get_rotation / get_opacity / get_features on the fused outputs; each falls back to the
+    reference's formula when `_scaling` / `_rotation` / `_opacity` is not the tensor the fused value came from."""
+
     @property
     def get_scaling(self):
-        act = getattr(self, "_hip_activated", None)
+        act = self.__dict__.get("_hip_activated")
         if act is not None and act[0] is self._scaling:
             return act[2]
         return torch.exp(self._scaling)
 
     @property
     def get_rotation(self):
-        act = getattr(self, "_hip_activated", None)
+        act = self.__dict__.get("_hip_activated")
         if act is not None and act[1] is self._rotation:
             return act[3]
         return torch.nn.functional.normalize(self._rotation)
 
     @property
     def get_opacity(self):
-        cached = getattr(self, "_hip_opacity", None)
+        cached = self.__dict__.get("_hip_opacity")
         if cached is not None and cached[0] is self._opacity and cached[1] == self._opacity._version:
             return cached[2]
         return torch.sigmoid(self._opacity)
@@ -104,15 +81,125 @@ class HipMeshMixin:
         return SplitSH(self._features_dc, self._features_rest)
 
 
-class HipMultiMeshMixin:
-    """Drop-in for GaussianMultiMeshModel.update_alpha / _calc_xyz / prepare_scaling_rot
-    (games/multi_mesh_splatting/scene/gaussian_multi_mesh_model.py:99-199): the per-mesh python loop and the
+class HipMeshMixin(_HipGetters):
+    """Host class provides: vertices [V,3], faces [F,3], _alpha [F,S,3], _scale [P,1] (attribute name in
+    `_hip_scale_attr`); optional `_opacity` [P,1].  `alpha_mode`: "relu" (mesh models) or "softmax" (FLAME)."""
+
+    alpha_mode = "relu"
+    _hip_scale_attr = "_scale"
+
+    # ---- inputs of the op (overridden by the FLAME mixin, whose vertices come out of the FLAME layer)
+    def _hip_inputs(self):
+        return self.vertices, self.faces, self._alpha, getattr(self, self._hip_scale_attr)
+
+    def _hip_run(self):
+        vertices, faces, _alpha, _scale = self._hip_inputs()
+        P = int(_alpha.shape[0] * _alpha.shape[1])
+        # create_from_pcd calls update_alpha() before `_scale` exists (gaussian_mesh_model.py:78-81,
+        # gaussian_flame_model.py:78-82): alpha / xyz do not depend on it, scaling / rotation are not cached then
+        have_scale = torch.is_tensor(_scale) and _scale.numel() == P
+        scale_in = _scale if have_scale else torch.ones((P, 1), dtype=torch.float32, device=_alpha.device)
+        opa = getattr(self, "_opacity", None)
+        fuse_opacity = have_scale and torch.is_tensor(opa) and opa.is_cuda and opa.numel() == P
+        out = mesh_to_gaussians(vertices, faces, _alpha, scale_in, self.alpha_mode, fused_activations=True,
+                                _opacity=opa if fuse_opacity else None)
+        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = out[:6]
+        self.__dict__["_hip_opacity"] = (opa, opa._version, out[6]) if fuse_opacity else None
+        self.__dict__["_hip_cached"] = ((scaling, rotation, scaling_act, rotation_unit),
+                                        _stamp(vertices, faces, _alpha, _scale)) if have_scale else None
+        return alpha, xyz
+
+    def update_alpha(self):
+        alpha, xyz = self._hip_run()
+        self.alpha = alpha
+        self._xyz = xyz
+        # `triangles` is only read by save_ply and the animated renderers: gathered on first access
+        self.__dict__.pop("_hip_tri", None)
+        self.__dict__["_hip_tri_external"] = None
+        if "triangles" in self.__dict__:           # a save_ply put it there (see save_ply below): keep it fresh
+            self.__dict__["triangles"] = self.triangles
+
+    @property
+    def triangles(self):
+        ext = self.__dict__.get("_hip_tri_external")
+        if ext is not None:
+            return ext
+        tri = self.__dict__.get("_hip_tri")
+        vertices, faces = getattr(self, "vertices", None), getattr(self, "faces", None)
+        if tri is None and torch.is_tensor(vertices) and torch.is_tensor(faces) and faces.numel():
+            with torch.no_grad():
+                tri = vertices[faces]
+            self.__dict__["_hip_tri"] = tri
+        return tri
+
+    @triangles.setter
+    def triangles(self, value):
+        # a renderer / loader replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72,
+        # GaussianMeshModel.load_ply :231)
+        self.__dict__["_hip_tri_external"] = value
+
+    def prepare_scaling_rot(self, *unused):
+        tri = self.__dict__.get("_hip_tri_external")
+        cached = self.__dict__.get("_hip_cached")
+        vertices, faces, _alpha, _scale = self._hip_inputs()
+        if tri is not None:
+            # a renderer replaced pc.triangles (renderer/gaussian_animated_renderer/__init__.py:72-73):
+            # derive scale / rotation from those triangles
+            _, _, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
+                tri, _alpha, _scale, self.alpha_mode, fused_activations=True)
+        elif cached is not None and cached[1] == _stamp(vertices, faces, _alpha, _scale):
+            scaling, rotation, scaling_act, rotation_unit = cached[0]
+        else:   # no update_alpha() since the inputs changed: recompute from the current tensors, as the reference does
+            _, _, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
+                vertices, faces, _alpha, _scale, self.alpha_mode, fused_activations=True)
+        self._scaling = scaling
+        self._rotation = rotation
+        self.__dict__["_hip_activated"] = (scaling, rotation, scaling_act, rotation_unit)
+
+    def save_ply(self, path):
+        """The reference's save_ply (gaussian_mesh_model.py:189-207) reads `triangles` out of the instance
+        `__dict__`; here it is a lazily gathered property, so materialise it there first (update_alpha keeps it
+        fresh from then on)."""
+        self.__dict__["triangles"] = self.triangles
+        return super().save_ply(path)
+
+
+class HipFlameMixin(HipMeshMixin):
+    """GaussianFlameModel: softmax barycentric weights (gaussian_flame_model.py:195), vertices produced by the host
+    class's FLAME layer (:196-207, python/torch: linear blend skinning is outside the hot path, SURVEY 8 out-of-scope),
+    scale parameter named `_scales` (:42,:82).  One launch derives alpha / xyz / scaling / rotation from them."""
+
+    alpha_mode = "softmax"
+    _hip_scale_attr = "_scales"
+
+    def _hip_flame_vertices(self):
+        pc = self.point_cloud
+        vertices, _ = pc.flame_model(shape_params=self._flame_shape, expression_params=self._flame_exp,
+                                     pose_params=self._flame_pose, neck_pose=self._flame_neck_pose,
+                                     transl=self._flame_trans)
+        return pc.transform_vertices_function(vertices, self._vertices_enlargement)
+
+    def update_alpha(self):
+        self.vertices = self._hip_flame_vertices()
+        alpha, xyz = self._hip_run()
+        self.alpha = alpha
+        self._xyz = xyz
+        self.__dict__.pop("_hip_tri", None)
+        self.__dict__["_hip_tri_external"] = None
+
+    def save_ply(self, path):       # GaussianFlameModel.save_ply does not read `triangles`
+        return super(HipMeshMixin, self).save_ply(path)
+
+
+class HipMultiMeshMixin(_HipGetters):
+    """GaussianMultiMeshModel.update_alpha / _calc_xyz / prepare_scaling_rot: the per-mesh python loop and the
     torch.cat of its results become ONE launch over the concatenated meshes (faces re-indexed by the vertex
     offsets, splat ranges as CSR because every mesh may carry a different number of splats per face).
     Host class provides the reference's list attributes: vertices[i], faces[i], _alpha[i] [F_i,S_i,3], _scale[i] [P_i,1]."""
 
     def _hip_topology(self):
-        key = tuple((int(f.shape[0]), int(a.shape[1]), int(v.shape[0])) for f, a, v in zip(self.faces, self._alpha, self.vertices))
+        key = (_stamp(*self.faces), tuple((int(f.shape[0]), int(a.shape[1]), int(v.shape[0]))
+                                          for f, a, v in zip(self.faces, self._alpha, self.vertices)))
         cached = self.__dict__.get("_hip_topo")
         if cached is not None and cached[0] == key:
             return cached[1:]
@@ -120,7 +207,7 @@ class HipMultiMeshMixin:
         faces, counts = [], []
         voff = 0
         for f, a, v in zip(self.faces, self._alpha, self.vertices):
-            faces.append(f.to(device).long() + voff)
+            faces.append(torch.as_tensor(f).to(device).long() + voff)
             counts.append(torch.full((int(f.shape[0]),), int(a.shape[1]), dtype=torch.int64))
             voff += int(v.shape[0])
         counts = torch.cat(counts)
@@ -130,36 +217,64 @@ class HipMultiMeshMixin:
         self.__dict__["_hip_topo"] = (key,) + topo
         return topo
 
-    def update_alpha(self):
+    def _hip_run(self):
         faces, fso, sf = self._hip_topology()
         V = torch.cat(list(self.vertices))
         A = torch.cat([a.reshape(-1, 3) for a in self._alpha])
         Sc = torch.cat(list(self._scale))
-        alpha, xyz, scaling, rotation, scaling_act, rotation_unit = mesh_to_gaussians(
-            V, faces, A, Sc, "relu", face_splat_offset=fso, splat_face=sf, fused_activations=True)
+        opa = getattr(self, "_opacity", None)
+        fuse_opacity = torch.is_tensor(opa) and opa.is_cuda and opa.numel() == Sc.numel()
+        out = mesh_to_gaussians(V, faces, A, Sc, "relu", face_splat_offset=fso, splat_face=sf, fused_activations=True,
+                                _opacity=opa if fuse_opacity else None)
+        self.__dict__["_hip_opacity"] = (opa, opa._version, out[6]) if fuse_opacity else None
+        self.__dict__["_hip_cached"] = (tuple(out[2:6]), _stamp(*self.vertices, *self.faces, *self._alpha, *self._scale))
+        return out[0], out[1]
+
+    def update_alpha(self):
+        alpha, xyz = self._hip_run()
         sizes = [a.shape[0] * a.shape[1] for a in self._alpha]
         self.alpha = [x.reshape(a.shape) for x, a in zip(torch.split(alpha, sizes), self._alpha)]
         self._xyz = xyz
-        self._hip_cached = (scaling, rotation, scaling_act, rotation_unit)
+
+    def _calc_xyz(self):
+        self.update_alpha()
 
     def prepare_scaling_rot(self, *unused):
-        if self.__dict__.get("_hip_cached") is None:
-            self.update_alpha()
-        scaling, rotation, scaling_act, rotation_unit = self._hip_cached
+        cached = self.__dict__.get("_hip_cached")
+        if cached is None or cached[1] != _stamp(*self.vertices, *self.faces, *self._alpha, *self._scale):
+            self._hip_run()
+            cached = self.__dict__["_hip_cached"]
+        scaling, rotation, scaling_act, rotation_unit = cached[0]
         self._scaling, self._rotation = scaling, rotation
-        self._hip_activated = (scaling, rotation, scaling_act, rotation_unit)
-
-    get_scaling = HipMeshMixin.get_scaling
-    get_rotation = HipMeshMixin.get_rotation
+        self.__dict__["_hip_activated"] = (scaling, rotation, scaling_act, rotation_unit)
 
 
-class HipGaussianMeshModel(HipMeshMixin):
-    """Stand-alone model (no dependency on the reference tree) used by bench.py / tests."""
-
+# ---------------------------------------------------------------------------------------------------------------
+# Stand-alone hosts (no dependency on the reference tree) used by bench.py / the GPU tests
+class _StandaloneBase:
     def __init__(self, sh_degree: int = 3):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
         self.optimizer = None
+
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    def oneupSHdegree(self):        # scene/gaussian_model.py:117-119
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
+
+    def _make_optimizer(self, groups, fused):
+        if fused:       # one HIP launch per step (csrc/adam.hip); same state layout as torch.optim.Adam
+            from .optim import FusedAdam
+            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+
+
+class HipGaussianMeshModel(HipMeshMixin, _StandaloneBase):
+    """gs_mesh (games/mesh_splatting/scene/gaussian_mesh_model.py) on the fused op."""
 
     @classmethod
     def from_scene(cls, scene, device="cuda"):
@@ -182,19 +297,15 @@ class HipGaussianMeshModel(HipMeshMixin):
 
     def training_setup(self, vertices_lr=0.0, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
                        fused=True):
-        groups = [
+        """Parameter groups of gaussian_mesh_model.py:171-183."""
+        self._make_optimizer([
             {"params": [self.vertices], "lr": vertices_lr, "name": "vertices"},
             {"params": [self._alpha], "lr": alpha_lr, "name": "alpha"},
             {"params": [self._features_dc], "lr": feature_lr, "name": "f_dc"},
             {"params": [self._features_rest], "lr": feature_lr / 20.0, "name": "f_rest"},
             {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
             {"params": [self._scale], "lr": scaling_lr, "name": "scaling"},
-        ]
-        if fused:       # one HIP launch per step (csrc/adam.hip); same state layout as torch.optim.Adam
-            from .optim import FusedAdam
-            self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
-        else:
-            self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        ], fused)
 
     # ---- checkpoints: the reference's on-disk format (scene/gaussian_model.py:177-268 point_cloud.ply +
     # games/mesh_splatting/scene/gaussian_mesh_model.py:189-222 model_params.pt), through the plyfile stand-in
@@ -208,7 +319,7 @@ class HipGaussianMeshModel(HipMeshMixin):
     def save_ply(self, path):
         import os
         import numpy as np
-        from plyfile import PlyData, PlyElement
+        from ._plyfile_compat import PlyData, PlyElement
         self.update_alpha()
         self.prepare_scaling_rot()
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
@@ -225,7 +336,7 @@ class HipGaussianMeshModel(HipMeshMixin):
 
     def load_ply(self, path, device="cuda"):
         import numpy as np
-        from plyfile import PlyData
+        from ._plyfile_compat import PlyData
         el = PlyData.read(path).elements[0]
         col = lambda n: np.asarray(el[n], dtype=np.float32)
         P = el.count
@@ -246,19 +357,133 @@ class HipGaussianMeshModel(HipMeshMixin):
         self.update_alpha()
         self.prepare_scaling_rot()
 
-    @property
-    def get_xyz(self):
-        return self._xyz
 
+class HipGaussianMultiMeshModel(HipMultiMeshMixin, _StandaloneBase):
+    """gs_multi_mesh (BASELINE config 4): several meshes, each with its own splats-per-face, one set of SH /
+    opacity tensors over the concatenation (gaussian_multi_mesh_model.py:48-97)."""
+
+    @classmethod
+    def from_scenes(cls, scenes, device="cuda"):
+        m = cls(3)
+        m.active_sh_degree = scenes[0].active_sh_degree
+        par = lambda t: nn.Parameter(t.to(device).float().contiguous())
+        m.vertices = [par(s.vertices) for s in scenes]
+        m.faces = [s.faces.to(device) for s in scenes]
+        m._alpha = [par(s._alpha) for s in scenes]
+        m._scale = [par(s._scale) for s in scenes]
+        m._opacity = par(torch.cat([s._opacity for s in scenes]))
+        m._features_dc = par(torch.cat([s._features_dc for s in scenes]))
+        m._features_rest = par(torch.cat([s._features_rest for s in scenes]))
+        m.update_alpha()
+        m.prepare_scaling_rot()
+        return m
+
+    def parameters(self):
+        return [*self.vertices, *self._alpha, self._features_dc, self._features_rest, self._opacity, *self._scale]
+
+    def training_setup(self, vertices_lr=0.0, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005,
+                       fused=True):
+        """Parameter groups of gaussian_multi_mesh_model.py:221-236."""
+        self._make_optimizer([
+            {"params": list(self._alpha), "lr": alpha_lr, "name": "alpha"},
+            {"params": list(self.vertices), "lr": vertices_lr, "name": "vertices"},
+            {"params": [self._features_dc], "lr": feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
+            {"params": list(self._scale), "lr": scaling_lr, "name": "scaling"},
+        ], fused)
+
+
+class _SyntheticFlameLayer:
+    """Stand-in for the licensed FLAME layer (games/flame_splatting/FLAME, absent: needs smplx + the model file):
+    a differentiable vertex generator with the same call signature and return shape ([1,V,3], landmarks) --
+    template + expression-weighted blend shapes + a global rotation about z by pose[0,0] + translation."""
+
+    def __init__(self, template, n_exp=4, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.template = template
+        self.blend = 0.02 * torch.randn(n_exp, *template.shape, generator=g).to(template.device)
+
+    def __call__(self, shape_params=None, expression_params=None, pose_params=None, neck_pose=None, transl=None):
+        v = self.template + torch.einsum("e,evk->vk", expression_params.reshape(-1)[: self.blend.shape[0]], self.blend)
+        a = pose_params.reshape(-1)[0]
+        c, s = torch.cos(a), torch.sin(a)
+        R = torch.stack([torch.stack([c, -s, torch.zeros_like(c)]), torch.stack([s, c, torch.zeros_like(c)]),
+                         torch.stack([torch.zeros_like(c), torch.zeros_like(c), torch.ones_like(c)])])
+        v = v @ R.T + transl.reshape(1, 3)
+        return v[None], None
+
+
+class _FlameCloud:
+    """The attributes of FLAMEPointCloud (games/flame_splatting/utils/graphics_utils.py) the model reads."""
+
+    def __init__(self, flame_model, transform_vertices_function):
+        self.flame_model, self.transform_vertices_function = flame_model, transform_vertices_function
+
+
+class HipGaussianFlameModel(HipFlameMixin, _StandaloneBase):
+    """gs_flame (BASELINE config 5) with a synthetic vertex generator in place of the FLAME layer: per-frame
+    vertex animation + on-device re-derivation of the face-local rotation / scale."""
+
+    @classmethod
+    def from_scene(cls, scene, device="cuda", enlargement=1.0):
+        m = cls(3)
+        m.active_sh_degree = scene.active_sh_degree
+        par = lambda t: nn.Parameter(t.to(device).float().contiguous())
+        template = scene.vertices.to(device).float()
+        m.point_cloud = _FlameCloud(_SyntheticFlameLayer(template),
+                                    lambda v, c: torch.squeeze(v, 0) * c)       # dataset_readers.py:41-46 (axis swap omitted)
+        m.faces = scene.faces.to(device)
+        m._flame_shape = par(torch.zeros(1, 4))
+        m._flame_exp = par(torch.zeros(1, 4))
+        m._flame_pose = par(torch.zeros(1, 6))
+        m._flame_neck_pose = par(torch.zeros(1, 3))
+        m._flame_trans = par(torch.zeros(1, 3))
+        m._vertices_enlargement = par(torch.full_like(template, float(enlargement)))
+        m._alpha = par(scene._alpha)
+        m._scales = par(scene._scale)
+        m._opacity = par(scene._opacity)
+        m._features_dc = par(scene._features_dc)
+        m._features_rest = par(scene._features_rest)
+        m.update_alpha()
+        m.prepare_scaling_rot()
+        return m
+
+    def parameters(self):
+        return [self._flame_exp, self._flame_pose, self._flame_trans, self._vertices_enlargement, self._alpha,
+                self._features_dc, self._features_rest, self._opacity, self._scales]
+
+
+_MIXINS = {"gs_mesh": HipMeshMixin, "gs_multi_mesh": HipMultiMeshMixin, "gs_flame": HipFlameMixin}
 
 
 def install(games_module=None):
-    """Swap the fused op into the reference's registry (games/__init__.py:35-51): the mesh model keeps
-    its class, dataset reader, optimizer groups and PLY I/O; only update_alpha / prepare_scaling_rot
-    are overridden.  Call after `import games` in an environment that has the reference on sys.path."""
+    """Swap the fused op into the reference's registries (games/__init__.py:35-51): `gaussianModel` (train.py) and
+    `gaussianModelRender` (scripts/render.py:22,41) for gs_mesh, gs_multi_mesh and gs_flame.  Every model keeps its
+    class, dataset reader, optimizer groups and PLY I/O; only update_alpha / prepare_scaling_rot (+ the fused property
+    getters) are overridden.  Call after `import games` in an environment that has the reference on sys.path.
+    Returns {name: patched class}; `uninstall(games_module, returned)` restores the originals."""
     if games_module is None:
         import games as games_module  # type: ignore
-    base = games_module.gaussianModel["gs_mesh"]
-    cls = type("Hip" + base.__name__, (HipMeshMixin, base), {"alpha_mode": "relu"})
-    games_module.gaussianModel["gs_mesh"] = cls
-    return {"gs_mesh": cls}
+    out = {}
+    for name, mixin in _MIXINS.items():
+        base = games_module.gaussianModel[name]
+        if issubclass(base, mixin):            # already installed
+            out[name] = base
+            continue
+        cls = type("Hip" + base.__name__, (mixin, base), {"_hip_base": base})
+        for registry in (games_module.gaussianModel, getattr(games_module, "gaussianModelRender", {})):
+            if registry.get(name) is base:
+                registry[name] = cls
+        out[name] = cls
+    return out
+
+
+def uninstall(games_module, installed):
+    for name, cls in installed.items():
+        base = getattr(cls, "_hip_base", None)
+        if base is None:
+            continue
+        for registry in (games_module.gaussianModel, getattr(games_module, "gaussianModelRender", {})):
+            if registry.get(name) is cls:
+                registry[name] = base

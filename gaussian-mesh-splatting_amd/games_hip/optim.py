@@ -28,7 +28,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = _lib.load()
         by_hyper = {}
-        keep = []
+        keep, updated = [], []
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             lr, eps = float(group["lr"]), float(group["eps"])
@@ -61,9 +61,14 @@ class FusedAdam(torch.optim.Optimizer):
                 if lst is None:
                     lst = by_hyper[key] = []
                 lst.append(_lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step)))
+                updated.append(p)
         for (device, beta1, beta2, eps), tensors in by_hyper.items():
             arr = (_lib.AdamTensor * len(tensors))(*tensors)
             with _lib.on_device(device):
                 rc = lib.gms_adam_step(arr, len(tensors), beta1, beta2, eps, C.c_void_p(_lib.stream_ptr(device)))
             _lib.check(rc, "gms_adam_step")
+        # the kernel writes through raw pointers: tell autograd the parameters changed in place (version counters feed
+        # the saved-tensor modification check and the models' fused-getter caches)
+        if updated:
+            torch.autograd.graph.increment_version(updated)
         return loss

@@ -204,6 +204,28 @@ def mesh_scene(name: str = "c2_hotdog_like", state: str = "trained", seed: int =
                      {"name": name, "state": state, "F": F, "S": S, "P": P, "image": cfg[3]})
 
 
+MULTI_MESH_CONFIGS = {
+    # name: ([(n_lat, n_lon, splats_per_face, radius, (cx, cy, cz))], image size).  BASELINE config 4 ("gs_multi_mesh
+    # ficus, ~300k Gaussians, 800x800"): three meshes with different splat counts per face, 299 472 Gaussians
+    "c4_ficus_like": ([(130, 130, 3, 0.62, (0.0, 0.0, 0.45)), (100, 100, 5, 0.5, (0.45, -0.3, -0.4)),
+                       (160, 157, 2, 0.55, (-0.45, 0.3, -0.35))], 800),
+    "multi_tiny": ([(6, 8, 2, 0.6, (0.0, 0.0, 0.4)), (5, 6, 3, 0.5, (0.4, -0.2, -0.4))], 64),
+}
+
+
+def multi_mesh_scenes(name: str = "c4_ficus_like", state: str = "trained", seed: int = 0):
+    """List of MeshScene (one per mesh) for the multi-mesh model: each mesh keeps its own faces / splats-per-face
+    (games/multi_mesh_splatting/scene/gaussian_multi_mesh_model.py:48-97 keeps them as python lists)."""
+    parts, size = MULTI_MESH_CONFIGS[name]
+    scenes = []
+    for k, (n_lat, n_lon, S, radius, centre) in enumerate(parts):
+        sc = mesh_scene("c2_hotdog_like", state=state, seed=seed + k, n_lat=n_lat, n_lon=n_lon, splats=S)
+        sc.vertices = sc.vertices * radius + torch.tensor(centre, dtype=torch.float32)
+        sc.meta.update({"name": f"{name}[{k}]", "image": size})
+        scenes.append(sc)
+    return scenes
+
+
 @dataclass
 class FreeScene:
     """Free (non mesh-bound) Gaussians in the rasterizer's own input terms."""

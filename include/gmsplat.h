@@ -5,9 +5,12 @@
  *
  * Plain pointers and sizes only: no torch types, no C++ in the signatures.  Every pointer
  * marked "device" is an address in the HBM of the GPU that `stream` belongs to.  `stream`
- * is a hipStream_t passed as void* (NULL = the null stream).  All entry points are
- * re-entrant and keep no global mutable state besides a per-thread pinned 64-byte
- * read-back slot.
+ * is a hipStream_t passed as void* (NULL = the null stream).  The calling thread must have
+ * that GPU current (hipSetDevice).  All entry points are re-entrant.  State that outlives a
+ * call is per host thread and keyed by (device, stream[, W, H, P]): the always-zero tile
+ * counter buffer, the launch-size hints learnt from earlier frames of the same shape, and one
+ * pinned 64-byte read-back slot per thread; nothing is shared between threads, devices or
+ * streams.
  *
  * What each entry point replaces in the reference (waczjoan/gaussian-mesh-splatting):
  *
@@ -285,6 +288,9 @@ const char *gms_last_error(void);
 /* Byte sizes of the scratch buffers for given problem sizes (what the callbacks will be asked for). */
 size_t gms_geom_bytes(int32_t P);
 size_t gms_image_bytes(int32_t width, int32_t height);
+/* Byte offset, inside the image scratch buffer, of n_contrib [H*W] uint32 (1-based list position of the last splat each
+ * pixel composited): lets a caller sum the per-pixel walk lengths ("interactions") after a forward. */
+size_t gms_image_n_contrib_offset(int32_t width, int32_t height);
 size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
 #ifdef __cplusplus

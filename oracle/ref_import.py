@@ -34,8 +34,9 @@ def import_reference():
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
     # absent third-party deps: only their names are needed at import time
-    try:                                  # the repo ships a plyfile stand-in (gaussian-mesh-splatting_amd/plyfile.py)
-        import plyfile  # noqa: F401
+    try:            # the real package when installed, else the repo's stand-in (games_hip/_plyfile.py) under its name
+        from games_hip._plyfile_compat import ensure_plyfile
+        ensure_plyfile()
     except ImportError:
         _stub("plyfile", PlyData=object, PlyElement=object)
     for name in ("trimesh", "smplx", "smplx.lbs", "smplx.utils", "simple_knn", "simple_knn._C"):
@@ -60,6 +61,7 @@ def import_reference():
     ns.gaussian_model = importlib.import_module("scene.gaussian_model")
     ns.mesh_model = importlib.import_module("games.mesh_splatting.scene.gaussian_mesh_model")
     ns.multi_mesh_model = importlib.import_module("games.multi_mesh_splatting.scene.gaussian_multi_mesh_model")
+    ns.flame_model = importlib.import_module("games.flame_splatting.scene.gaussian_flame_model")
     return ns
 
 
@@ -72,20 +74,32 @@ def drop_reference_stubs():
 
 @contextlib.contextmanager
 def cuda_literals_on_cpu():
-    """The reference hard-codes device="cuda" in utils/general_utils.py:145,163,182.  Run its code
-    unmodified on CPU by making tensor factories ignore that literal for the duration."""
+    """The reference hard-codes device="cuda" / .cuda() (utils/general_utils.py:145,163,182, every create_from_pcd).
+    Run its code unmodified on CPU by making tensor factories ignore that literal and `.cuda()` a no-op for the
+    duration."""
     import torch
 
-    orig_zeros = torch.zeros
+    names = ("zeros", "ones", "tensor", "empty", "zeros_like", "ones_like", "rand", "full")
+    orig = {n: getattr(torch, n) for n in names}
 
-    def zeros(*a, **k):
-        if k.get("device") == "cuda":
-            k = dict(k)
-            k["device"] = "cpu"
-        return orig_zeros(*a, **k)
+    def wrap(fn):
+        def inner(*a, **k):
+            if k.get("device") == "cuda":
+                k = dict(k)
+                k["device"] = "cpu"
+            return fn(*a, **k)
+        return inner
 
-    torch.zeros = zeros
+    orig_cuda = torch.Tensor.cuda
+    orig_mod_cuda = torch.nn.Module.cuda
+    for n in names:
+        setattr(torch, n, wrap(orig[n]))
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
     try:
         yield
     finally:
-        torch.zeros = orig_zeros
+        for n in names:
+            setattr(torch, n, orig[n])
+        torch.Tensor.cuda = orig_cuda
+        torch.nn.Module.cuda = orig_mod_cuda

@@ -81,20 +81,82 @@ def forward_report(hip, ora, W, H):
                 psnr=float(10 * math.log10(1.0 / mse)) if mse > 0 else float("inf"))
 
 
-def grad_report(gh, go, q=0.999):
-    """Per-tensor error statistics relative to the tensor's own scale."""
+GRAD_REL = 1e-3          # north_star: 1e-3 relative on gradients
+ADJUDICATE_K = 16.0      # an outlier is float32 conditioning if HIP is within K x the float32 oracle's own error vs float64
+
+
+def grad_report(gh, go, q=0.999, go64=None):
+    """Per-tensor error statistics relative to the tensor's own scale, plus the HARD criteria:
+
+      * `zero_violation`: the oracle's gradient tensor is identically zero but the HIP one is not;
+      * `outliers`: entries with |hip - o32| > 1e-3 (|o32| + 1e-3 max|o32|);
+      * `unexplained`: outliers that are NOT float32 conditioning.  With the float64 oracle `go64` (same algorithm in
+        double: oracle/gs_oracle.c built with ORACLE_DOUBLE) an outlier is explained when the HIP value is as close to
+        the float64 truth as the float32 ORACLE itself is, up to a factor K (different summation order, float atomics):
+            |hip - o64| <= K |o32 - o64| + 1e-3 (|o64| + 1e-3 max|o64|).
+        Without `go64` every outlier counts as unexplained.
+    Tests assert unexplained == 0 and zero_violation == False: a bound on EVERY entry, not a quantile."""
     rep = {}
     for k, b in go.items():
         a = gh.get(k)
         if a is None or b is None or b.size == 0:
             continue
-        a = a.reshape(b.shape)
+        a = np.asarray(a).reshape(b.shape)
         scale = float(np.abs(b).max())
         if scale == 0:
-            rep[k] = dict(scale=0.0, max_abs=float(np.abs(a).max()), q_rel=0.0, max_rel=0.0)
+            mx = float(np.abs(a).max())
+            rep[k] = dict(scale=0.0, max_abs=mx, q_rel=0.0, max_rel=0.0, frac_bad=0.0, outliers=0, unexplained=0,
+                          zero_violation=bool(mx != 0.0), worst_ratio=0.0)
             continue
         err = np.abs(a - b)
         rel = err / (np.abs(b) + 1e-3 * scale)      # 1e-3 relative with an absolute floor of 1e-3*max|g|
+        bad = rel > GRAD_REL
+        n_out = int(bad.sum())
+        unexplained, worst = n_out, 0.0
+        if n_out and go64 is not None and go64.get(k) is not None:
+            t = np.asarray(go64[k], np.float64).reshape(b.shape)
+            s64 = float(np.abs(t).max())
+            e_hip = np.abs(a.astype(np.float64) - t)[bad]
+            e_o32 = np.abs(b.astype(np.float64) - t)[bad]
+            slack = GRAD_REL * (np.abs(t)[bad] + 1e-3 * s64)
+            ok = e_hip <= ADJUDICATE_K * e_o32 + slack
+            unexplained = int((~ok).sum())
+            with np.errstate(divide="ignore", invalid="ignore"):
+                ratio = np.where(e_o32 > 0, (e_hip - slack) / e_o32, np.where(e_hip > slack, np.inf, 0.0))
+            worst = float(np.max(ratio)) if ratio.size else 0.0
         rep[k] = dict(scale=scale, max_abs=float(err.max()), q_rel=float(np.quantile(rel, q)), max_rel=float(rel.max()),
-                      frac_bad=float((rel > 1e-3).mean()))
+                      frac_bad=float(bad.mean()), outliers=n_out, unexplained=unexplained, zero_violation=False,
+                      worst_ratio=worst)
     return rep
+
+
+def assert_grads(gh, go, go64_fn=None, q=0.999, where=""):
+    """The gradient criterion of every parity test: quantile <= 1e-3 AND no unexplained outlier AND no non-zero gradient
+    where the oracle's is identically zero.  `go64_fn()` (lazy: only evaluated if some entry is an outlier) returns the
+    float64 oracle's gradients."""
+    rep = grad_report(gh, go, q=q)
+    if go64_fn is not None and any(v["outliers"] for v in rep.values()):
+        rep = grad_report(gh, go, q=q, go64=go64_fn())
+    for k, v in rep.items():
+        assert not v["zero_violation"], (where, k, v)
+        assert v["q_rel"] <= GRAD_REL, (where, k, v)
+        assert v["frac_bad"] <= 2e-3, (where, k, v)
+        assert v["unexplained"] == 0, (where, k, v)
+    _log_parity(where, rep)
+    return rep
+
+
+def _log_parity(where, rep):
+    """Append the per-tensor maxima to gpurun_out/parity_report.jsonl (merged back from the GPU box): the numbers
+    DESIGN.md quotes for max_rel come from here."""
+    import json
+    import os
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
+            f.write(json.dumps({"where": where, "tensors": {k: {m: v[m] for m in ("scale", "q_rel", "max_rel", "outliers",
+                                                                                 "unexplained", "worst_ratio")}
+                                                             for k, v in rep.items()}}) + "\n")
+    except OSError:
+        pass

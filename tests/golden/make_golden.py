@@ -10,6 +10,9 @@ What is pinned here (reference code executed, CPU, float32):
                      backward (games/mesh_splatting/scene/gaussian_mesh_model.py:86-169),
                      incl. degenerate faces, negative _alpha / _scale entries
   k0_multi_mesh.npz  GaussianMultiMeshModel (games/multi_mesh_splatting/.../gaussian_multi_mesh_model.py:99-199)
+  k0_flame.npz       GaussianFlameModel.update_alpha + prepare_scaling_rot (games/flame_splatting/scene/
+                     gaussian_flame_model.py:123-207: softmax alpha, `_scales`, vertices from the FLAME layer -- stubbed
+                     by a layer returning given vertices -- through transform_vertices_function) and autograd backward
   stages.npz         eval_sh (utils/sh_utils.py:57), geom_transform_points (utils/graphics_utils.py:22),
                      build_covariance_from_scaling_rotation (scene/gaussian_model.py:27-31),
                      rot_to_quat_batch (utils/general_utils.py:43), getProjectionMatrix/getWorld2View2
@@ -71,6 +74,50 @@ def run_mesh_model(ref, vertices, faces, _alpha, _scale, seed):
         d_vertices=m.vertices.grad, d_alpha=m._alpha.grad, d_scale=m._scale.grad)
 
 
+class StubFlameLayer:
+    """Stands in for the licensed FLAME layer: returns the given vertices as [1,V,3] (what FLAME.forward returns,
+    games/flame_splatting/FLAME/FLAME.py) so the reference's GaussianFlameModel.update_alpha runs unmodified."""
+
+    def __init__(self, vertices):
+        self.vertices = vertices
+
+    def __call__(self, shape_params=None, expression_params=None, pose_params=None, neck_pose=None, transl=None):
+        return self.vertices[None] + 0.0 * transl.sum(), None
+
+
+def flame_transform(vertices, c=8):
+    """games/flame_splatting/scene/dataset_readers.py:41-46, restated without the in-place writes (same values)."""
+    v = torch.squeeze(vertices)
+    v = torch.stack([v[:, 0], -v[:, 2], v[:, 1]], dim=1)
+    return v * c
+
+
+def run_flame_model(ref, vertices, faces, _alpha, _scales, seed):
+    """GaussianFlameModel.update_alpha + prepare_scaling_rot (gaussian_flame_model.py:123-207) executed on CPU."""
+    from types import SimpleNamespace
+    m = ref.flame_model.GaussianFlameModel(3)
+    v0 = torch.nn.Parameter(vertices.clone())
+    m.point_cloud = SimpleNamespace(flame_model=StubFlameLayer(v0), transform_vertices_function=flame_transform)
+    m.faces = faces
+    z = lambda *s: torch.nn.Parameter(torch.zeros(*s))
+    m._flame_shape, m._flame_exp, m._flame_pose, m._flame_neck_pose, m._flame_trans = z(1, 4), z(1, 4), z(1, 6), z(1, 3), z(1, 3)
+    m._vertices_enlargement = torch.nn.Parameter(torch.full_like(vertices, 1.5))
+    m._alpha = torch.nn.Parameter(_alpha.clone())
+    m._scales = torch.nn.Parameter(_scales.clone())
+    m.update_alpha()
+    m.prepare_scaling_rot()
+    g = torch.Generator().manual_seed(seed + 100)
+    P = m._xyz.shape[0]
+    gx, gs, gr = (torch.randn(P, 3, generator=g), torch.randn(P, 3, generator=g), torch.randn(P, 4, generator=g))
+    loss = (m.get_xyz * gx).sum() + (m.get_scaling * gs).sum() + (m.get_rotation * gr).sum()
+    loss.backward()
+    return dict(
+        flame_vertices=vertices, faces=faces, _alpha=_alpha, _scales=_scales, enlargement=m._vertices_enlargement.detach(),
+        vertices=m.vertices.detach(), alpha=m.alpha.detach(), xyz=m._xyz.detach(), scaling=m._scaling.detach(),
+        rotation=m._rotation.detach(), g_xyz=gx, g_scaling_act=gs, g_rotation_act=gr,
+        d_flame_vertices=v0.grad, d_enlargement=m._vertices_enlargement.grad, d_alpha=m._alpha.grad, d_scales=m._scales.grad)
+
+
 def loss_fixture(ref):
     """Photometric loss: reference functions executed on CPU float32."""
     g = torch.Generator().manual_seed(21)
@@ -108,6 +155,11 @@ def main():
     np.savez_compressed(os.path.join(HERE, "k0_mesh.npz"), **tonp(run_mesh_model(ref, v, f, a, s, 0)))
     v, f, a, s = k0_inputs(1, 6, 7, 5, degenerate=False)
     np.savez_compressed(os.path.join(HERE, "k0_mesh_s5.npz"), **tonp(run_mesh_model(ref, v, f, a, s, 1)))
+
+    # ---- K0 FLAME variant: softmax alpha, vertices out of a (stubbed) FLAME layer + transform, `_scales`
+    v, f, a, s = k0_inputs(4, 6, 7, 4, degenerate=False)
+    a = 3.0 * (a - 0.5)                      # softmax inputs of both signs
+    np.savez_compressed(os.path.join(HERE, "k0_flame.npz"), **tonp(run_flame_model(ref, v, f, a, s, 4)))
 
     # ---- K0 multi mesh (two meshes, different splat counts)
     mm = ref.multi_mesh_model.GaussianMultiMeshModel(3)

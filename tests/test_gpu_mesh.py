@@ -30,6 +30,11 @@ def _close(a, b, rtol=2e-4, atol_rel=2e-5):
 
 @pytest.mark.parametrize("name", ["k0_mesh.npz", "k0_mesh_s5.npz"])
 def test_single_mesh_matches_reference_fixture(golden_dir, name):
+    """Forward AND backward against the reference-executed fixture.  k0_mesh.npz carries the edge cases of
+    gaussian_mesh_model.py:103-169: relu-clipped alpha rows, a negative `_scale` entry (all three scales collapse to eps,
+    zero gradient) and two degenerate faces (repeated vertex, point face).  Degenerate faces: the forward must give the
+    reference's own finite values; their gradients are compared everywhere except on the degenerate faces' own vertices /
+    splats, where the reference differentiates 0/0-type norms by torch's sub-gradient convention."""
     from games_hip.mesh_op import mesh_to_gaussians
     g = _load(golden_dir, name)
     v = g["vertices"].cuda().requires_grad_(True)
@@ -38,19 +43,177 @@ def test_single_mesh_matches_reference_fixture(golden_dir, name):
     alpha, xyz, scaling, rot = mesh_to_gaussians(v, g["faces"].cuda(), a, s, "relu")
     _close(alpha, g["alpha"], rtol=1e-6)
     _close(xyz, g["xyz"], rtol=1e-5)
-    # degenerate faces (zero area) give garbage-but-finite frames in the reference: exclude their splats
     tri = g["triangles"]
     area = torch.linalg.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).norm(dim=1)
     S = g["_alpha"].shape[1]
-    ok = (area > 1e-9).repeat_interleave(S)
+    okf = area > 1e-9                                   # non-degenerate faces
+    ok = okf.repeat_interleave(S)
     _close(scaling[ok.cuda()], g["scaling"][ok], rtol=1e-5)
     _close(rot[ok.cuda()], g["rotation"][ok], rtol=1e-4)
     assert torch.isfinite(rot).all() and torch.isfinite(scaling).all()
-    if ok.all():
-        _loss(xyz, scaling, rot, g, "cuda").backward()
-        _close(v.grad, g["d_vertices"])
-        _close(a.grad, g["d_alpha"])
-        _close(s.grad, g["d_scale"])
+    if not ok.all():
+        # degenerate faces: "the same finite values" as the reference.  log-scales sit at
+        # log(eps)-like values (-17..-18.4) where one float ulp of s*eps moves the log by ~1e-7 relative: abs tolerance
+        bad = ~ok
+        assert float((scaling[bad.cuda()].cpu() - g["scaling"][bad]).abs().max()) < 2e-2
+        _close(torch.exp(scaling[bad.cuda()]), torch.exp(g["scaling"][bad]), rtol=1e-3, atol_rel=1e-3)
+        point = (tri[:, 0] == tri[:, 1]).all(1) & (tri[:, 1] == tri[:, 2]).all(1)         # all three vertices equal
+        pt = point.repeat_interleave(S)
+        _close(rot[pt.cuda()], g["rotation"][pt], rtol=1e-5)        # zero frame -> quaternion (0.5, 0, 0, 0)
+    # negative _scale entries: relu(_scale * s) = 0 -> every log-scale = log(eps) exactly as the reference
+    neg = (g["_scale"][:, 0] < 0)
+    if neg.any():
+        assert torch.equal(scaling[neg.cuda()].cpu(), g["scaling"][neg])
+    _loss(xyz, scaling, rot, g, "cuda").backward()
+    assert torch.isfinite(v.grad).all() and torch.isfinite(a.grad).all() and torch.isfinite(s.grad).all()
+    touched = torch.zeros(g["vertices"].shape[0], dtype=torch.bool)
+    touched[g["faces"][~okf].reshape(-1)] = True        # vertices of degenerate faces
+    _close(v.grad.cpu()[~touched], g["d_vertices"][~touched])
+    _close(a.grad.cpu()[okf], g["d_alpha"][okf])
+    _close(s.grad.cpu()[ok], g["d_scale"][ok])
+    if neg.any():
+        assert float(s.grad.cpu()[neg].abs().max()) == 0.0 and float(g["d_scale"][neg].abs().max()) == 0.0
+    # d xyz / d alpha does not involve the frame: exact on degenerate faces too
+    if not okf.all():
+        _close(a.grad.cpu()[~okf], g["d_alpha"][~okf])
+
+
+def test_negative_and_zero_scale_backward_against_restatement():
+    """`_scale <= 0` rows (relu closes the gate: log(eps) forward, zero gradient) mixed with ordinary ones, both backward
+    paths (thread-per-face S=3, wave-per-face S=20)."""
+    from games_hip.mesh_op import mesh_to_gaussians
+    for S in (3, 20):
+        v, f = syn.uv_sphere(7, 9)
+        gen = torch.Generator().manual_seed(50 + S)
+        F = f.shape[0]
+        a = torch.rand(F, S, 3, generator=gen)
+        s = torch.exp(0.3 * torch.randn(F * S, 1, generator=gen))
+        s[::5] = -s[::5]
+        s[3::11] = 0.0
+        g = dict(g_xyz=torch.randn(F * S, 3, generator=gen), g_scaling_act=torch.randn(F * S, 3, generator=gen),
+                 g_rotation_act=torch.randn(F * S, 4, generator=gen))
+        vc, ac, sc = v.clone().requires_grad_(True), a.clone().requires_grad_(True), s.clone().requires_grad_(True)
+        _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vc, f, ac, sc, "relu")
+        _loss(xyz, scaling, rot, g, "cpu").backward()
+        vg, ag, sg = v.cuda().requires_grad_(True), a.cuda().requires_grad_(True), s.cuda().requires_grad_(True)
+        _, xyz_h, scaling_h, rot_h = mesh_to_gaussians(vg, f.cuda(), ag, sg, "relu")
+        _loss(xyz_h, scaling_h, rot_h, g, "cuda").backward()
+        closed = (s[:, 0] <= 0)
+        assert torch.equal(scaling_h.cpu()[closed], scaling.detach()[closed])
+        assert float(sg.grad.cpu()[closed].abs().max()) == 0.0 and float(sc.grad[closed].abs().max()) == 0.0
+        _close(scaling_h, scaling, rtol=1e-5); _close(vg.grad, vc.grad); _close(ag.grad, ac.grad); _close(sg.grad, sc.grad)
+
+
+def test_flame_mixin_matches_reference_fixture(golden_dir):
+    """HipFlameMixin on a host with the attributes of GaussianFlameModel (gaussian_flame_model.py:27-50): softmax alpha,
+    vertices out of the FLAME layer + transform_vertices_function, `_scales`; fixture = the reference class executed."""
+    from types import SimpleNamespace
+    from games_hip.model import HipFlameMixin
+    g = _load(golden_dir, "k0_flame.npz")
+
+    class Host(HipFlameMixin):
+        pass
+
+    def transform(vertices, c):                       # games/flame_splatting/scene/dataset_readers.py:41-46
+        vv = torch.squeeze(vertices)
+        return torch.stack([vv[:, 0], -vv[:, 2], vv[:, 1]], dim=1) * c
+    m = Host()
+    v0 = g["flame_vertices"].cuda().requires_grad_(True)
+    m.point_cloud = SimpleNamespace(flame_model=lambda **kw: (v0[None], None), transform_vertices_function=transform)
+    m.faces = g["faces"].cuda()
+    z = lambda *sh: torch.zeros(*sh, device="cuda")
+    m._flame_shape, m._flame_exp, m._flame_pose, m._flame_neck_pose, m._flame_trans = z(1, 4), z(1, 4), z(1, 6), z(1, 3), z(1, 3)
+    m._vertices_enlargement = g["enlargement"].cuda().requires_grad_(True)
+    m._alpha = g["_alpha"].cuda().requires_grad_(True)
+    m._scales = torch.empty(0)
+    m.update_alpha()                                   # create_from_pcd order: before `_scales` exists (:78-82)
+    _close(m.alpha, g["alpha"], rtol=1e-5); _close(m._xyz, g["xyz"], rtol=1e-5); _close(m.vertices, g["vertices"], rtol=1e-6)
+    m._scales = g["_scales"].cuda().requires_grad_(True)
+    m._opacity = torch.zeros(g["_scales"].shape[0], 1, device="cuda")
+    m.prepare_scaling_rot()
+    _close(m._scaling, g["scaling"], rtol=1e-5); _close(m._rotation, g["rotation"], rtol=1e-4)
+    m.update_alpha(); m.prepare_scaling_rot()          # the per-iteration order of train.py:154-157
+    _close(m._scaling, g["scaling"], rtol=1e-5); _close(m._rotation, g["rotation"], rtol=1e-4)
+    assert float((m.get_opacity - 0.5).abs().max()) < 1e-6
+    ((m.get_xyz if hasattr(m, "get_xyz") else m._xyz) * g["g_xyz"].cuda()).sum().backward(retain_graph=True)
+    ((m.get_scaling * g["g_scaling_act"].cuda()).sum() + (m.get_rotation * g["g_rotation_act"].cuda()).sum()).backward()
+    _close(v0.grad, g["d_flame_vertices"]); _close(m._vertices_enlargement.grad, g["d_enlargement"])
+    _close(m._alpha.grad, g["d_alpha"]); _close(m._scales.grad, g["d_scales"])
+
+
+def test_standalone_multi_mesh_and_flame_models_render_and_train_step():
+    """The stand-alone gs_multi_mesh / gs_flame hosts used by bench.py: one fwd+bwd through render() gives finite
+    gradients on every parameter, and the model-level outputs equal the restatement's."""
+    from games_hip.model import HipGaussianFlameModel, HipGaussianMultiMeshModel
+    from games_hip.render import PipelineParams, render
+    scenes = syn.multi_mesh_scenes("multi_tiny")
+    mm = HipGaussianMultiMeshModel.from_scenes(scenes, "cuda")
+    xyz_o, scaling_o, rot_o = mesh_oracle.multi_mesh_to_gaussians([s.vertices for s in scenes], [s.faces for s in scenes],
+                                                                  [s._alpha for s in scenes], [s._scale for s in scenes])
+    _close(mm.get_xyz, xyz_o, rtol=1e-5); _close(mm._scaling, scaling_o, rtol=1e-5); _close(mm._rotation, rot_o, rtol=1e-4)
+    fm = HipGaussianFlameModel.from_scene(syn.mesh_scene("tiny"), "cuda")
+    cam = syn.orbit_camera(1, width=64, height=64).to("cuda")
+    bg = torch.ones(3, device="cuda")
+    for model in (mm, fm):
+        model.update_alpha(); model.prepare_scaling_rot()
+        img = render(cam, model, PipelineParams(), bg)["render"]
+        assert torch.isfinite(img).all() and float((img - 1.0).abs().max()) > 0.05       # something was drawn
+        img.backward((img.detach() - 0.5) / img.numel())
+        for p in model.parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert float(fm._flame_exp.grad.abs().max()) > 0 and float(mm.vertices[1].grad.abs().max()) > 0
+
+
+def test_reference_call_order_save_dict_and_cache_invalidation(tmp_path):
+    """What the reference's own methods do to a model carrying HipMeshMixin: create_from_pcd calls
+    update_alpha() while `_scale` is still torch.empty(0) (gaussian_mesh_model.py:78-81); save_ply reads `triangles` out
+    of the instance __dict__ (:193-207); prepare_scaling_rot() alone after editing vertices / _scale must not serve the
+    values cached by the last update_alpha(); FusedAdam.step() must invalidate the fused opacity getter."""
+    from games_hip.model import HipMeshMixin
+    from games_hip.optim import FusedAdam
+    scene = syn.mesh_scene("tiny")
+
+    class Base:                                        # the slice of GaussianMeshModel.save_ply that matters here
+        def save_ply(self, path):
+            self.update_alpha(); self.prepare_scaling_rot()
+            attrs = self.__dict__
+            torch.save({k: attrs[k] for k in ("_alpha", "_scale", "triangles", "vertices", "faces")}, path)
+
+    class Host(HipMeshMixin, Base):
+        pass
+    m = Host()
+    m.triangles = None                                 # GaussianMeshModel.__init__ :47
+    m.vertices = torch.nn.Parameter(scene.vertices.cuda())
+    m.faces = scene.faces.cuda()
+    m._alpha = torch.nn.Parameter(scene._alpha.cuda())
+    m._scale = torch.empty(0)
+    m.update_alpha()                                   # :78, before _scale is set
+    _, _, xyz_o, scaling_o, rot_o = mesh_oracle.mesh_to_gaussians(scene.vertices, scene.faces, scene._alpha, scene._scale)
+    _close(m._xyz, xyz_o, rtol=1e-5)
+    m._scale = torch.nn.Parameter(scene._scale.cuda())
+    m.prepare_scaling_rot()                            # :82
+    m._opacity = torch.nn.Parameter(scene._opacity.cuda())
+    _close(m._scaling, scaling_o, rtol=1e-5); _close(m._rotation, rot_o, rtol=1e-4)
+    path = str(tmp_path / "model_params.pt")
+    m.save_ply(path)
+    saved = torch.load(path, weights_only=False)
+    assert torch.equal(saved["triangles"].cpu(), scene.vertices[scene.faces])
+    # stale-cache check: edit vertices and _scale in place, call ONLY prepare_scaling_rot()
+    with torch.no_grad():
+        m.vertices.mul_(torch.tensor([1.0, 1.4, 0.7], device="cuda"))
+        m._scale.mul_(1.3)
+    m.prepare_scaling_rot()
+    v2 = scene.vertices * torch.tensor([1.0, 1.4, 0.7])
+    _, _, _, scaling2, rot2 = mesh_oracle.mesh_to_gaussians(v2, scene.faces, scene._alpha, scene._scale * 1.3)
+    _close(m._scaling, scaling2, rtol=1e-5); _close(m._rotation, rot2, rtol=1e-4)
+    # FusedAdam writes through raw pointers: the fused get_opacity must notice
+    m.update_alpha(); m.prepare_scaling_rot()
+    before = m.get_opacity.clone()
+    opt = FusedAdam([{"params": [m._opacity], "lr": 0.5}], lr=0.0, eps=1e-15)
+    m._opacity.grad = torch.ones_like(m._opacity)
+    opt.step()
+    after = m.get_opacity
+    assert float((after - torch.sigmoid(m._opacity)).abs().max()) <= 2e-7 and float((after - before).abs().max()) > 0.05
 
 
 def test_multi_mesh_csr_matches_reference_fixture(golden_dir):
@@ -221,7 +384,7 @@ def test_checkpoint_roundtrip_in_the_reference_file_format(tmp_path):
     """save_ply / load_ply: point_cloud.ply with the reference's attribute list + model_params.pt."""
     from games_hip.model import HipGaussianMeshModel
     from games_hip.render import PipelineParams, render
-    from plyfile import PlyData
+    from games_hip._plyfile_compat import PlyData
     m = HipGaussianMeshModel.from_scene(syn.mesh_scene("tiny"), "cuda")
     path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
     m.save_ply(path)

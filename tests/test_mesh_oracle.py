@@ -50,6 +50,27 @@ def test_multi_mesh_matches_reference(golden_dir):
         torch.testing.assert_close(sc[i].grad, g[f"d_scale{i}"], rtol=1e-5, atol=1e-6)
 
 
+def test_flame_variant_matches_reference(golden_dir):
+    """softmax alpha + vertices through the FLAME transform (gaussian_flame_model.py:123-207), fixture = the reference's
+    GaussianFlameModel executed with a stubbed FLAME layer."""
+    g = _load(golden_dir, "k0_flame.npz")
+    v0 = g["flame_vertices"].clone().requires_grad_(True)
+    enl = g["enlargement"].clone().requires_grad_(True)
+    vv = torch.squeeze(v0[None])
+    verts = torch.stack([vv[:, 0], -vv[:, 2], vv[:, 1]], dim=1) * enl       # dataset_readers.py:41-46
+    a = g["_alpha"].clone().requires_grad_(True)
+    s = g["_scales"].clone().requires_grad_(True)
+    alpha, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(verts, g["faces"], a, s, "softmax")
+    assert torch.equal(verts.detach(), g["vertices"])
+    for got, key in ((alpha, "alpha"), (xyz, "xyz"), (scaling, "scaling"), (rot, "rotation")):
+        assert torch.equal(got.detach(), g[key]), key
+    _loss(xyz, scaling, rot, g).backward()
+    torch.testing.assert_close(v0.grad, g["d_flame_vertices"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(enl.grad, g["d_enlargement"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad, g["d_alpha"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(s.grad, g["d_scales"], rtol=1e-5, atol=1e-6)
+
+
 def test_quaternion_of_rotation_matches_reference(golden_dir):
     g = _load(golden_dir, "stages.npz")
     assert torch.equal(mesh_oracle.rot_to_quat_batch(g["R"]), g["quat_of_R"])

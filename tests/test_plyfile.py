@@ -1,4 +1,4 @@
-"""CPU: the `plyfile` stand-in (gaussian-mesh-splatting_amd/plyfile.py) on the reference's own call patterns
+"""CPU: the `plyfile` stand-in (gaussian-mesh-splatting_amd/games_hip/_plyfile.py) on the reference's own call patterns
 (scene/gaussian_model.py:194-268 save/load of a Gaussian cloud, scene/dataset_readers.py:107-130 fetchPly/storePly)
 and against hand-built PLY bytes (the format is the published PLY 1.0 layout)."""
 import io
@@ -6,7 +6,7 @@ import struct
 
 import numpy as np
 
-from plyfile import PlyData, PlyElement
+from games_hip._plyfile import PlyData, PlyElement
 
 
 def test_gaussian_cloud_roundtrip_with_the_reference_attribute_layout(tmp_path):
