@@ -22,8 +22,8 @@
 //            wave as ONE atomic instruction into the splat's 64-byte record.
 //
 // Inside a unit the splat records are gathered 256 at a time into an LDS queue; every wave tests
-// 64 queue entries at once against its quadrant (bounding box of the alpha >= 1/255 ellipse --
-// exact: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors,
+// 64 queue entries at once against its quadrant (exact ellipse-vs-rectangle test on the alpha >= 1/255
+// ellipse: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors,
 // NE (= 4) entries per trip: their alpha evaluations are independent, only the recurrence is serial.
 #include <stdlib.h>
 
@@ -48,12 +48,36 @@ __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u)
     return p;
 }
 
-__device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p)
+// Does any pixel centre of the wave's 8x8 quadrant see this splat with alpha >= 1/255?  Conservative (it may keep a
+// pair the per-pixel test skips, never the reverse):
+//   (1) bounding box of the {alpha >= 1/255} ellipse against the quadrant (rejects most far entries with 4 compares);
+//   (2) EXACT ellipse-vs-rectangle: the minimum over the rectangle of Q(d) = A dx^2 + 2 B dx dy + C dy^2 (convex: the
+//       centre if inside, else the best of the four edges' clamped 1-D minima) against 2 (ln(255 op) + 1e-3), which is
+//       ex^2 (A C - B^2) / C because ex^2 = 2 Sigma_xx (ln(255 op) + 1e-3) and Sigma_xx = C / det(conic).  Mesh-bound
+//       splats are flat and often diagonal on screen, where the box of the ellipse is loose.  The slack (1e-4 relative +
+//       0.01 absolute in Q, i.e. 0.005 in the exponent) covers the float error of both evaluations.
+__device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p, bool bbox_only = false)
 {
     if (j >= cnt) return false;
     const float4 q0 = recs[j].q0;
     const float4 q2 = recs[j].q2;
-    return !(q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1);
+    if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) return false;
+    if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
+    const float A = q0.z, B = q0.w, C = recs[j].q1.x;
+    const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
+    const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+    const float thr = q2.z * q2.z * (A * C - B * B) * iC;
+    const float B2 = 2.f * B;
+    float qmin;
+    {
+        const float ya = fminf(fmaxf(-B * dx0 * iC, dy0), dy1), yb = fminf(fmaxf(-B * dx1 * iC, dy0), dy1);
+        const float xa = fminf(fmaxf(-B * dy0 * iA, dx0), dx1), xb = fminf(fmaxf(-B * dy1 * iA, dx0), dx1);
+        const float e0 = dx0 * (A * dx0 + B2 * ya) + C * ya * ya, e1 = dx1 * (A * dx1 + B2 * yb) + C * yb * yb;
+        const float e2 = xa * (A * xa + B2 * dy0) + C * dy0 * dy0, e3 = xb * (A * xb + B2 * dy1) + C * dy1 * dy1;
+        qmin = fminf(fminf(e0, e1), fminf(e2, e3));
+    }
+    return qmin <= thr * 1.0001f + 0.01f;
 }
 
 // ------------------------------------------------------------------------------------ tloc
@@ -81,7 +105,7 @@ __device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *re
         // value: a quadrant whose pixels are all there (or outside the image) stops evaluating
         if (__all(Tl < T_MIN || !p.inside)) continue;
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
-            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)));
             while (mask) {
                 // NE queue entries per trip: independent alpha evaluations, sequential transmittance product
                 int k[NE]; bool val[NE]; float al[NE], pw[NE];
@@ -95,7 +119,7 @@ __device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *re
                 for (int e = 0; e < NE; e++) {
                     const float4 r0 = recs[k[e]].q0, r1 = recs[k[e]].q1;
                     const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-                    pw[e] = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+                    pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
                     al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
                 }
 #pragma unroll
@@ -155,7 +179,7 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
         const int cnt = (int)min((uint32_t)QUEUE, u.end - base);
         if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
-            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p));
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)));
             while (mask) {
                 // NE queue entries per trip: their alpha evaluations are independent (ILP hides the LDS and exp
                 // latency when few waves are resident); only the compositing recurrence is sequential
@@ -171,7 +195,7 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
                     const float4 r0 = recs[k[e]].q0;
                     r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
                     const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-                    pw[e] = -0.5f * (r0.z * dx * dx + r1[e].x * dy * dy) - r0.w * dx * dy;
+                    pw[e] = pair_power(r0.z, r0.w, r1[e].x, dx, dy);
                     al[e] = fminf(ALPHA_MAX, r1[e].y * __expf(pw[e]));
                 }
 #pragma unroll
@@ -421,7 +445,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
         if (m == 0) continue;                         // wave-uniform: quadrant has nothing in this unit
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
-            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
+            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
             if (dbg_on(g, 4u)) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
             while (mask) {
                 // NE queue entries per trip: loads, exp and the wave reductions of different entries are independent
@@ -438,7 +462,7 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
                     const float4 r0 = recs[k[e]].q0;
                     r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
                     dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
-                    const float pw = -0.5f * (r0.z * dx[e] * dx[e] + r1[e].x * dy[e] * dy[e]) - r0.w * dx[e] * dy[e];
+                    const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
                     G[e] = __expf(pw);
                     al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
                     const uint32_t pos = hi - 1 - (uint32_t)k[e];                  // 0-based tile position

@@ -89,6 +89,8 @@ def last_stats() -> dict:
     radii = d.pop("radii", None)
     if radii is not None:
         d["visible"] = int((radii > 0).sum())
+    d.pop("binning", None)
+    d.pop("geom", None)
     image = d.pop("image", None)
     if image is not None and image.numel():
         # sum over pixels of the 1-based list position of the last splat each pixel composited: the number of
@@ -209,7 +211,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
         _last_stats.update(num_rendered=int(num_rendered), num_units=int(num_units.value), capacity_hint=hint, P=P, width=W, height=H,
                            deepest_tile=int(lib.gms_last_deepest_tile()), radii=radii,
-                           image=scratch.tensors.get("image"))
+                           image=scratch.tensors.get("image"), binning=scratch.tensors.get("binning"),
+                           geom=scratch.tensors.get("geom"))
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)

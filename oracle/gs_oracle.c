@@ -79,6 +79,18 @@ static const real SH_C3[7] = {(real)-0.5900435899266435, (real)2.890611442640554
                               (real)-0.4570457994644658, (real)1.445305721320277,
                               (real)-0.5900435899266435};
 
+/* Exponent of the Gaussian at a pixel offset (dx, dy) for the conic (A, B, C), in ONE documented operation order
+ * shared by every consumer (forward walk, backward walk, and the HIP kernels' gms_blend.h::pair_power): two explicit
+ * FMAs, every other product rounded on its own.  The skip tests (power > 0, alpha < 1/255) are discrete decisions on
+ * this value: for elongated splats far from the pixel the three terms cancel (|term| ~ 10^3 for |power| ~ 5), so two
+ * evaluation orders can differ by 1e-4 in `power` -- enough to flip the 1/255 test.  A fixed order removes that. */
+static inline real pair_power(real A, real B, real C, real dx, real dy)
+{
+    const real a = A * dx, c = C * dy, b = B * dx;
+    const real s = R_FMA(a, dx, c * dy);
+    return R_FMA((real)-0.5, s, -(b * dy));
+}
+
 typedef struct {
     int P;              /* number of Gaussians */
     int D;              /* active SH degree 0..3 */
@@ -385,17 +397,36 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
                     uint32_t g = st->point_list[s];
                     real dx = st->xy[2 * (size_t)g] - (real)xx, dy = st->xy[2 * (size_t)g + 1] - (real)yy;
                     const real *co = st->conic_op + 4 * (size_t)g;
-                    real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    real power = pair_power(co[0], co[1], co[2], dx, dy);
                     inter += 1;
-                    if (R_FABS(power) < (real)1e-6) amb = 1;
+                    /* bit 0: the decision is within the rounding of exp() for IDENTICAL rasterizer inputs.
+                     * bit 1: it is within the rounding of the INPUTS: the three terms of `power` cancel for elongated
+                     * splats far from the pixel (|term| ~ 10^3 for |power| ~ 5), so a 1-ulp difference in the conic (two
+                     * float32 implementations of the mesh->Gaussian stage in front) moves `power` by ~eps * cond.  Only
+                     * comparisons whose inputs went through different float32 code in front use bit 1. */
+                    real cond = (real)0.5 * (R_FABS(co[0] * dx * dx) + R_FABS(co[2] * dy * dy)) + R_FABS(co[1] * dx * dy);
+                    real in_band = (real)8 * (real)6e-8 * cond;
+                    if (R_FABS(power) < (real)1e-6) amb |= 1;
+                    if (R_FABS(power) < (real)1e-6 + in_band) amb |= 2;
                     if (power > 0) continue;
                     real ex = R_EXP(power);
                     real araw = co[3] * ex;
                     real alpha = araw < ALPHA_MAX ? araw : ALPHA_MAX;
-                    if (R_FABS(araw * 255 - 1) < (real)4e-5) amb = 1;
+                    if (R_FABS(araw * 255 - 1) < (real)4e-5) amb |= 1;
+                    if (R_FABS(araw * 255 - 1) < (real)4e-5 + in_band) amb |= 2;
+                    if (R_FABS(araw * 255 - 1) < (real)4e-5 || R_FABS(power) < (real)1e-6) {
+                        /* gauss_ambig bit 1: this Gaussian has a (pixel, Gaussian) skip decision within exp() rounding:
+                         * an independent float32 implementation may include or drop that one pixel's term of its gradient */
+#pragma omp atomic
+                        st->gauss_ambig[g] |= 2;
+                    }
                     if (alpha < ALPHA_MIN) continue;
                     real testT = Tr * (1 - alpha);
-                    if (R_FABS(testT - T_MIN) < (real)1e-8) amb = 1;
+                    if (R_FABS(testT - T_MIN) < (real)1e-8) {
+                        amb |= 3;
+#pragma omp atomic
+                        st->gauss_ambig[g] |= 2;
+                    }
                     if (testT < T_MIN) break;
                     real w = alpha * Tr;
                     for (int c = 0; c < 3; c++) C[c] += st->rgb[3 * (size_t)g + c] * w;
@@ -414,6 +445,15 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
 }
 
 /* ----------------------------------------------------------------- backward */
+/* Accumulators of the per-(Gaussian, tile) gradient sums.  Default: double, so the float32 build's gradients carry only
+ * the per-term rounding (a clean reference value).  -DORACLE_FLOAT_ACCUM: `real`, i.e. float32 sums in a fixed order --
+ * what an implementation with float atomics (the reference's CUDA kernels, the HIP kernels) can be expected to reach
+ * on rows whose sums cancel; tests use |this build - float64 build| as the float32 noise scale of a row. */
+#ifdef ORACLE_FLOAT_ACCUM
+typedef real acc_t;
+#else
+typedef double acc_t;
+#endif
 /* per-instance gradient slots */
 enum { G_MX = 0, G_MY, G_CA, G_CB, G_CC, G_OP, G_R, G_G, G_B, G_ID, G_NUM };
 
@@ -427,7 +467,7 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
     set_threads(sc->nthreads);
     const int P = st->P, W = st->W, H = st->H, gx = st->gx;
     const long T = (long)gx * st->gy, N = st->N;
-    double *ginst = (double *)calloc((size_t)(N > 0 ? N : 1) * G_NUM, sizeof(double));
+    acc_t *ginst = (acc_t *)calloc((size_t)(N > 0 ? N : 1) * G_NUM, sizeof(acc_t));
 
     /* ---- A.4 per-tile back-to-front */
 #pragma omp parallel for schedule(dynamic, 1)
@@ -452,7 +492,7 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                     uint32_t g = st->point_list[s];
                     real dx = st->xy[2 * (size_t)g] - (real)xx, dy = st->xy[2 * (size_t)g + 1] - (real)yy;
                     const real *co = st->conic_op + 4 * (size_t)g;
-                    real power = (real)-0.5 * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    real power = pair_power(co[0], co[1], co[2], dx, dy);
                     if (power > 0) continue;
                     real Gv = R_EXP(power);
                     real araw = co[3] * Gv;
@@ -460,20 +500,20 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                     if (alpha < ALPHA_MIN) continue;
                     Tr = Tr / (1 - alpha);
                     real w = alpha * Tr;
-                    double *gi = ginst + (size_t)s * G_NUM;
+                    acc_t *gi = ginst + (size_t)s * G_NUM;
                     real dL_dalpha = 0;
                     for (int c = 0; c < 3; c++) {
                         real col = st->rgb[3 * (size_t)g + c];
                         accum[c] = last_alpha * last_col[c] + (1 - last_alpha) * accum[c];
                         last_col[c] = col;
                         dL_dalpha += (col - accum[c]) * dpix[c];
-                        gi[G_R + c] += (double)(w * dpix[c]);
+                        gi[G_R + c] += (acc_t)(w * dpix[c]);
                     }
                     real invd = 1 / st->depth[g];
                     accum_d = last_alpha * last_invd + (1 - last_alpha) * accum_d;
                     last_invd = invd;
                     dL_dalpha += (invd - accum_d) * dinvd;
-                    gi[G_ID] += (double)(w * dinvd);
+                    gi[G_ID] += (acc_t)(w * dinvd);
                     dL_dalpha *= Tr;
                     last_alpha = alpha;
                     dL_dalpha += (-Tfinal / (1 - alpha)) * bgdot;
@@ -482,19 +522,19 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                     real gdx = Gv * dx, gdy = Gv * dy;
                     real dG_ddx = -gdx * co[0] - gdy * co[1];
                     real dG_ddy = -gdy * co[2] - gdx * co[1];
-                    gi[G_MX] += (double)(dL_dG * dG_ddx * (real)0.5 * W);
-                    gi[G_MY] += (double)(dL_dG * dG_ddy * (real)0.5 * H);
-                    gi[G_CA] += (double)((real)-0.5 * gdx * dx * dL_dG);
-                    gi[G_CB] += (double)((real)-0.5 * gdx * dy * dL_dG);
-                    gi[G_CC] += (double)((real)-0.5 * gdy * dy * dL_dG);
-                    gi[G_OP] += (double)(Gv * dL_dalpha);
+                    gi[G_MX] += (acc_t)(dL_dG * dG_ddx * (real)0.5 * W);
+                    gi[G_MY] += (acc_t)(dL_dG * dG_ddy * (real)0.5 * H);
+                    gi[G_CA] += (acc_t)((real)-0.5 * gdx * dx * dL_dG);
+                    gi[G_CB] += (acc_t)((real)-0.5 * gdx * dy * dL_dG);
+                    gi[G_CC] += (acc_t)((real)-0.5 * gdy * dy * dL_dG);
+                    gi[G_OP] += (acc_t)(Gv * dL_dalpha);
                 }
             }
     }
 
     /* deterministic per-Gaussian reduction in sorted-instance order */
     size_t Pn = P > 0 ? (size_t)P : 1;
-    double *gacc = (double *)calloc(Pn * G_NUM, sizeof(double));
+    acc_t *gacc = (acc_t *)calloc(Pn * G_NUM, sizeof(acc_t));
     for (long s = 0; s < N; s++) {
         uint32_t g = st->point_list[s];
         for (int q = 0; q < G_NUM; q++) gacc[(size_t)g * G_NUM + q] += ginst[(size_t)s * G_NUM + q];
@@ -509,7 +549,7 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
     for (int i = 0; i < P; i++) {
         real dmean[3] = {0, 0, 0};
         real dcov3[6] = {0, 0, 0, 0, 0, 0};
-        const double *ga = gacc + (size_t)i * G_NUM;
+        const acc_t *ga = gacc + (size_t)i * G_NUM;
         if (dL_dmeans2D) { dL_dmeans2D[3 * (size_t)i] = (real)ga[G_MX]; dL_dmeans2D[3 * (size_t)i + 1] = (real)ga[G_MY]; dL_dmeans2D[3 * (size_t)i + 2] = 0; }
         if (dL_dconic_out) { dL_dconic_out[4 * (size_t)i] = (real)ga[G_CA]; dL_dconic_out[4 * (size_t)i + 1] = (real)ga[G_CB]; dL_dconic_out[4 * (size_t)i + 2] = 0; dL_dconic_out[4 * (size_t)i + 3] = (real)ga[G_CC]; }
         real dop = (real)ga[G_OP];

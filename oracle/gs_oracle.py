@@ -26,11 +26,11 @@ def build(force: bool = False) -> None:
     """Compile the C oracle (both precisions) with gcc."""
     out = os.path.join(_HERE, "_build")
     need = force or not all(
-        os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64")
+        os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc")
     )
     src = os.path.join(_HERE, "gs_oracle.c")
     if not need:
-        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64"))
+        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc"))
         need = os.path.getmtime(src) > newest
     if need:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
@@ -58,7 +58,7 @@ def _lib(precision: str):
     if precision not in _LIBS:
         build()
         lib = C.CDLL(os.path.join(_HERE, "_build", f"libgs_oracle_{precision}.so"))
-        real = C.c_float if precision == "f32" else C.c_double
+        real = C.c_double if precision == "f64" else C.c_float
         lib.or_forward.restype = C.c_void_p
         lib.or_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.or_backward.restype = None
@@ -133,7 +133,7 @@ def rasterize(*, means3D, opacities, shs=None, colors_precomp=None, scales=None,
               antialiasing=False, precision="f32", nthreads=0) -> OracleOutput:
     """Forward pass.  Array-likes are converted to contiguous numpy of the chosen precision."""
     lib, real, Scene = _lib(precision)
-    dt = np.float32 if precision == "f32" else np.float64
+    dt = np.float64 if precision == "f64" else np.float32       # "f32acc": float32 with float32 gradient accumulators
 
     def arr(a):
         if a is None:

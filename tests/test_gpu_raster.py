@@ -31,7 +31,8 @@ def _check(inputs, kw, W, H, gd=True, q=0.999):
     assert rep["max_invdepth_clean"] <= RGB_TOL, rep
     assert rep["max_amb"] <= 0.02, rep          # a flipped alpha>=1/255 decision moves a pixel by < 1/255 * max colour
     g = U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f64")["grads"], q=q,
-                       where=f"P={inputs['means3D'].shape[0]} {W}x{H}")
+                       where=f"P={inputs['means3D'].shape[0]} {W}x{H}", excuse=(o["details"]["gauss_ambig"] & 2) != 0,
+                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f32acc")["grads"])
     return h, o, rep, g
 
 
@@ -196,7 +197,8 @@ def test_full_size_parity_with_oracle_through_the_mesh_op():
     (pkg["render"] * gc.cuda()).sum().backward()
     h = dict(color=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(), invdepth=pkg["depth"].detach().cpu().numpy())
     ora = dict(color=o.color, radii=o.radii, invdepth=o.invdepth, details=o.state.details())
-    rep = U.forward_report(h, ora, 800, 800)
+    # each side ran its own float32 mesh->Gaussian stage: the rasterizer inputs differ by rounding (input_rounding=True)
+    rep = U.forward_report(h, ora, 800, 800, input_rounding=True)
     assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.02, rep
     assert rep["psnr"] > 60.0, rep
     gh = dict(vertices=model.vertices.grad, _alpha=model._alpha.grad, _scale=model._scale.grad, _opacity=model._opacity.grad,
@@ -282,7 +284,8 @@ def test_repeated_backward_reuses_the_rezeroed_gradient_records():
             h, ref = U.hip_render(inputs, kw, grad_color=-2.0 * gc, grad_invdepth=gdm), ref_b
         gc_w, gd_w = (gc, None) if which == "a" else (-2.0 * gc, gdm)
         U.assert_grads(h["grads"], ref["grads"], lambda: U.oracle_render(inputs, kw, gc_w, gd_w, precision="f64")["grads"],
-                       where=f"repeat {which}")
+                       where=f"repeat {which}", excuse=(ref["details"]["gauss_ambig"] & 2) != 0,
+                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc_w, gd_w, precision="f32acc")["grads"])
 
 
 @pytest.mark.parametrize("P", [9000, 30000])
@@ -373,62 +376,66 @@ def test_unit_count_overflow_reruns_with_full_size_launches():
     h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
     rep = U.forward_report(h, o, 416, 400)
     assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, rep
-    U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"], where="unit overflow")
+    U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"], where="unit overflow",
+                   excuse=(o["details"]["gauss_ambig"] & 2) != 0, go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, None, precision="f32acc")["grads"])
 
 
 def test_config5_size_parity_deep_tiles_two_phase_products():
     """BASELINE config 5 size: 997 600 mesh-bound Gaussians (FLAME-like F = 9 976 x S = 100), 1024x1024, ~12 M instances,
-    tiles up to ~30 k keys deep.  Exercises at full size what the toy scenes cannot: >= 2 multi-block merge-path sort
+    tiles up to ~26 k keys deep.  Exercises at full size what the toy scenes cannot: >= 2 multi-block merge-path sort
     passes, the two-phase transmittance products with the per-tile dead check (taken only when capacity > 2 L T) and
-    hundreds of segments per tile.  Image and all six parameter gradients against the OpenMP oracle chain."""
-    from games_hip.model import HipGaussianMeshModel
-    from games_hip.render import PipelineParams, render
-    from oracle import gs_oracle, mesh_oracle
-    import diff_gaussian_rasterization as dgr
+    dozens of segments per tile.  Stage by stage on IDENTICAL inputs:
+      (1) K0 at this size against the torch restatement;
+      (2) the rasterizer (image, radii, n_contrib-driven backward: gradients of all five inputs) against the OpenMP
+          oracle, both fed the RESTATEMENT's Gaussians -- frame 0 without history (synchronous sizes, one-block sort
+          fallback), frames 1-2 on the capacity / unit / sort-pass hints;
+      (3) K0 backward at this size with the oracle's rasterizer gradients as upstream."""
+    from diff_gaussian_rasterization import last_stats
+    from games_hip.mesh_op import mesh_to_gaussians
+    from oracle import mesh_oracle
     scene = syn.mesh_scene("c5_flame_like_1m", state="trained")
     size = scene.meta["image"]
-    cam_cpu = syn.orbit_camera(2, width=size, height=size)
+    cam = syn.orbit_camera(2, width=size, height=size)
     leaf = lambda t: t.clone().requires_grad_(True)
-    v, a, s, op_raw, fdc, frest = leaf(scene.vertices), leaf(scene._alpha), leaf(scene._scale), leaf(scene._opacity), leaf(scene._features_dc), leaf(scene._features_rest)
+    v, a, s = leaf(scene.vertices), leaf(scene._alpha), leaf(scene._scale)
     _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(v, scene.faces, a, s)
-    xyz_a, s_a, r_a, o_a, shs = mesh_oracle.activated(xyz, scaling, rot, op_raw, fdc, frest)
-    okw = {k: val for k, val in U.settings_kwargs(cam_cpu, torch.ones(3)).items() if k not in ("prefiltered", "debug")}
-    o = gs_oracle.rasterize(means3D=xyz_a, opacities=o_a, shs=shs, scales=s_a, rotations=r_a, **okw)
-    gc = syn.upstream_grad(torch.from_numpy(o.color)) * 1000.0
-    g = gs_oracle.backward(o, gc)
-    ((xyz_a * torch.from_numpy(g["means3D"])).sum() + (s_a * torch.from_numpy(g["scales"])).sum()
-     + (r_a * torch.from_numpy(g["rotations"])).sum() + (o_a * torch.from_numpy(g["opacities"])).sum()
-     + (shs * torch.from_numpy(g["sh"])).sum()).backward()
-    det = o.state.details()
+    xyz_a, s_a, r_a, o_a, shs = mesh_oracle.activated(xyz, scaling, rot, scene._opacity, scene._features_dc, scene._features_rest)
+    # (1) K0 forward
+    vg, ag, sg = scene.vertices.cuda().requires_grad_(True), scene._alpha.cuda().requires_grad_(True), scene._scale.cuda().requires_grad_(True)
+    _, xyz_h, scaling_h, rot_h, sact_h, runit_h = mesh_to_gaussians(vg, scene.faces.cuda(), ag, sg, "relu", fused_activations=True)
+    for got, ref, tol in ((xyz_h, xyz, 1e-5), (sact_h, s_a, 1e-5), (runit_h, r_a, 1e-4)):
+        d = (got.detach().cpu() - ref.detach()).abs()
+        assert float(d.max()) <= tol * float(ref.detach().abs().max()) + 1e-12
+    # (2) rasterizer on identical inputs
+    inputs = dict(means3D=xyz_a.detach(), opacities=o_a.detach(), shs=shs.detach(), scales=s_a.detach(), rotations=r_a.detach())
+    kw = U.settings_kwargs(cam, torch.ones(3))
+    o = U.oracle_render(inputs, kw)
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
+    o = U.oracle_render(inputs, kw, gc, None)
+    det = o["details"]
     depth = int((det["ranges"][:, 1] - det["ranges"][:, 0]).max())
     assert det["N"] > 2 * 256 * (size // 16) ** 2 and depth > 2 * 8192, (det["N"], depth)       # deep path + >= 2 merge-path passes
-    model = HipGaussianMeshModel.from_scene(scene, "cuda")
-    ora = dict(color=o.color, radii=o.radii, invdepth=o.invdepth, details=det)
-    for frame in range(3):          # frame 0: no history (synchronous sizes, one-block sort fallback); 1, 2: hints + merge-path passes
-        for p in model.parameters():
-            p.grad = None
-        model.update_alpha(); model.prepare_scaling_rot()
-        pkg = render(cam_cpu.to("cuda"), model, PipelineParams(), torch.ones(3, device="cuda"))
-        (pkg["render"] * gc.cuda()).sum().backward()
-        h = dict(color=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(), invdepth=pkg["depth"].detach().cpu().numpy())
-        rep = U.forward_report(h, ora, size, size)
-        assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.02 and rep["max_amb"] <= 0.02, (frame, rep)
-        assert dgr.last_stats()["num_rendered"] == det["N"]
-    gh = dict(vertices=model.vertices.grad, _alpha=model._alpha.grad, _scale=model._scale.grad, _opacity=model._opacity.grad,
-              f_dc=model._features_dc.grad, f_rest=model._features_rest.grad)
-    go = dict(vertices=v.grad, _alpha=a.grad, _scale=s.grad, _opacity=op_raw.grad, f_dc=fdc.grad, f_rest=frest.grad)
+    for frame in range(3):
+        h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
+        rep = U.forward_report(h, o, size, size)
+        assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.01 and rep["max_amb"] <= 0.02, (frame, rep)
+        assert last_stats()["num_rendered"] == det["N"]
+        U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"],
+                       where=f"c5_flame_like_1m {size}x{size} frame {frame}", excuse=(det["gauss_ambig"] & 2) != 0,
+                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, None, precision="f32acc")["grads"])
+        assert float(((det["gauss_ambig"] & 2) != 0).mean()) < 0.02
+    # (3) K0 backward at this size, upstream = the oracle's rasterizer gradients
+    og = o["grads"]
+    gx, gs, gr = (torch.from_numpy(og[k]) for k in ("means3D", "scales", "rotations"))
+    ((xyz_a * gx).sum() + (s_a * gs).sum() + (r_a * gr).sum()).backward()
+    ((xyz_h * gx.cuda()).sum() + (sact_h * gs.cuda()).sum() + (runit_h * gr.cuda()).sum()).backward()
 
-    def f64_chain():
+    def f64_k0():
         d = lambda t: t.detach().double().clone().requires_grad_(True)
-        v6, a6, s6, op6, fdc6, frest6 = d(scene.vertices), d(scene._alpha), d(scene._scale), d(scene._opacity), d(scene._features_dc), d(scene._features_rest)
+        v6, a6, s6 = d(scene.vertices), d(scene._alpha), d(scene._scale)
         _, _, xyz6, scaling6, rot6 = mesh_oracle.mesh_to_gaussians(v6, scene.faces, a6, s6)
-        xa, sa, ra, oa, sh6 = mesh_oracle.activated(xyz6, scaling6, rot6, op6, fdc6, frest6)
-        o6 = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=sh6, scales=sa, rotations=ra, precision="f64", **okw)
-        g6 = gs_oracle.backward(o6, gc.double())
-        ((xa * torch.from_numpy(g6["means3D"])).sum() + (sa * torch.from_numpy(g6["scales"])).sum()
-         + (ra * torch.from_numpy(g6["rotations"])).sum() + (oa * torch.from_numpy(g6["opacities"])).sum()
-         + (sh6 * torch.from_numpy(g6["sh"])).sum()).backward()
-        return dict(vertices=v6.grad.numpy(), _alpha=a6.grad.numpy(), _scale=s6.grad.numpy(), _opacity=op6.grad.numpy(),
-                    f_dc=fdc6.grad.numpy(), f_rest=frest6.grad.numpy())
-    U.assert_grads({k: t.cpu().numpy() for k, t in gh.items()}, {k: t.numpy() for k, t in go.items()}, f64_chain,
-                   where="c5_flame_like_1m 1024x1024 through K0")
+        ((xyz6 * gx.double()).sum() + (torch.exp(scaling6) * gs.double()).sum()
+         + (torch.nn.functional.normalize(rot6) * gr.double()).sum()).backward()
+        return dict(vertices=v6.grad.numpy(), _alpha=a6.grad.numpy(), _scale=s6.grad.numpy())
+    U.assert_grads(dict(vertices=vg.grad.cpu().numpy(), _alpha=ag.grad.cpu().numpy(), _scale=sg.grad.cpu().numpy()),
+                   dict(vertices=v.grad.numpy(), _alpha=a.grad.numpy(), _scale=s.grad.numpy()), f64_k0, where="K0 backward at c5 size")
