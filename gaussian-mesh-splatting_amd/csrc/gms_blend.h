@@ -61,8 +61,8 @@ inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_
 constexpr int QUEUE = GMS_QUEUE;   // LDS splat-queue entries per batch (<= BLOCK)
 constexpr int TLOC_HEAD = 4;       // segments whose transmittance products are always evaluated
 
-// Exponent of the Gaussian at a pixel offset, in the operation order documented in oracle/gs_oracle.c::pair_power
-// (two explicit FMAs, every other product rounded on its own, no contraction).  EVERY kernel that evaluates a
+// Exponent of the Gaussian at a pixel offset, in ONE documented operation order (discontinuity rule:
+// two explicit FMAs, every other product rounded on its own, no contraction; the CPU checker evaluates the same chain).  EVERY kernel that evaluates a
 // (pixel, splat) pair -- transmittance products, forward walk, backward walk -- goes through this one function, so the
 // discrete skip decisions (power > 0, alpha < 1/255) are bit-identical between them: a splat can never count for a
 // segment's transmittance product but not for its colour, or for the forward but not for the backward.
