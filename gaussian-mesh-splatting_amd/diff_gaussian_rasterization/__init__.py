@@ -30,7 +30,23 @@ import torch.nn as nn
 
 from . import _lib
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats", "SplitSH"]
+# Two bindings of the same C ABI (include/gmsplat.h, libgmsplat.so):
+#   `_C`     the PyTorch-ROCm extension module (csrc/torch_binding.cpp): upstream's three entry points plus the autograd
+#            node in C++ -- the default, one Python call per render;
+#   ctypes   `_lib.py`: the raw C ABI driven from Python (what INTEGRATION.md shows a maintainer), GMS_BINDING=ctypes.
+# Both reach the same kernels; neither has a CPU path.
+_BINDING = os.environ.get("GMS_BINDING", "auto")
+try:
+    if _BINDING == "ctypes":
+        raise ImportError("GMS_BINDING=ctypes")
+    from . import _C  # noqa: F401
+except ImportError as _e:          # not built (make -C csrc) or disabled: the ctypes binding serves every call
+    if _BINDING == "torch":
+        raise
+    _C = None
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats", "SplitSH",
+           "set_capacity_hint", "clear_capacity_hints"]
 
 
 class SplitSH:
@@ -82,10 +98,33 @@ _capacity_cache = {}
 _last_stats = {}
 
 
+def set_capacity_hint(device_index: int, width: int, height: int, P: int, value: int) -> None:
+    """Overwrite the learnt instance count the next forward of this (device, W, H, P) sizes its binning buffer from
+    (x1.25 + 4096); `value` < 0 forgets it.  Tests use it to force the overflow re-run."""
+    if _C is not None:
+        _C.set_capacity(int(device_index), int(width), int(height), int(P), int(value))
+    elif value < 0:
+        _capacity_cache.pop((device_index, width, height, P), None)
+    else:
+        _capacity_cache[(device_index, width, height, P)] = int(value)
+
+
+def clear_capacity_hints() -> None:
+    if _C is not None:
+        _C.clear_capacity()
+    _capacity_cache.clear()
+
+
+def raw_buffers() -> dict:
+    """The scratch tensors of the most recent forward (geom / binning / image byte buffers): diagnostics only."""
+    d = _C.last_stats() if _C is not None else _last_stats
+    return {k: d.get(k) for k in ("geom", "binning", "image")}
+
+
 def last_stats() -> dict:
     """Counters of the most recent forward call: num_rendered (N), capacity hint used, deepest_tile (instances in the
     deepest tile) and `visible` (Gaussians with radius > 0; computed on request: one device sync)."""
-    d = dict(_last_stats)
+    d = dict(_C.last_stats()) if _C is not None else dict(_last_stats)
     radii = d.pop("radii", None)
     if radii is not None:
         d["visible"] = int((radii > 0).sum())
@@ -130,9 +169,33 @@ class _Scratch:
         self.geom_cb, self.binning_cb, self.image_cb = make("geom"), make("binning"), make("image")
 
 
+_empties = {}
+
+
+def _empty(device):
+    e = _empties.get(device)
+    if e is None:
+        e = _empties[device] = torch.empty(0, device=device)
+    return e
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, visible_out=None):
     """`visible_out`: optional bool[P] tensor the preprocess kernel fills with radii > 0 (saves the elementwise pass)."""
+    if _C is not None:
+        rs = raster_settings
+        e = _empty(means3D.device)
+        rest = e
+        if isinstance(sh, SplitSH):
+            if sh.dc.shape[1] == 1 and sh.rest.shape[1] == 15 and sh.dc.is_cuda:
+                sh, rest = sh.dc, sh.rest
+            else:
+                sh = sh.full()
+        return _C.rasterize(means3D, means2D, sh, rest, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
+                            rs.viewmatrix, rs.projmatrix, rs.campos, int(rs.image_height), int(rs.image_width), float(rs.tanfovx),
+                            float(rs.tanfovy), float(rs.scale_modifier), int(rs.sh_degree), bool(rs.prefiltered),
+                            bool(rs.antialiasing), bool(rs.debug), visible_out if visible_out is not None else e,
+                            os.environ.get("GMS_SYNC_BINNING", "0") != "1")
     if isinstance(sh, SplitSH):
         if sh.dc.shape[1] == 1 and sh.rest.shape[1] == 15 and sh.dc.is_cuda:
             return _RasterizeGaussians.apply(means3D, means2D, sh.dc, colors_precomp, opacities, scales, rotations,
@@ -295,8 +358,11 @@ class GaussianRasterizer(nn.Module):
 
     def markVisible(self, positions: torch.Tensor) -> torch.Tensor:
         """bool[P]: Gaussian centre passes the near-plane test of the current camera."""
-        lib = _lib.load()
         rs = self.raster_settings
+        if _C is not None:
+            with torch.no_grad():
+                return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+        lib = _lib.load()
         _lib.require_gpu(positions)
         with torch.no_grad():
             pos = _f32c(positions)

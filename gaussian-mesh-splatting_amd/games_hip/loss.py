@@ -11,7 +11,16 @@ import ctypes as C
 
 import torch
 
+import diff_gaussian_rasterization as _dgr
 from diff_gaussian_rasterization import _lib
+
+
+def _weighted(img, gt, w_l1, w_ssim, bias):
+    if _dgr._C is not None:          # autograd node in C++ (csrc/torch_binding.cpp), same C ABI underneath
+        if img.shape != gt.shape:
+            raise ValueError(f"image shapes differ: {tuple(img.shape)} vs {tuple(gt.shape)}")
+        return _dgr._C.l1_ssim(img, gt, float(w_l1), float(w_ssim), float(bias))
+    return _WeightedL1Ssim.apply(img, gt, w_l1, w_ssim, bias)
 
 
 def _planes(img1, img2):
@@ -76,7 +85,7 @@ class _L1SsimLoss:
 
     def __call__(self, image, gt_image, lambda_dssim: float = 0.2):
         lam = float(lambda_dssim)
-        out = _WeightedL1Ssim.apply(image, gt_image, 1.0 - lam, -lam, lam)
+        out = _weighted(image, gt_image, 1.0 - lam, -lam, lam)
         self.last_l1, self.last_ssim = out[1].detach(), out[2].detach()
         return out[0]
 
@@ -90,9 +99,9 @@ def ssim(img1, img2, window_size=11, size_average=True):
         raise NotImplementedError("the HIP kernel is specialised for the reference's window_size=11")
     if not size_average:
         raise NotImplementedError("size_average=False is not used by the reference's training or metrics")
-    return _WeightedL1Ssim.apply(img1, img2, 0.0, 1.0, 0.0)[0]
+    return _weighted(img1, img2, 0.0, 1.0, 0.0)[0]
 
 
 def l1_loss(network_output, gt):
     """utils/loss_utils.py:17."""
-    return _WeightedL1Ssim.apply(network_output, gt, 1.0, 0.0, 0.0)[0]
+    return _weighted(network_output, gt, 1.0, 0.0, 0.0)[0]

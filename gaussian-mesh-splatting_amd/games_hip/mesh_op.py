@@ -145,6 +145,15 @@ def mesh_to_gaussians(vertices: torch.Tensor, faces: torch.Tensor, _alpha: torch
         spf = int(_alpha.shape[1])
     else:
         spf = 0
+    import diff_gaussian_rasterization as _dgr
+    if _dgr._C is not None:          # autograd node in C++ (csrc/torch_binding.cpp), same C ABI underneath
+        if _opacity is not None and not fused_activations:
+            raise ValueError("_opacity fusion needs fused_activations=True")
+        e = _dgr._empty(vertices.device)
+        return tuple(_dgr._C.mesh_to_gaussians(vertices, faces, _alpha, _scale, mode, spf,
+                                               face_splat_offset if face_splat_offset is not None else e,
+                                               splat_face if splat_face is not None else e, bool(fused_activations),
+                                               _opacity if _opacity is not None else e))
     return _MeshToGaussians.apply(vertices, faces, _alpha, _scale, mode, spf, face_splat_offset, splat_face,
                                   bool(fused_activations), _opacity)
 

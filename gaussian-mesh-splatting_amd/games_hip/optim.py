@@ -9,6 +9,7 @@ import ctypes as C
 
 import torch
 
+import diff_gaussian_rasterization as _dgr
 from diff_gaussian_rasterization import _lib
 
 
@@ -60,9 +61,14 @@ class FusedAdam(torch.optim.Optimizer):
                 lst = by_hyper.get(key)
                 if lst is None:
                     lst = by_hyper[key] = []
-                lst.append(_lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step)))
+                lst.append((p, g, m, v, lr, int(step)) if _dgr._C is not None else
+                           _lib.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, int(step)))
                 updated.append(p)
         for (device, beta1, beta2, eps), tensors in by_hyper.items():
+            if _dgr._C is not None:
+                ps, gs, ms, vs, lrs, steps = zip(*tensors)
+                _dgr._C.adam_step(list(ps), list(gs), list(ms), list(vs), list(lrs), list(steps), beta1, beta2, eps)
+                continue
             arr = (_lib.AdamTensor * len(tensors))(*tensors)
             with _lib.on_device(device):
                 rc = lib.gms_adam_step(arr, len(tensors), beta1, beta2, eps, C.c_void_p(_lib.stream_ptr(device)))

@@ -134,11 +134,11 @@ def test_capacity_hint_path_equals_sync_path_and_is_deterministic(monkeypatch):
     monkeypatch.setenv("GMS_SYNC_BINNING", "1")
     a = U.hip_render(_inputs(sc), kw, need_grad=False)
     monkeypatch.setenv("GMS_SYNC_BINNING", "0")
-    dgr._capacity_cache.clear()
+    dgr.clear_capacity_hints()
     b = U.hip_render(_inputs(sc), kw, need_grad=False)            # first call: no hint yet
     c = U.hip_render(_inputs(sc), kw, need_grad=False)            # second call: optimistic path
     assert dgr.last_stats()["capacity_hint"] > 0
-    dgr._capacity_cache[next(iter(dgr._capacity_cache))] = 10     # force an overflow + re-run
+    dgr.set_capacity_hint(0, 160, 160, 5000, 10)                  # force an overflow + re-run
     d = U.hip_render(_inputs(sc), kw, need_grad=False)
     for other in (b, c, d):
         assert np.array_equal(a["color"], other["color"]) and np.array_equal(a["radii"], other["radii"])
@@ -314,7 +314,8 @@ def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
 
 
 @pytest.mark.parametrize("env", [{"GMS_SEG_LEN": "128"}, {"GMS_SEG_LEN": "512"}, {"GMS_TRIP": "2", "GMS_TRIP_BWD": "2"},
-                                 {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}])
+                                 {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}, {"GMS_BINDING": "ctypes"},
+                                 {"GMS_BINDING": "ctypes", "GMS_SYNC_BINNING": "1"}])
 def test_tuning_knobs_do_not_change_results(env):
     """The knobs of INTEGRATION.md section 6 are read once per process: run the parity check in a child process per
     setting (segment lengths other than the default, 2-entry trips, no XCD run interleave, synchronous binning)."""
@@ -371,8 +372,7 @@ def test_unit_count_overflow_reruns_with_full_size_launches():
         U.hip_render(inputs, kw_far, need_grad=False)
     units_far = dgr.last_stats()["num_units"]
     assert units_near > 1.25 * units_far + 64 + 512, (units_near, units_far)      # more units than the padded optimistic launch
-    key = next(k for k in dgr._capacity_cache if k[1:] == (416, 400, 20000))
-    dgr._capacity_cache[key] = n_near                                 # the binning buffer itself is large enough
+    dgr.set_capacity_hint(0, 416, 400, 20000, n_near)                 # the binning buffer itself is large enough
     h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
     rep = U.forward_report(h, o, 416, 400)
     assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, rep
@@ -439,3 +439,36 @@ def test_config5_size_parity_deep_tiles_two_phase_products():
         return dict(vertices=v6.grad.numpy(), _alpha=a6.grad.numpy(), _scale=s6.grad.numpy())
     U.assert_grads(dict(vertices=vg.grad.cpu().numpy(), _alpha=ag.grad.cpu().numpy(), _scale=sg.grad.cpu().numpy()),
                    dict(vertices=v.grad.numpy(), _alpha=a.grad.numpy(), _scale=s.grad.numpy()), f64_k0, where="K0 backward at c5 size")
+
+
+def test_two_streams_interleaving_two_scene_sizes_match_the_serial_run():
+    """Library state that outlives a call (tile counters, capacity / unit / sort-pass hints) is keyed by (device, stream,
+    W, H, P): two torch streams in one process, each rendering its own scene (different P and image size) in alternation and
+    without synchronising in between, must give bit-identical images and radii to the same scenes rendered serially."""
+    cases = [(syn.random_scene(7000, seed=51, scale_lo=0.01, scale_hi=0.12), syn.orbit_camera(1, width=272, height=208, radius=2.8)),
+             (syn.random_scene(1800, seed=52, scale_lo=0.02, scale_hi=0.2), syn.orbit_camera(4, width=96, height=144, radius=3.2))]
+    kws = [U.settings_kwargs(cam, torch.tensor([0.1, 0.2, 0.3])) for _, cam in cases]
+    serial = [U.hip_render(_inputs(sc), kw, need_grad=False) for (sc, _), kw in zip(cases, kws)]
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    dev = torch.device("cuda")
+    tens, rss = [], []
+    for (sc, _), kw in zip(cases, kws):
+        tens.append({k: v.to(dev).float() for k, v in _inputs(sc).items()})
+        kwd = dict(kw)
+        for k in ("bg", "viewmatrix", "projmatrix", "campos"):
+            kwd[k] = kwd[k].to(dev).float()
+        rss.append(GaussianRasterizationSettings(**kwd))
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for rep in range(6):                                # frames 0: synchronous sizes; 1..: optimistic hints, all in flight
+        for k in (0, 1):
+            with torch.cuda.stream(streams[k]):
+                t = tens[k]
+                color, radii, _ = GaussianRasterizer(rss[k])(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]),
+                                                             opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+                outs[k].append((color, radii))
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for color, radii in outs[k]:
+            assert np.array_equal(color.cpu().numpy(), serial[k]["color"]) and np.array_equal(radii.cpu().numpy(), serial[k]["radii"])

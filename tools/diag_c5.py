@@ -43,13 +43,13 @@ for frame in range(3):
     tiles = np.unique((ys // 16) * gx + xs // 16)
     print("  bad tiles:", len(tiles), "depths:", sorted(depth[tiles].tolist())[-10:], "min depth", depth[tiles].min() if len(tiles) else None)
     # n_contrib / final_T
-    image_buf = dgr._last_stats["image"]; HW = size * size
+    image_buf = dgr.raw_buffers()["image"]; HW = size * size
     fT = image_buf[:4 * HW].view(torch.float32).cpu().numpy().reshape(size, size)
     off = al(HW * 4)
     nc = image_buf[off:off + 4 * HW].view(torch.int32).cpu().numpy().reshape(size, size)
     print("  n_contrib mismatch (clean px):", int(((nc != det["n_contrib"]) & ~amb).sum()), " final_T maxdiff clean:", float(np.abs(fT - det["final_T"])[~amb].max()))
     # sorted lists
-    binb = dgr._last_stats.get("binning")
+    binb = dgr.raw_buffers().get("binning")
     if binb is not None:
         toff_off = 2 * al(HW * 4) + 2 * al(T * 4)
         toff = image_buf[toff_off:toff_off + 4 * (T + 1)].view(torch.int32).cpu().numpy().astype(np.int64)
@@ -66,7 +66,7 @@ for frame in range(3):
                     first = int(np.nonzero(a != b)[0][0]) if len(a) == len(b) else -1
                     worst.append((int(t), int(depth[t]), first, bool(np.array_equal(np.sort(a), np.sort(b)))))
         print("  tiles with a list != oracle:", nbad_t, "examples (tile, depth, first diff pos, same multiset):", worst, flush=True)
-    geom = dgr._last_stats.get("geom")
+    geom = dgr.raw_buffers().get("geom")
     if geom is not None and frame == 0:
         P = scene.num_gaussians
         rec = geom[:48 * P].view(torch.float32).reshape(P, 12).cpu().numpy()
