@@ -49,8 +49,11 @@ def import_reference():
     for n in ("Struct", "to_tensor", "to_np", "rot_mat_to_euler"):
         setattr(sys.modules["smplx.utils"], n, None)
     if "diff_gaussian_rasterization" not in sys.modules:
-        _stub("diff_gaussian_rasterization", GaussianRasterizationSettings=None, GaussianRasterizer=None,
-              __games_stub__=True)
+        try:        # the drop-in itself when it is on sys.path (imports without a GPU); a name-only stub otherwise
+            import diff_gaussian_rasterization  # noqa: F401
+        except ImportError:
+            _stub("diff_gaussian_rasterization", GaussianRasterizationSettings=None, GaussianRasterizer=None,
+                  __games_stub__=True)
     import importlib
 
     ns = types.SimpleNamespace()
