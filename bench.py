@@ -481,9 +481,17 @@ def main():
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        final_line = json.dumps(out)
     if distributed:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio (flushed at exit): flush it first so that the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -79,6 +79,7 @@ using namespace gms;
 
 extern "C" int32_t gms_adam_step(const GmsAdamTensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream_)
 {
+    gms::TraceRange trace_range("gms_adam_step");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     if (count < 0 || (count > 0 && !tensors)) { set_error("gms_adam_step: invalid argument"); return GMS_ERR_INVALID_ARGUMENT; }

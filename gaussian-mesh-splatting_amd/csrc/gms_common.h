@@ -335,6 +335,9 @@ __device__ __forceinline__ float dot3p(float a, float b, float c, float d, float
 // thread-local error text for gms_last_error()
 void set_error(const char *fmt, ...);
 
+// ROCTX range around a C-ABI entry point (env GMS_ROCTX=1; profile.hip)
+struct TraceRange { bool on; explicit TraceRange(const char *name); ~TraceRange(); };
+
 // optional per-kernel event timing (profile.hip)
 extern bool g_profile_on;
 void profile_begin(int kernel_id, hipStream_t stream);

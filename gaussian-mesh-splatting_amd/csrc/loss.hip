@@ -234,6 +234,7 @@ extern "C" size_t gms_l1_ssim_partials(int32_t planes, int32_t height, int32_t w
 
 extern "C" int32_t gms_l1_ssim_forward(const GmsLossArgs *a, float *dmaps, float *partials, float *out, void *stream_)
 {
+    gms::TraceRange trace_range("gms_l1_ssim_forward");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     if (!loss_args_ok(a) || !out || !partials) { set_error("gms_l1_ssim_forward: invalid argument"); return GMS_ERR_INVALID_ARGUMENT; }
@@ -253,6 +254,7 @@ extern "C" int32_t gms_l1_ssim_forward(const GmsLossArgs *a, float *dmaps, float
 extern "C" int32_t gms_l1_ssim_backward(const GmsLossArgs *a, const float *dmaps, const float *dL_dvalue, float *dL_dimg,
                                         void *stream_)
 {
+    gms::TraceRange trace_range("gms_l1_ssim_backward");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     if (!loss_args_ok(a) || !dmaps || !dL_dimg) { set_error("gms_l1_ssim_backward: invalid argument"); return GMS_ERR_INVALID_ARGUMENT; }

@@ -445,6 +445,7 @@ extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *al
                                                  float *rotation, float *scaling_act, float *rotation_unit,
                                                  float *opacity_act, void *stream_)
 {
+    gms::TraceRange trace_range("gms_mesh_to_gaussians_forward");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     int32_t rc = check_mesh_args(A);
@@ -464,6 +465,7 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
                                                   float *dL_dvertices, float *dL_dalpha, float *dL_dscale,
                                                   float *dL_d_opacity, void *stream_)
 {
+    gms::TraceRange trace_range("gms_mesh_to_gaussians_backward");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     int32_t rc = check_mesh_args(A);

@@ -1,12 +1,49 @@
 // profile.hip -- opt-in per-kernel timing with HIP events recorded on the launch stream.
 // bench.py uses it to report each kernel's average launch duration next to its algorithmic
 // bytes (roofline), inside the same process and on the same stream that does the work.
+#include <dlfcn.h>
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
 #include "gms_common.h"
 
 namespace gms {
+
+// ---- ROCTX ranges (tracing): with GMS_ROCTX=1 every C-ABI entry point brackets its launches with
+// roctxRangePush / Pop, so a `rocprofv3 --marker-trace --kernel-trace` timeline groups the kernels by call
+// (rasterize_forward / rasterize_backward / mesh_to_gaussians_* / l1_ssim_* / adam_step).  libroctx64 is looked up at
+// run time; without the variable (or the library) the ranges cost one predictable branch.
+namespace {
+using RangePush = int (*)(const char *);
+using RangePop = int (*)();
+RangePush g_push = nullptr;
+RangePop g_pop = nullptr;
+int g_roctx_state = -1;        // -1 unknown, 0 off, 1 on
+bool roctx_on()
+{
+    if (g_roctx_state < 0) {
+        int st = 0;
+        const char *e = getenv("GMS_ROCTX");
+        if (e && atoi(e) != 0) {
+            void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                g_push = (RangePush)dlsym(h, "roctxRangePushA");
+                g_pop = (RangePop)dlsym(h, "roctxRangePop");
+                st = (g_push && g_pop) ? 1 : 0;
+            }
+        }
+        g_roctx_state = st;
+    }
+    return g_roctx_state == 1;
+}
+}  // namespace
+
+TraceRange::TraceRange(const char *name) : on(roctx_on()) { if (on) g_push(name); }
+TraceRange::~TraceRange() { if (on) g_pop(); }
 
 bool g_profile_on = false;
 

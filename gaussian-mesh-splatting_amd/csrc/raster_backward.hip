@@ -1,19 +1,21 @@
-// raster_backward.hip -- backward pass of the gfx950 Gaussian rasterizer.
+// raster_backward.hip -- backward pass of the gfx950 Gaussian rasterizer: the per-Gaussian stage and the C ABI entry.
 //
-//   K7  blend_bwd       one block (4 waves) per 16x16 tile, back-to-front over the tile's sorted
-//                       segment, same LDS splat queue + per-quadrant ballot cull as the forward.
-//                       Per (wave, splat) the ten partial gradients are summed over the 64 lanes
-//                       with DPP row operations (6 v_add_f32_dpp each) and leave the wave as ONE
-//                       hardware float atomic per value instead of 64 -- global float atomics are
-//                       the scarce resource on CDNA4, not VALU.
-//   K8+K9 preprocess_bwd 1 thread / Gaussian: conic -> cov2D -> (cov3D, mean) through the EWA
-//                       Jacobian, pixel mean -> world mean through the projection, inverse
-//                       depth, SH backward (coefficients staged in, gradients staged out through
-//                       the same LDS rows so both the 192-B read and the 192-B write per Gaussian
-//                       are coalesced float4 streams), cov3D -> scale / quaternion.
+//   K7  blend_bwd        (blend.hip) one block per (tile, segment) unit, back-to-front from the segment's end state; per
+//                        (wave, splat) ten partial sums -- five moments of q = dL/dG * G, sum q, three colour weights, the
+//                        inverse-depth weight -- leave the wave through a transposing DPP / permlane reduction as ONE
+//                        atomic instruction into the splat's 64-byte gradient record.
+//   K8+K9 preprocess_bwd 1 thread / Gaussian: reads the 64-byte record (and clears it), maps the moments to the gradients
+//                        of (pixel mean, conic, opacity) with per-Gaussian constants, then conic -> cov2D -> (cov3D, mean)
+//                        through the EWA Jacobian, pixel mean -> world mean through the projection, inverse depth, SH
+//                        backward (coefficients staged in, gradients staged out through the same LDS rows, so both the
+//                        192-B read and the 192-B write per Gaussian are coalesced float4 streams), cov3D -> scale /
+//                        quaternion.
 //
 // Gradient conventions: SURVEY.md appendix A.4/A.5 (straight-through alpha clamp, constant
-// skip tests, clamp masks, 1/(det^2+1e-7), NDC-scaled mean2D gradient).
+// skip tests, clamp masks, 1/(det^2+1e-7), NDC-scaled mean2D gradient).  Two forms are restated from the published
+// algorithm and cannot be checked against the CUDA binary (absent): the antialiasing backward (analytic derivative of
+// sqrt(det0/det)) and dL/dscale carrying the scale_modifier factor; both are inert in GaMeS training (antialiasing off,
+// modifier 1.0).  DESIGN.md section 2 lists them.
 #include "gms_blend.h"
 #include "gms_common.h"
 #include "gms_project.h"
@@ -383,6 +385,7 @@ using namespace gms;
 
 extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *stream_)
 {
+    gms::TraceRange trace_range("gms_rasterize_backward");
     hipStream_t stream = (hipStream_t)stream_;
     set_error("%s", "");
     if (!A || A->P < 0 || A->width <= 0 || A->height <= 0) {

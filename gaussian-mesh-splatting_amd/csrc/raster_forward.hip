@@ -996,6 +996,7 @@ extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 
 extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *stream_)
 {
+    gms::TraceRange trace_range("gms_rasterize_forward");
     hipStream_t stream = (hipStream_t)stream_;
     g_err[0] = 0;
     if (!A || A->P < 0 || A->width <= 0 || A->height <= 0 || !A->out_color || !A->out_invdepth || !A->background) {

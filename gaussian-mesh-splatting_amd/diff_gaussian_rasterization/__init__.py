@@ -179,9 +179,37 @@ def _empty(device):
     return e
 
 
+def _cpu_copy(x):
+    if torch.is_tensor(x):
+        return x.detach().cpu().clone()
+    if isinstance(x, SplitSH):
+        return (_cpu_copy(x.dc), _cpu_copy(x.rest))
+    if isinstance(x, tuple):
+        return tuple(_cpu_copy(v) for v in x)
+    return x
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings, visible_out=None):
-    """`visible_out`: optional bool[P] tensor the preprocess kernel fills with radii > 0 (saves the elementwise pass)."""
+    """`visible_out`: optional bool[P] tensor the preprocess kernel fills with radii > 0 (saves the elementwise pass).
+    With `raster_settings.debug` (pipe.debug, arguments/__init__.py:68) every kernel is followed by a sync + error check
+    and, as upstream does, a failing forward leaves its inputs in `snapshot_fw.dump` (torch.save of CPU copies)."""
+    if raster_settings.debug:
+        snapshot = _cpu_copy((means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                              tuple(raster_settings)))
+        try:
+            return _rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                        raster_settings, visible_out)
+        except Exception:
+            torch.save(snapshot, "snapshot_fw.dump")
+            print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise
+    return _rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                raster_settings, visible_out)
+
+
+def _rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                         raster_settings, visible_out=None):
     if _C is not None:
         rs = raster_settings
         e = _empty(means3D.device)
@@ -341,8 +369,15 @@ class _RasterizeGaussians(torch.autograd.Function):
             dL_dscales=_lib.ptr(dL_dscales),
             dL_drotations=_lib.ptr(dL_drot), grad_accum_rezero=1, num_units=ctx.num_units)
         if P > 0:
-            with _lib.on_device(device):
-                _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
+            try:
+                with _lib.on_device(device):
+                    _lib.check(lib.gms_rasterize_backward(C.byref(a), C.c_void_p(stream)), "gms_rasterize_backward")
+            except Exception:
+                if rs.debug:        # upstream: the inputs of a failing backward go to snapshot_bw.dump
+                    torch.save(_cpu_copy((means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, radii,
+                                          grad_color, tuple(rs))), "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise
         # only a call that completed hands its (re-zeroed) buffer back; a failed one lets it go
         if len(_accum_cache) >= 8:
             _accum_cache.clear()

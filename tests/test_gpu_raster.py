@@ -472,3 +472,20 @@ def test_two_streams_interleaving_two_scene_sizes_match_the_serial_run():
     for k in (0, 1):
         for color, radii in outs[k]:
             assert np.array_equal(color.cpu().numpy(), serial[k]["color"]) and np.array_equal(radii.cpu().numpy(), serial[k]["radii"])
+
+
+def test_debug_flag_dumps_the_inputs_of_a_failing_forward(tmp_path, monkeypatch):
+    """Upstream behaviour with pipe.debug: a failing forward leaves `snapshot_fw.dump` (CPU copies of its arguments)."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    monkeypatch.chdir(tmp_path)
+    sc, cam = syn.random_scene(300, seed=1), syn.orbit_camera(0, width=48, height=48)
+    kw = U.settings_kwargs(cam, torch.zeros(3), sh_degree=5)           # degree 5 needs 36 coefficients: rejected (16 stored)
+    kw["debug"] = True
+    for k in ("bg", "viewmatrix", "projmatrix", "campos"):
+        kw[k] = kw[k].cuda().float()
+    t = {k: v.cuda().float() for k, v in _inputs(sc).items()}
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(GaussianRasterizationSettings(**kw))(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]),
+                                                                opacities=t["opacities"], shs=t["shs"], scales=t["scales"], rotations=t["rotations"])
+    snap = torch.load(str(tmp_path / "snapshot_fw.dump"), weights_only=False)
+    assert torch.equal(snap[0], sc.means3D) and snap[8][8] == 5

@@ -1,12 +1,14 @@
 #!/usr/bin/env python
 """profiles/pmc_traffic.json from a collect_profiles.sh traffic summary.
-usage: make_pmc_traffic.py <summary_traffic.json> <workload/state> [profiles/pmc_traffic.json]"""
+usage: make_pmc_traffic.py <summary_traffic.json> <workload/state> [profiles/pmc_traffic.json] [blend_stats.json]
+The optional blend_stats.json (tools/blend_stats.py, CPU) adds the active (pixel, splat) pair count of the workload."""
 import json
 import os
 import sys
 
 src, key = sys.argv[1], sys.argv[2]
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+stats_path = sys.argv[4] if len(sys.argv) > 4 else None
+dst = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 t = json.load(open(src))
 names = {"preprocess_fwd": ["preprocess_fwd"], "tile_scan": ["tile_scan"], "emit_instances": ["emit_instances"],
          "tile_sort": ["tile_presort", "tile_merge"], "blend_head": ["blend_head"], "blend_fwd": ["blend_fwd"],
@@ -17,6 +19,22 @@ for k, srcs in names.items():
     vals = [t[s]["hbm_bytes_corrected"] for s in srcs if s in t]
     if vals:
         out[k] = int(sum(vals) / len(vals))      # per launch (tile_sort = mean of its two launches)
+# SQ counters (wave-instruction counts, mean per dispatch) for the VALU roofline of the compositing kernels
+sqo = {}
+for k, srcs in names.items():
+    for s_ in srcs:
+        if s_ in t and "sq" in t[s_]:
+            sqo[k] = {c: round(v) for c, v in t[s_]["sq"].items()}
+            break
+if stats_path and os.path.exists(stats_path):
+    st = json.load(open(stats_path))
+    pairs = st["active_pairs_per_instance"] * st["N_total"]
+    for k in ("blend_bwd", "blend_head", "blend_fwd"):
+        if k in sqo:
+            sqo[k]["active_pairs"] = round(pairs)
+            if sqo[k].get("SQ_INSTS_VALU"):
+                sqo[k]["active_lane_frac"] = round(st["blocks"]["8x8"]["active_lane_frac_exact"], 3)
+out["_sq"] = sqo
 allj = json.load(open(dst)) if os.path.exists(dst) else {}
 allj[key] = out
 allj["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->bytes) from separate rocprofv3 --pmc passes; "

@@ -37,11 +37,15 @@ def main(d, out):
     # counts wide coalesced reads at half their size (MI355X_MICROARCH.md, HBM section): both the raw and
     # the corrected (2x fetch) totals are reported.
     traffic = {}
+    sq = {}
     for f in sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"]).split("<")[0].replace("_kernel", "")
+            if r["Counter_Name"].startswith("SQ_"):
+                a = sq.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
+                a[0] += float(r["Counter_Value"]); a[1] += 1
             if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
-            k = short(r["Kernel_Name"]).split("<")[0].replace("_kernel", "")
             t = traffic.setdefault(k, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
             t[r["Counter_Name"]][0] += float(r["Counter_Value"]); t[r["Counter_Name"]][1] += 1
     if traffic:
@@ -51,6 +55,8 @@ def main(d, out):
             fe = t["FETCH_SIZE"][0] / max(t["FETCH_SIZE"][1], 1) * 1024
             wr = t["WRITE_SIZE"][0] / max(t["WRITE_SIZE"][1], 1) * 1024
             js[k] = {"fetch_bytes_raw": round(fe), "write_bytes": round(wr), "hbm_bytes_corrected": round(2 * fe + wr)}
+            if k in sq:
+                js[k]["sq"] = {c: v[0] / max(v[1], 1) for c, v in sq[k].items()}      # mean per dispatch
         open(os.path.splitext(out)[0] + "_traffic.json", "w").write(json.dumps(js, indent=1, sort_keys=True))
     open(out, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[:80]))
