@@ -165,6 +165,10 @@ def parse_args(argv=None):
                     help="views each rank renders (fwd+bwd) per step, gradients accumulated before the ONE all-reduce of the step. "
                          "The headline is 1 at every N (config 4: one view per GPU per step); on several GPUs the 4-view amortised "
                          "figure is measured too and reported under `amortised`")
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "ring", "direct"],
+                    help="how the large (SH) gradient is reduced on several GPUs: ring = one all_reduce (RCCL's choice of algorithm), "
+                         "direct = two all-to-all phases over all xGMI links at once (games_hip.ddp.DirectAllReduce); auto times both "
+                         "on gradient-sized buffers before the timed region and takes the faster one (both times are reported)")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -245,7 +249,7 @@ def main():
 
     from diff_gaussian_rasterization import _lib, last_stats
     from games_hip import synthetic as syn
-    from games_hip.ddp import OverlappedGradAllReduce
+    from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce
     from games_hip.render import PipelineParams, render
 
     workload = args.workload or ("c2_hotdog_like" if world == 1 else "c4_ficus_like")
@@ -264,6 +268,52 @@ def main():
         model.training_setup(vertices_lr=1e-12, alpha_lr=1e-12, feature_lr=1e-12, opacity_lr=1e-12, scaling_lr=1e-12,
                              fused=args.optimizer == "fused_adam")
 
+    def sync():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    # ---- several ranks: which collective for the large gradient (timed on gradient-sized buffers, outside the timed region)
+    algo, allreduce_times = "ring", {}
+    if distributed:
+        big = [torch.zeros_like(p) for p in params if p.numel() >= (1 << 22)]
+        small_n = sum(p.numel() for p in params if p.numel() < (1 << 22))
+        flat = torch.zeros(max(small_n, 1), device=device)
+
+        def collectives_once(which):
+            works, ds = [], []
+            for b in big:
+                if which == "direct" and world > 1:
+                    d = DirectAllReduce(world)
+                    d.start(b)
+                    ds.append(d)
+                else:
+                    works.append(dist.all_reduce(b, async_op=True))
+            works.append(dist.all_reduce(flat, async_op=True))
+            for w in works:
+                w.wait()
+            for d in ds:
+                d.finish()
+
+        for which in (("ring", "direct") if args.allreduce == "auto" else (args.allreduce,)):
+            try:
+                for _ in range(3):
+                    collectives_once(which)
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    collectives_once(which)
+                sync()
+                t = torch.tensor([(time.perf_counter() - t0) / 10], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                allreduce_times[which] = round(1000 * float(t.item()), 4)
+            except Exception as e:  # noqa: BLE001 - an algorithm the backend cannot run is simply not chosen
+                allreduce_times[which] = f"failed: {e!r}"[:200]
+        ok = {k: v for k, v in allreduce_times.items() if isinstance(v, float)}
+        algo = min(ok, key=ok.get) if ok else "ring"
+        allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
+        del big, flat
+
     def make_step(vps, reduce_grads):
         """One step = K0 forward (once: the parameters are the same for all its views) + vps x (render fwd + bwd) on this rank's
         views + [reduce_grads] ONE gradient all-reduce.  Rank r renders cameras (r*vps + v) % 8 (config 4: 8 views)."""
@@ -272,7 +322,7 @@ def main():
         # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
         inv_norm = 1.0 / (3.0 * size * size * vps * world)
         neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
-        reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp) if (reduce_grads and distributed) else None
+        reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed) else None
 
         def step():
             model.update_alpha()
@@ -296,11 +346,6 @@ def main():
                 for p in params:
                     p.grad = None
         return step, reducer
-
-    def sync():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(device)
 
     def timed(step, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
@@ -373,19 +418,10 @@ def main():
                                   "ms_per_step": round(1000 * el_am / max(1, args.steps // 2), 4)}
             r_am.remove()
         # (c) the collectives alone on gradient-sized buffers (one large + one flat bucket, as the reducer issues them)
-        big = [torch.zeros_like(p) for p in params if p.numel() >= (1 << 22)]
-        small_n = sum(p.numel() for p in params if p.numel() < (1 << 22))
-        flat = torch.zeros(max(small_n, 1), device=device)
-        sync()
-        t0 = time.perf_counter()
-        reps = 10
-        for _ in range(reps):
-            works = [dist.all_reduce(b, async_op=True) for b in big] + [dist.all_reduce(flat, async_op=True)]
-            for w in works:
-                w.wait()
-        sync()
-        extra["allreduce_ms"] = round(1000 * (time.perf_counter() - t0) / reps, 4)
-        extra["allreduce_bytes"] = 4 * (sum(b.numel() for b in big) + flat.numel())
+        extra["allreduce_ms"] = allreduce_times.get(algo)
+        extra["allreduce_algorithms_ms"] = allreduce_times
+        extra["allreduce_algorithm"] = algo
+        extra["allreduce_bytes"] = allreduce_bytes
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)

@@ -27,8 +27,10 @@ bool roctx_on()
         int st = 0;
         const char *e = getenv("GMS_ROCTX");
         if (e && atoi(e) != 0) {
-            void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
-            if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+            // rocprofv3 (rocprofiler-sdk) records the ranges of its own ROCTX library; the roctracer-era libroctx64 is the fallback
+            void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("/opt/rocm/lib/librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
             if (!h) h = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
             if (h) {
                 g_push = (RangePush)dlsym(h, "roctxRangePushA");

@@ -42,6 +42,50 @@ def allreduce_gradients(params: Iterable[torch.Tensor], world: int, average: boo
         torch._foreach_div_(grads, float(world))
 
 
+class DirectAllReduce:
+    """Sum all-reduce of ONE large contiguous tensor as two all-to-all phases, shaped for a FULLY CONNECTED xGMI node.
+
+    A ring all-reduce pushes 2 (W-1)/W of the message through one link per GPU, hop after hop (64 MB on 8 GPUs: 112 MB over a
+    153 GB/s link, ~0.7 ms).  xGMI gives every GPU a dedicated link to each of its 7 peers, so the textbook direct algorithm
+    uses all of them at once:
+        phase 1  all-to-all: shard j of my buffer goes to rank j (W-1 transfers of n/W elements, one per link);
+                 I then sum the W shards I hold -- my slice of the result -- in one local pass;
+        phase 2  all-to-all again: my reduced slice goes to every peer (one per link), theirs come to me.
+    Each link carries 2 n/W elements in total instead of 2 (W-1) n/W: 7x less per link on 8 GPUs.  Both phases are
+    `all_to_all_single` (grouped point-to-point sends in RCCL).  `start()` launches phase 1 asynchronously (from the autograd
+    hook, while the rest of the backward still runs); `finish()` does the local sum and phase 2 and leaves the result in the
+    caller's tensor.  Tested against `all_reduce` with gloo, world size 2 and 3, sizes not divisible by the world size."""
+
+    def __init__(self, world: int, group=None):
+        self.world, self.group = world, group
+        self._pending = None
+
+    def start(self, t: torch.Tensor):
+        assert t.is_contiguous()
+        flat = t.view(-1)
+        n, W = flat.numel(), self.world
+        shard = (n + W - 1) // W
+        if shard * W != n:                       # pad to a multiple of the world size (rare: 45 P is divisible by 8 for even P)
+            send = torch.zeros(shard * W, dtype=flat.dtype, device=flat.device)
+            send[:n] = flat
+        else:
+            send = flat
+        recv = torch.empty_like(send)
+        work = dist.all_to_all_single(recv, send, group=self.group, async_op=True)
+        self._pending = (flat, n, shard, recv, work)
+
+    def finish(self):
+        flat, n, shard, recv, work = self._pending
+        self._pending = None
+        W = self.world
+        work.wait()
+        mine = recv.view(W, shard).sum(dim=0)                    # my slice of the result
+        out = torch.empty(W * shard, dtype=flat.dtype, device=flat.device) if shard * W != n else flat
+        dist.all_to_all_single(out, mine.repeat(W), group=self.group)        # my slice to everyone, everyone's to me
+        if out is not flat:
+            flat.copy_(out[:n])
+
+
 class OverlappedGradAllReduce:
     """Gradient all-reduce driven by post-accumulate-grad hooks, shaped for RCCL over xGMI:
 
@@ -60,9 +104,14 @@ class OverlappedGradAllReduce:
     with torch's DistributedDataParallel) so that the collectives start once, on the accumulated gradients."""
 
     def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22,
-                 force: bool = False):
+                 force: bool = False, algorithm: str = "ring"):
+        """`algorithm`: how a LARGE gradient is reduced -- "ring" = one `all_reduce` (RCCL picks its algorithm), "direct" =
+        two all-to-all phases over all xGMI links at once (DirectAllReduce).  The flat bucket of small gradients always uses
+        `all_reduce` (latency bound)."""
         self.params = [p for p in params]
         self.world, self.average, self.big_numel = world, average, int(big_numel)
+        self.algorithm = algorithm
+        self._direct = []
         self._works, self._big, self._small, self._handles = [], [], [], []
         self._enabled = True
         # `force`: run the collectives even in a world of one (exercises the backend on a single GPU)
@@ -85,7 +134,12 @@ class OverlappedGradAllReduce:
             return
         if g.numel() >= self.big_numel and g.is_contiguous():
             self._big.append(g)
-            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            if self.algorithm == "direct" and self.world > 1:
+                d = DirectAllReduce(self.world)
+                d.start(g)
+                self._direct.append(d)
+            else:
+                self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
         else:
             self._small.append(p)
 
@@ -97,6 +151,9 @@ class OverlappedGradAllReduce:
             self._works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in self._works:
             w.wait()
+        for d in self._direct:
+            d.finish()
+        self._direct = []
         if self.average:
             scaled = self._big + ([flat] if flat is not None else [])
             if scaled:

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from games_hip.ddp import OverlappedGradAllReduce, allreduce_gradients, shard_views
+from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce, allreduce_gradients, shard_views
 
 
 def _free_port():
@@ -116,3 +116,52 @@ def test_single_process_is_a_no_op():
     p.grad = torch.ones(3)
     allreduce_gradients([p], 1)
     assert torch.equal(p.grad, torch.ones(3))
+
+
+def _direct_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = True
+        for n in (24, 25, 1000, 4097):                              # divisible and not divisible by the world size
+            x = torch.randn(n, generator=torch.Generator().manual_seed(10 * n + rank))
+            ref = x.clone()
+            dist.all_reduce(ref)
+            y = x.clone().view(-1)
+            d = DirectAllReduce(world)
+            d.start(y)
+            d.finish()
+            ok = ok and torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
+        # through the hook-driven reducer: the large gradient takes the direct path, the small ones the flat bucket
+        params = [torch.randn(s_, generator=torch.Generator().manual_seed(5)).requires_grad_(True) for s_ in ((64, 15, 3), (64, 1), (10, 3))]
+        local = [torch.randn(p.shape, generator=torch.Generator().manual_seed(70 + rank + k)) for k, p in enumerate(params)]
+        red = OverlappedGradAllReduce(params, world, average=True, big_numel=1000, algorithm="direct")
+        sum((p * l).sum() for p, l in zip(params, local)).backward()
+        red.finish()
+        red.remove()
+        q.put((rank, ok, [l.numpy().copy() for l in local], [p.grad.numpy().copy() for p in params]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_direct_two_phase_allreduce_equals_allreduce():
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+        finally:
+            for p in procs:
+                p.join(timeout=120)
+                if p.is_alive():
+                    p.kill()
+        assert all(p.exitcode == 0 for p in procs) and all(r[1] for r in res)
+        for k in range(3):
+            mean = sum(torch.from_numpy(r[2][k]) for r in res) / world
+            for r in res:
+                torch.testing.assert_close(torch.from_numpy(r[3][k]), mean, rtol=1e-5, atol=1e-6)
