@@ -69,11 +69,12 @@ struct ImageState {
     uint32_t *class_first;  // [8][T+1] exclusive scans per dispatch class (full, 4 partial size classes, empty), of the
                             //          1024-key sort runs of every tile (row 6) and of the tiles with more than one run (row 7)
     uint32_t *tile_dead;    // [T]     all pixels of the tile finished within the first few segments
+    uint32_t *scan_out;     // [4]     {N, deepest tile, work units} of this frame, for the launch that publishes them to the host
     static __host__ __device__ size_t bytes(size_t W, size_t H)
     {
         size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + 3 * align_up((T + 1) * 4, 256) +
-               align_up(8 * (T + 1) * 4, 256) + align_up(T * 4, 256);
+               align_up(8 * (T + 1) * 4, 256) + align_up(T * 4, 256) + 256;
     }
     static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
     {
@@ -88,7 +89,8 @@ struct ImageState {
         s.unit_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
         s.mseg_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
         s.class_first = (uint32_t *)p; p += align_up(8 * (T + 1) * 4, 256);
-        s.tile_dead = (uint32_t *)p;
+        s.tile_dead = (uint32_t *)p;   p += align_up(T * 4, 256);
+        s.scan_out = (uint32_t *)p;
         return s;
     }
 };

@@ -396,12 +396,25 @@ __device__ __forceinline__ void tile_terms(uint32_t c, uint32_t L, uint32_t t[NS
     (void)sort_np;
 }
 
+// The instance count N goes straight to the host: system-scope stores into pinned memory that the waiting host thread
+// polls -- no copy-engine hop, no event wake-up latency.  Three self-tagged 64-bit words {call sequence number : value}:
+// each is ONE relaxed system-scope store, so no release fence (= write-back of the XCD's dirty L2 lines) is needed to order
+// a value before its flag.
+__device__ __forceinline__ void publish_counts(int32_t *host_slot, int32_t seq, uint32_t n, uint32_t deepest, uint32_t units)
+{
+    unsigned long long *hs = reinterpret_cast<unsigned long long *>(host_slot);
+    const unsigned long long tag = (unsigned long long)(uint32_t)seq << 32;
+    __hip_atomic_store(&hs[2], tag | units, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&hs[1], tag | deepest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&hs[0], tag | n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // One block of 1024 threads: NSCAN exclusive scans over the tiles at once.  Each wave scans its 64 per-thread
 // sums with DPP-free shuffles, the 16 wave totals are scanned by the first wave: two block barriers in all.
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count, uint32_t *offset, uint32_t *cursor,
                                                                  uint32_t *unit_first, uint32_t *mseg_first,
                                                                  uint32_t *class_first, int T, uint32_t L, int32_t *host_slot,
-                                                                 int32_t seq, int sort_np)
+                                                                 int32_t seq, int sort_np, uint32_t *scan_out)
 {
     __shared__ uint32_t wave_tot[NSCAN][SCAN_THREADS / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -452,16 +465,14 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
     }
     // The instance count N goes straight to the host: two system-scope stores into pinned memory (value, then the
     // call's sequence number) that the waiting host thread polls -- no copy-engine hop, no event wake-up latency.
-    if (tid == 0 && host_slot) {
+    if (tid == 0) {
         uint32_t dm = 0;
         for (int w = 0; w < SCAN_THREADS / WAVE; w++) dm = max(dm, wave_deep[w]);
-        // two self-tagged 64-bit words {sequence number : value}: each is ONE relaxed system-scope store, so no release
-        // fence (= write-back of the XCD's dirty L2 lines) is needed to order a value before its flag
-        unsigned long long *hs = reinterpret_cast<unsigned long long *>(host_slot);
-        const unsigned long long tag = (unsigned long long)(uint32_t)seq << 32;
-        __hip_atomic_store(&hs[2], tag | tot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // work units
-        __hip_atomic_store(&hs[1], tag | dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);           // deepest tile
-        __hip_atomic_store(&hs[0], tag | tot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // N
+        // {N, deepest tile, work units}: to the host right here when it is waiting for N before it can size the binning buffer
+        // (first frame of a shape); otherwise left in device memory for the emit launch to publish, so that the PCIe stores
+        // (and the wait for them at the end of the kernel) are off this single-block kernel everything else waits for
+        scan_out[0] = tot[0]; scan_out[1] = dm; scan_out[2] = tot[1];
+        if (host_slot) publish_counts(host_slot, seq, tot[0], dm, tot[1]);
     }
     for (int t = b; t < e; t++) {
         uint32_t q[NSCAN];
@@ -533,9 +544,15 @@ __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
 // kernel, so it rides along instead of costing a launch of its own.
 __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, int gy, const int *radii, GeomState geom,
                                                                const uint32_t *tile_offset, uint32_t *tile_cursor,
-                                                               uint64_t *keys, uint64_t capacity, unsigned emit_blocks, FillUnitsArgs fu)
+                                                               uint64_t *keys, uint64_t capacity, unsigned emit_blocks, FillUnitsArgs fu,
+                                                               int32_t *host_slot, int32_t seq, const uint32_t *scan_out)
 {
-    if (blockIdx.x >= emit_blocks) { fill_units(fu, (int)(blockIdx.x - emit_blocks)); return; }
+    if (blockIdx.x >= emit_blocks) {
+        // (first spare block: this frame's counts go to the host from here when the scan left that to us)
+        if (blockIdx.x == emit_blocks && threadIdx.x == 0 && host_slot) publish_counts(host_slot, seq, scan_out[0], scan_out[1], scan_out[2]);
+        fill_units(fu, (int)(blockIdx.x - emit_blocks));
+        return;
+    }
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     const int r = i < P ? radii[i] : 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
@@ -1112,7 +1129,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
                                                                                    img.unit_first, img.mseg_first, img.class_first, T, L,
-                                                                                   slot, seq, sort_np));
+                                                                                   A->binning_capacity_hint > 0 ? nullptr : slot, seq, sort_np, img.scan_out));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
     ctr->dirty = false;
 
@@ -1138,7 +1155,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
-                                                                                                       img.tile_cursor, bin.keys, capacity, pblocks, fu));
+                                                                                                       img.tile_cursor, bin.keys, capacity, pblocks, fu,
+                                                                                                       A->binning_capacity_hint > 0 ? slot : nullptr, seq, img.scan_out));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
         if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)

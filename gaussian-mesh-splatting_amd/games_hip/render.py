@@ -60,15 +60,26 @@ def eval_sh(deg, sh, dirs):
     return result
 
 
+_zero_cache = {}
+
+
+def _zero_points(xyz: torch.Tensor) -> torch.Tensor:
+    key = (xyz.device, tuple(xyz.shape), xyz.dtype)
+    z = _zero_cache.get(key)
+    if z is None:
+        if len(_zero_cache) >= 8:
+            _zero_cache.clear()
+        z = _zero_cache[key] = torch.zeros(xyz.shape, dtype=xyz.dtype, device=xyz.device)
+    return z.detach().requires_grad_(True)
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
     xyz = pc.get_xyz
-    # the reference writes `torch.zeros_like(...) + 0` and retain_grad() (renderer/gaussian_renderer/__init__.py:33-37); a
-    # leaf tensor receives `.grad` just the same and saves the extra elementwise kernel
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # the reference writes `torch.zeros_like(...) + 0` and retain_grad() (renderer/gaussian_renderer/__init__.py:33-37): a
+    # 3.6 MB fill + an elementwise kernel per render for a tensor whose VALUES nobody reads (the rasterizer only hands a
+    # gradient back through it).  Here: a fresh leaf aliasing a cached all-zero buffer -- same values, its own `.grad`
+    # (train.py:129-133 reads it for the densification statistics), no kernel
+    screenspace_points = _zero_points(xyz)
     tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
     tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
     raster_settings = GaussianRasterizationSettings(

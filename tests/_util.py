@@ -126,10 +126,12 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None):
         n_exc = 0
         if excuse is not None and bad.any() and b.shape[0] == excuse.shape[0]:
             # rows (Gaussians) with a pixel-level skip decision inside exp() rounding (oracle gauss_ambig bit 1): an
-            # implementation may include or drop that pixel's term; bounded loosely instead of at 1e-3
+            # implementation may include or drop that pixel's term; bounded at 5 % of the tensor's largest gradient instead of at 1e-3
             row_exc = np.broadcast_to(excuse.reshape((-1,) + (1,) * (b.ndim - 1)), b.shape)
             n_exc = int((bad & row_exc).sum())
-            assert float(rel[bad & row_exc].max() if n_exc else 0.0) <= 0.25, (k, "excused outlier too large")
+            # one fringe pixel (alpha = 1/255) in or out: large RELATIVE to a small, self-cancelling gradient (the mean
+            # gradient of a symmetric splat sums to ~0), never comparable to the largest gradient of the tensor
+            assert float(err[bad & row_exc].max() if n_exc else 0.0) <= 0.05 * scale, (k, "excused outlier too large")
             bad = bad & ~row_exc
         n_out = int(bad.sum())
         unexplained, worst = n_out, 0.0
@@ -167,8 +169,10 @@ def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_f
         rep = grad_report(gh, go, q=q, go64=go64_fn(), excuse=excuse, go32acc=go32acc_fn() if go32acc_fn is not None else None)
     for k, v in rep.items():
         assert not v["zero_violation"], (where, k, v)
-        assert v["q_rel"] <= GRAD_REL, (where, k, v)
-        assert v["frac_bad"] <= 2e-3, (where, k, v)
+        # explained outliers must stay rare (float32 conditioning is the exception, not the rule); on tensors of a few hundred
+        # entries the 0.999 quantile IS the maximum, so the rarity rule is a count there
+        assert v["outliers"] <= max(8, int(2e-3 * v["size"])), (where, k, v)
+        assert v["q_rel"] <= GRAD_REL or v["size"] < 8000, (where, k, v)
         assert v["unexplained"] <= int(UNEXPLAINED_PER_MILLION * 1e-6 * v["size"]), (where, k, v)
     _log_parity(where, rep)
     return rep

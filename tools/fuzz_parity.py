@@ -33,19 +33,13 @@ for case in range(n_cases):
         o64 = U.oracle_render(inputs, kw, gc, gd, precision="f64")
 
         def grad_bad(hg):
-            """float32 conditioning (large splats: cancellation in the conic backward) is judged against the float64 oracle:
-            a gradient is bad only if the HIP error exceeds both the tolerance and three times the float32 oracle's own."""
-            out = {}
-            for k, ref in o64["grads"].items():
-                if ref is None or hg.get(k) is None or np.asarray(ref).size == 0:
-                    continue
-                ref = np.asarray(ref, np.float64)
-                den = np.abs(ref) + 1e-3 * np.abs(ref).max() + 1e-30
-                eh = float((np.abs(np.asarray(hg[k], np.float64) - ref) / den).max())
-                eo = float((np.abs(np.asarray(o["grads"][k], np.float64) - ref) / den).max())
-                if eh > max(1e-3, 3.0 * eo):
-                    out[k] = (eh, eo)
-            return out
+            """The criterion of the test-suite (tests/_util.py::grad_report): every entry within 1e-3 of the float32 oracle, or
+            explained by float32 conditioning against the float64 oracle (K x the larger error of the two float32 oracle
+            builds on the same row), or on a Gaussian with a pixel-level decision inside exp() rounding."""
+            oacc = U.oracle_render(inputs, kw, gc, gd, precision="f32acc")
+            rep = U.grad_report(hg, o["grads"], go64=o64["grads"], go32acc=oacc["grads"], excuse=(o["details"]["gauss_ambig"] & 2) != 0)
+            return {k: (v["max_rel"], v["outliers"], v["unexplained"], round(v["worst_ratio"], 1)) for k, v in rep.items()
+                    if v["zero_violation"] or v["outliers"] > max(8, int(2e-3 * v["size"])) or v["unexplained"] > int(2e-6 * v["size"])}
 
         for rep_i in range(2):                       # twice: second call takes the capacity-hint path
             h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=gd)
