@@ -389,6 +389,18 @@ def main():
 
     vps = max(1, args.views_per_step)
     step, reducer = make_step(vps, True)
+    # untimed pre-warm (~0.3 s of steps before the W warm-up steps): allocator pools, capacity / unit hints and the GPU's
+    # clocks reach their steady state; two back-to-back runs on one box otherwise differ by 6 % (first run slower)
+    if distributed:                      # the same number of steps on every rank: each step contains collectives
+        for _ in range(40):
+            step()
+        torch.cuda.synchronize(device)
+    else:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < 0.3:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(device)
     elapsed = timed(step, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * vps * args.steps / elapsed

@@ -468,9 +468,10 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
     if (tid == 0) {
         uint32_t dm = 0;
         for (int w = 0; w < SCAN_THREADS / WAVE; w++) dm = max(dm, wave_deep[w]);
-        // {N, deepest tile, work units}: to the host right here when it is waiting for N before it can size the binning buffer
-        // (first frame of a shape); otherwise left in device memory for the emit launch to publish, so that the PCIe stores
-        // (and the wait for them at the end of the kernel) are off this single-block kernel everything else waits for
+        // {N, deepest tile, work units} go to the host right here, as early as they exist: the host thread that waits for N
+        // then has the rest of the forward (emit, sort, compositing: ~220 us on the headline scene) to get the backward
+        // enqueued before the GPU runs dry.  (Publishing from the emit launch instead was measured: the scan is not
+        // shortened by it -- 15.7 -> 15.4 us -- and the host loses 24 us of that slack.)  The device copy serves that variant.
         scan_out[0] = tot[0]; scan_out[1] = dm; scan_out[2] = tot[1];
         if (host_slot) publish_counts(host_slot, seq, tot[0], dm, tot[1]);
     }
@@ -1129,7 +1130,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
                                                                                    img.unit_first, img.mseg_first, img.class_first, T, L,
-                                                                                   A->binning_capacity_hint > 0 ? nullptr : slot, seq, sort_np, img.scan_out));
+                                                                                   slot, seq, sort_np, img.scan_out));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
     ctr->dirty = false;
 
@@ -1156,7 +1157,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                                        img.tile_cursor, bin.keys, capacity, pblocks, fu,
-                                                                                                       A->binning_capacity_hint > 0 ? slot : nullptr, seq, img.scan_out));
+                                                                                                       nullptr, seq, img.scan_out));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
         if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)
