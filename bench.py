@@ -397,7 +397,7 @@ def main():
         torch.cuda.synchronize(device)
     else:
         t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < 0.3:
+        while time.perf_counter() - t_pre < float(os.environ.get("GMS_BENCH_PREWARM_S", "0.3")):
             for _ in range(10):
                 step()
             torch.cuda.synchronize(device)
