@@ -1,0 +1,155 @@
+"""CPU, authoring container only: the REFERENCE's own `render()` (renderer/gaussian_renderer/__init__.py:25-111) and its
+own `GaussianMeshModel` run unmodified on top of the drop-in package's Python surface -- `GaussianRasterizationSettings`,
+`GaussianRasterizer.forward` with the reference's keyword call, the (color, radii, invdepth) return, the autograd contract
+with `screenspace_points.grad` -- with only the innermost kernel call replaced by the CPU oracle (there is no GPU here and
+no reference tree on the GPU box, so this is the one place where the reference's glue and the drop-in meet in a test).
+With `install()`: the mixin model (K0 op replaced by the restatement) renders the same image as the reference class."""
+import numpy as np
+import pytest
+import torch
+
+from games_hip import synthetic as syn
+from oracle import gs_oracle, ref_import
+
+
+class _OracleRaster(torch.autograd.Function):
+    """Test-only stand-in for the kernels: same inputs / outputs as `_rasterize_gaussians`, computed by the C oracle."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors, opacities, scales, rotations, cov, rs):
+        nz = lambda t: t.detach() if (t is not None and t.numel()) else None
+        o = gs_oracle.rasterize(means3D=means3D.detach(), opacities=opacities.detach(), shs=nz(sh), colors_precomp=nz(colors),
+                                scales=nz(scales), rotations=nz(rotations), cov3D_precomp=nz(cov),
+                                image_height=rs.image_height, image_width=rs.image_width, tanfovx=rs.tanfovx, tanfovy=rs.tanfovy,
+                                bg=rs.bg, scale_modifier=rs.scale_modifier, viewmatrix=rs.viewmatrix, projmatrix=rs.projmatrix,
+                                sh_degree=rs.sh_degree, campos=rs.campos, antialiasing=rs.antialiasing)
+        ctx.o = o
+        ctx.has = (sh.numel() > 0, colors.numel() > 0, scales.numel() > 0, cov.numel() > 0)
+        radii = torch.from_numpy(o.radii.copy())
+        ctx.mark_non_differentiable(radii)
+        return torch.from_numpy(o.color.copy()), radii, torch.from_numpy(o.invdepth.copy())
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii, g_invd):
+        g = gs_oracle.backward(ctx.o, g_color, g_invd if g_invd is not None and g_invd.abs().sum() > 0 else None)
+        t = lambda k: torch.from_numpy(np.asarray(g[k]).copy())
+        has_sh, has_col, has_sr, has_cov = ctx.has
+        return (t("means3D"), t("means2D"), t("sh") if has_sh else None, t("colors_precomp") if has_col else None, t("opacities"),
+                t("scales") if has_sr else None, t("rotations") if has_sr else None, t("cov3D_precomp") if has_cov else None, None)
+
+
+def _oracle_rasterize(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings, visible_out=None):
+    from diff_gaussian_rasterization import SplitSH
+    if isinstance(sh, SplitSH):
+        sh = sh.full()
+    return _OracleRaster.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings)
+
+
+class _Pipe:
+    convert_SHs_python = False
+    compute_cov3D_python = False
+    debug = False
+    antialiasing = False
+
+
+@pytest.mark.parametrize("installed", [False, True])
+def test_reference_render_and_backward_run_on_the_drop_in_surface(monkeypatch, installed):
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref = ref_import.import_reference()
+    import importlib
+    import diff_gaussian_rasterization as dgr
+    assert not getattr(dgr, "__games_stub__", False)
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", _oracle_rasterize)
+    import games
+    from games_hip import model as hip_model
+    import test_abi
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", test_abi._cpu_op)
+    ref_render = importlib.import_module("renderer.gaussian_renderer").render          # the reference's render(), unmodified
+    out = hip_model.install(games) if installed else {}
+    try:
+        scene = syn.mesh_scene("tiny")
+        with ref_import.cuda_literals_on_cpu():
+            m = games.gaussianModel["gs_mesh"](3)
+            m.vertices = torch.nn.Parameter(scene.vertices.clone())
+            m.faces = scene.faces
+            m._alpha = torch.nn.Parameter(scene._alpha.clone())
+            m._scale = torch.nn.Parameter(scene._scale.clone())
+            m._opacity = torch.nn.Parameter(scene._opacity.clone())
+            m._features_dc = torch.nn.Parameter(scene._features_dc.clone())
+            m._features_rest = torch.nn.Parameter(scene._features_rest.clone())
+            m.active_sh_degree = 3
+            m.update_alpha()
+            m.prepare_scaling_rot()
+            cam = syn.orbit_camera(2, width=64, height=48)
+            bg = torch.tensor([1.0, 1.0, 1.0])
+            pkg = ref_render(cam, m, _Pipe(), bg)
+            image = pkg["render"]
+            assert image.shape == (3, 48, 64) and pkg["radii"].dtype == torch.int32 and pkg["depth"].shape == (1, 48, 64)
+            assert pkg["visibility_filter"].dtype == torch.bool and int(pkg["visibility_filter"].sum()) > 0
+            loss = ((image - 0.5) ** 2).mean()
+            loss.backward()
+        # gradients reached every model parameter through the reference's getters and the K0 stage, and the screen-space leaf
+        for p in (m.vertices, m._alpha, m._scale, m._opacity, m._features_dc, m._features_rest):
+            assert p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) > 0
+        assert pkg["viewspace_points"].grad is not None and float(pkg["viewspace_points"].grad.abs().max()) > 0
+        # the picture equals the oracle rendering of the restatement's Gaussians
+        from oracle import mesh_oracle
+        with torch.no_grad():
+            _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(scene.vertices, scene.faces, scene._alpha, scene._scale)
+            xa, sa, ra, oa, shs = mesh_oracle.activated(xyz, scaling, rot, scene._opacity, scene._features_dc, scene._features_rest)
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=48, image_width=64,
+                                tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, viewmatrix=cam.world_view_transform,
+                                projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center)
+        assert float(np.abs(image.detach().numpy() - o.color).max()) <= 1e-5
+    finally:
+        if out:
+            hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
+
+
+def test_reference_animated_renderer_with_the_installed_mixin(monkeypatch):
+    """renderer/gaussian_animated_renderer/__init__.py:21-121 (scripts/render_time_animated.py drives it): it assigns
+    `pc.triangles`, calls `pc.prepare_scaling_rot()` and takes the centres from `pc.alpha @ triangles`; with install() the
+    mixin derives scale / rotation from the assigned triangles.  Image == oracle rendering of the deformed mesh."""
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import diff_gaussian_rasterization as dgr
+    import games
+    from games_hip import model as hip_model
+    from oracle import mesh_oracle
+    import test_abi
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", _oracle_rasterize)
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", test_abi._cpu_op)
+
+    def cpu_tri_op(triangles, _alpha, _scale, alpha_mode="relu", fused_activations=False):
+        F = triangles.shape[0]
+        return test_abi._cpu_op(triangles.reshape(3 * F, 3), torch.arange(3 * F).reshape(F, 3), _alpha, _scale, alpha_mode,
+                                fused_activations=fused_activations)
+    monkeypatch.setattr(hip_model, "triangles_to_gaussians", cpu_tri_op)
+    anim_render = importlib.import_module("renderer.gaussian_animated_renderer").render
+    out = hip_model.install(games)
+    try:
+        scene = syn.mesh_scene("tiny")
+        new_v = scene.vertices * torch.tensor([1.1, 0.9, 1.0]) + torch.tensor([0.0, 0.03, 0.0])
+        with ref_import.cuda_literals_on_cpu(), torch.no_grad():
+            m = games.gaussianModelRender["gs_mesh"](3)
+            m.vertices, m.faces = scene.vertices.clone(), scene.faces
+            m._alpha, m._scale, m._opacity = scene._alpha.clone(), scene._scale.clone(), scene._opacity.clone()
+            m._features_dc, m._features_rest = scene._features_dc.clone(), scene._features_rest.clone()
+            m.active_sh_degree = 3
+            m.update_alpha()
+            cam = syn.orbit_camera(5, width=64, height=64)
+            bg = torch.ones(3)
+            img = anim_render(None, new_v[scene.faces], cam, m, _Pipe(), bg)["render"]
+            _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(new_v, scene.faces, scene._alpha, scene._scale)
+            xa, sa, ra, oa, shs = mesh_oracle.activated(xyz, scaling, rot, scene._opacity, scene._features_dc, scene._features_rest)
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=64, image_width=64,
+                                tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, viewmatrix=cam.world_view_transform,
+                                projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center)
+        assert float(np.abs(img.numpy() - o.color).max()) <= 1e-5
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
