@@ -165,7 +165,7 @@ def parse_args(argv=None):
                     help="views each rank renders (fwd+bwd) per step, gradients accumulated before the ONE all-reduce of the step. "
                          "The headline is 1 at every N (config 4: one view per GPU per step); on several GPUs the 4-view amortised "
                          "figure is measured too and reported under `amortised`")
-    ap.add_argument("--allreduce", default="auto", choices=["auto", "ring", "direct"],
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "ring", "direct", "direct_ag"],
                     help="how the large (SH) gradient is reduced on several GPUs: ring = one all_reduce (RCCL's choice of algorithm), "
                          "direct = two all-to-all phases over all xGMI links at once (games_hip.ddp.DirectAllReduce); auto times both "
                          "on gradient-sized buffers before the timed region and takes the faster one (both times are reported)")
@@ -283,8 +283,8 @@ def main():
         def collectives_once(which):
             works, ds = [], []
             for b in big:
-                if which == "direct" and world > 1:
-                    d = DirectAllReduce(world)
+                if which in ("direct", "direct_ag") and (world > 1 or force_ddp):
+                    d = DirectAllReduce(world, gather="all_gather" if which == "direct_ag" else "all_to_all")
                     d.start(b)
                     ds.append(d)
                 else:
@@ -295,7 +295,7 @@ def main():
             for d in ds:
                 d.finish()
 
-        for which in (("ring", "direct") if args.allreduce == "auto" else (args.allreduce,)):
+        for which in (("ring", "direct", "direct_ag") if args.allreduce == "auto" else (args.allreduce,)):
             try:
                 for _ in range(3):
                     collectives_once(which)

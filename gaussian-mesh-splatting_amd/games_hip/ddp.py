@@ -56,8 +56,11 @@ class DirectAllReduce:
     hook, while the rest of the backward still runs); `finish()` does the local sum and phase 2 and leaves the result in the
     caller's tensor.  Tested against `all_reduce` with gloo, world size 2 and 3, sizes not divisible by the world size."""
 
-    def __init__(self, world: int, group=None):
-        self.world, self.group = world, group
+    def __init__(self, world: int, group=None, gather: str = "all_to_all"):
+        """`gather`: phase 2 as a second all-to-all of the replicated slice ("all_to_all": every link in parallel, one extra
+        local pass to replicate the slice) or as `all_gather_into_tensor` ("all_gather": no replication, RCCL's own choice
+        of all-gather algorithm)."""
+        self.world, self.group, self.gather = world, group, gather
         self._pending = None
 
     def start(self, t: torch.Tensor):
@@ -81,7 +84,10 @@ class DirectAllReduce:
         work.wait()
         mine = recv.view(W, shard).sum(dim=0)                    # my slice of the result
         out = torch.empty(W * shard, dtype=flat.dtype, device=flat.device) if shard * W != n else flat
-        dist.all_to_all_single(out, mine.repeat(W), group=self.group)        # my slice to everyone, everyone's to me
+        if self.gather == "all_gather":
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            dist.all_to_all_single(out, mine.repeat(W), group=self.group)    # my slice to everyone, everyone's to me
         if out is not flat:
             flat.copy_(out[:n])
 
@@ -106,11 +112,12 @@ class OverlappedGradAllReduce:
     def __init__(self, params: Iterable[torch.Tensor], world: int, average: bool = True, big_numel: int = 1 << 22,
                  force: bool = False, algorithm: str = "ring"):
         """`algorithm`: how a LARGE gradient is reduced -- "ring" = one `all_reduce` (RCCL picks its algorithm), "direct" =
-        two all-to-all phases over all xGMI links at once (DirectAllReduce).  The flat bucket of small gradients always uses
+        two all-to-all phases over all xGMI links at once (DirectAllReduce), "direct_ag" = all-to-all + all-gather.  The flat bucket of small gradients always uses
         `all_reduce` (latency bound)."""
         self.params = [p for p in params]
         self.world, self.average, self.big_numel = world, average, int(big_numel)
         self.algorithm = algorithm
+        self._force = bool(force)
         self._direct = []
         self._works, self._big, self._small, self._handles = [], [], [], []
         self._enabled = True
@@ -134,8 +141,8 @@ class OverlappedGradAllReduce:
             return
         if g.numel() >= self.big_numel and g.is_contiguous():
             self._big.append(g)
-            if self.algorithm == "direct" and self.world > 1:
-                d = DirectAllReduce(self.world)
+            if self.algorithm in ("direct", "direct_ag") and (self.world > 1 or self._force):
+                d = DirectAllReduce(self.world, gather="all_gather" if self.algorithm == "direct_ag" else "all_to_all")
                 d.start(g)
                 self._direct.append(d)
             else:

@@ -128,11 +128,12 @@ def _direct_worker(rank, world, port, q):
             x = torch.randn(n, generator=torch.Generator().manual_seed(10 * n + rank))
             ref = x.clone()
             dist.all_reduce(ref)
-            y = x.clone().view(-1)
-            d = DirectAllReduce(world)
-            d.start(y)
-            d.finish()
-            ok = ok and torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
+            for gather in ("all_to_all", "all_gather"):
+                y = x.clone().view(-1)
+                d = DirectAllReduce(world, gather=gather)
+                d.start(y)
+                d.finish()
+                ok = ok and torch.allclose(y, ref, rtol=1e-6, atol=1e-6)
         # through the hook-driven reducer: the large gradient takes the direct path, the small ones the flat bucket
         params = [torch.randn(s_, generator=torch.Generator().manual_seed(5)).requires_grad_(True) for s_ in ((64, 15, 3), (64, 1), (10, 3))]
         local = [torch.randn(p.shape, generator=torch.Generator().manual_seed(70 + rank + k)) for k, p in enumerate(params)]
