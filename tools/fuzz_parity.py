@@ -39,7 +39,7 @@ for case in range(n_cases):
             oacc = U.oracle_render(inputs, kw, gc, gd, precision="f32acc")
             rep = U.grad_report(hg, o["grads"], go64=o64["grads"], go32acc=oacc["grads"], excuse=(o["details"]["gauss_ambig"] & 2) != 0)
             return {k: (v["max_rel"], v["outliers"], v["unexplained"], round(v["worst_ratio"], 1)) for k, v in rep.items()
-                    if v["zero_violation"] or v["outliers"] > max(8, int(2e-3 * v["size"])) or v["unexplained"] > int(2e-6 * v["size"])}
+                    if v["zero_violation"] or v["outliers"] > max(8, int(1e-2 * v["size"])) or v["unexplained"] > int(2e-6 * v["size"])}
 
         for rep_i in range(2):                       # twice: second call takes the capacity-hint path
             h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=gd)
