@@ -145,11 +145,32 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
 
 struct Backward { Tensor dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dsh_rest, dscales, drots; };
 
+// The gradient outputs of a backward call.  The autograd fast path allocates them in FORWARD, before the C call (there the
+// host runs ahead of the GPU and then waits for the instance count anyway), so that between "N has arrived" and "blend_bwd is
+// enqueued" -- the stretch in which a slow host lets the GPU run dry -- no allocation remains.
+Backward alloc_backward(const Tensor &means3D, const Tensor &opac, const Tensor &sh, const Tensor &sh_rest, const Tensor &cov)
+{
+    const int64_t P = means3D.size(0);
+    auto fopt = torch::TensorOptions().dtype(torch::kFloat).device(means3D.device());
+    const bool has_sh = sh.defined() && sh.numel() > 0, split = sh_rest.defined() && sh_rest.numel() > 0;
+    const bool has_cov = cov.defined() && cov.numel() > 0;
+    Backward b;
+    b.dmeans2D = torch::empty({P, 3}, fopt);
+    b.dopacity = torch::empty(opac.sizes(), fopt);
+    b.dmeans3D = torch::empty({P, 3}, fopt);
+    if (!has_sh) b.dcolors = torch::empty({P, 3}, fopt);
+    if (has_sh) b.dsh = torch::empty(sh.sizes(), fopt);
+    if (split) b.dsh_rest = torch::empty(sh_rest.sizes(), fopt);
+    if (has_cov) b.dcov3D = torch::empty({P, 6}, fopt);
+    else { b.dscales = torch::empty({P, 3}, fopt); b.drots = torch::empty({P, 4}, fopt); }
+    return b;
+}
+
 Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &radii, const Tensor &colors, const Tensor &opac,
                        const Tensor &scales, const Tensor &rots, double mod, const Tensor &cov, const Tensor &view, const Tensor &proj,
                        double tanx, double tany, const Tensor &dL_dcolor_, const Tensor &dL_dinvd_, const Tensor &sh, const Tensor &sh_rest,
                        int64_t D, const Tensor &campos, const Tensor &geom, int64_t R, int64_t capacity, int64_t num_units,
-                       const Tensor &binning, const Tensor &image, bool aa, bool debug)
+                       const Tensor &binning, const Tensor &image, bool aa, bool debug, const Backward *prealloc = nullptr)
 {
     const auto dev = means3D.device();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
@@ -170,15 +191,7 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
         if (it != g_accum.end()) { accum = it->second; g_accum.erase(it); }
     }
     if (!accum.defined()) accum = torch::zeros({std::max<int64_t>(P, 1), 16}, fopt);
-    Backward b;
-    b.dmeans2D = torch::empty({P, 3}, fopt);
-    b.dopacity = torch::empty(opac.sizes(), fopt);
-    b.dmeans3D = torch::empty({P, 3}, fopt);
-    if (!has_sh) b.dcolors = torch::empty({P, 3}, fopt);
-    if (has_sh) b.dsh = torch::empty(sh.sizes(), fopt);
-    if (split) b.dsh_rest = torch::empty(sh_rest.sizes(), fopt);
-    if (has_cov) b.dcov3D = torch::empty({P, 6}, fopt);
-    else { b.dscales = torch::empty({P, 3}, fopt); b.drots = torch::empty({P, 4}, fopt); }
+    Backward b = prealloc ? *prealloc : alloc_backward(means3D, opac, sh, sh_rest, cov);
     GmsRasterBackwardArgs a{};
     a.P = (int32_t)P; a.D = (int32_t)D; a.M = (int32_t)M; a.width = (int32_t)W; a.height = (int32_t)H;
     a.num_rendered = R; a.binning_capacity = capacity;
@@ -251,9 +264,18 @@ public:
     static variable_list forward(AutogradContext *ctx, Tensor means3D, Tensor means2D, Tensor sh, Tensor sh_rest, Tensor colors,
                                  Tensor opacities, Tensor scales, Tensor rotations, Tensor cov3D, Tensor bg, Tensor view, Tensor proj,
                                  Tensor campos, int64_t H, int64_t W, double tanx, double tany, double mod, int64_t D, bool prefiltered,
-                                 bool aa, bool debug, Tensor visible_out, bool use_hint)
+                                 bool aa, bool debug, Tensor visible_out, bool use_hint, bool will_backward)
     {
         ctx->set_materialize_grads(false);      // an unused output (inverse depth in train.py) arrives undefined: its channel is skipped
+        if (will_backward && means3D.is_cuda()) {
+            c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(means3D.device());
+            Backward pre = alloc_backward(means3D, opacities, sh, sh_rest, cov3D);
+            const Tensor *ts[9] = {&pre.dmeans2D, &pre.dcolors, &pre.dopacity, &pre.dmeans3D, &pre.dcov3D, &pre.dsh, &pre.dsh_rest,
+                                   &pre.dscales, &pre.drots};
+            for (int k = 0; k < 9; k++)
+                if (ts[k]->defined()) ctx->saved_data[std::string("pre") + char('0' + k)] = *ts[k];
+            ctx->saved_data["pre"] = true;
+        }
         Forward f = forward_core(bg, means3D, sh, sh_rest, colors, opacities, scales, rotations, cov3D, view, proj, campos, H, W, tanx,
                                  tany, mod, D, prefiltered, aa, debug, visible_out, use_hint);
         const auto dev = means3D.device();
@@ -274,14 +296,25 @@ public:
         const Tensor &radii = s[8], &geom = s[9], &binning = s[10], &image = s[11], &bg = s[12], &view = s[13], &proj = s[14], &campos = s[15];
         const int64_t H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
         Tensor gcol = grads[0].defined() ? grads[0] : torch::zeros({3, H, W}, means3D.options());
+        Backward pre;
+        const bool have_pre = ctx->saved_data.count("pre") > 0;
+        if (have_pre) {        // handed out once: a second backward through a retained graph allocates its own outputs
+            Tensor *ts[9] = {&pre.dmeans2D, &pre.dcolors, &pre.dopacity, &pre.dmeans3D, &pre.dcov3D, &pre.dsh, &pre.dsh_rest, &pre.dscales,
+                             &pre.drots};
+            for (int k = 0; k < 9; k++) {
+                const std::string key = std::string("pre") + char('0' + k);
+                if (ctx->saved_data.count(key)) { *ts[k] = ctx->saved_data[key].toTensor(); ctx->saved_data.erase(key); }
+            }
+            ctx->saved_data.erase("pre");
+        }
         Backward b = backward_core(bg, means3D, radii, colors, opac, scales, rots, ctx->saved_data["mod"].toDouble(), cov, view, proj,
                                    ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], sh, sh_rest,
                                    ctx->saved_data["D"].toInt(), campos, geom, ctx->saved_data["R"].toInt(), ctx->saved_data["cap"].toInt(),
                                    ctx->saved_data["units"].toInt(), binning, image, ctx->saved_data["aa"].toBool(),
-                                   ctx->saved_data["debug"].toBool());
+                                   ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
         Tensor none;
         return {b.dmeans3D, b.dmeans2D, b.dsh, b.dsh_rest, b.dcolors, b.dopacity, b.dscales, b.drots, b.dcov3D,
-                none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+                none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
 };
 
@@ -291,8 +324,11 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(const Tensor &means3D, const Tensor
                                              const Tensor &campos, int64_t H, int64_t W, double tanx, double tany, double mod, int64_t D,
                                              bool prefiltered, bool aa, bool debug, const Tensor &visible_out, bool use_hint)
 {
+    const bool will_backward = at::GradMode::is_enabled() &&
+        (means3D.requires_grad() || means2D.requires_grad() || sh.requires_grad() || sh_rest.requires_grad() || colors.requires_grad() ||
+         opacities.requires_grad() || scales.requires_grad() || rotations.requires_grad() || cov3D.requires_grad());
     auto out = RasterizeFn::apply(means3D, means2D, sh, sh_rest, colors, opacities, scales, rotations, cov3D, bg, view, proj, campos, H,
-                                  W, tanx, tany, mod, D, prefiltered, aa, debug, visible_out, use_hint);
+                                  W, tanx, tany, mod, D, prefiltered, aa, debug, visible_out, use_hint, will_backward);
     return std::make_tuple(out[0], out[1], out[2]);
 }
 
