@@ -36,9 +36,9 @@ struct Pix {
     int xi, yi; bool inside; float xf, yf; float wx0, wy0, wx1, wy1;
 };
 
-__device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u)
+__device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u, int wave)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
     const int qx = u.tx * TILE + (wave & 1) * 8, qy = u.ty * TILE + (wave >> 1) * 8;
     Pix p;
     p.xi = qx + (lane & 7); p.yi = qy + (lane >> 3);
@@ -47,6 +47,7 @@ __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u)
     p.wx0 = (float)qx; p.wy0 = (float)qy; p.wx1 = (float)(qx + 7); p.wy1 = (float)(qy + 7);
     return p;
 }
+__device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u) { return pixel_of(g, u, (int)(threadIdx.x >> 6)); }
 
 // Does any pixel centre of the wave's 8x8 quadrant see this splat with alpha >= 1/255?  Conservative (it may keep a
 // pair the per-pixel test skips, never the reverse):
@@ -345,18 +346,26 @@ __device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1
     v[0] = qx; v[1] = qy; v[2] = qx * dx; v[3] = qx * dy; v[4] = qy * dy; v[5] = q;
 }
 
-template <bool INVD, int NE>
-__global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
+// WPB = waves per block.  4: one block per unit, the four quadrant waves share one 256-entry queue and move through it
+// in lockstep (two block barriers per queue).  1: one block per (unit, quadrant) -- a wave on its own 64-entry queue: no
+// block barrier, no waiting for a slower quadrant, a quadrant that is done frees its slot, and the scheduler places
+// work at a quarter of the granularity; the price is that each quadrant gathers the unit's records itself (from L2).
+template <bool INVD, int NE, int WPB>
+__global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    __shared__ SplatRec recs[QUEUE];
-    __shared__ uint32_t ids[QUEUE];
+    constexpr int QN = WPB == 4 ? QUEUE : WAVE;
+    __shared__ SplatRec recs[QN];
+    __shared__ uint32_t ids[QN];
     __shared__ uint32_t wave_max[4];
     Unit u;
-    if (!load_unit(g, u)) return;
+    // WPB == 1: the four quadrants of a unit are consecutive blocks of ONE XCD (they gather the same records)
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, WPB == 4 ? bs : bs >> 2, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qt = threadIdx.x, lane = qt & 63, wave = WPB == 4 ? qt >> 6 : (int)(bs & 3u);
+    const int tid = wave * WAVE + lane;                  // pixel index inside the tile (quadrant-major)
     Stamp stamp(dbg_on(g, 16u) ? g.dbg_buf : nullptr);
-    const Pix p = pixel_of(g, u);
+    const Pix p = pixel_of(g, u, wave);
     const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
     const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
@@ -426,22 +435,25 @@ __global__ void __launch_bounds__(BLOCK) blend_bwd_kernel(BlendGrid g, BlendBwdA
     m = m > seg_lo ? m : 0u;                       // 0 = this pixel has nothing in this unit
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-    if (lane == 0) wave_max[wave] = m;
-    __syncthreads();
-    const uint32_t top = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    uint32_t top = m;
+    if (WPB == 4) {
+        if (lane == 0) wave_max[wave] = m;
+        __syncthreads();
+        top = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+    }
     if (top == 0) return;
     if (dbg_on(g, 2u)) return;                              // experiment: prologue only
 
-    for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > QUEUE ? hi - QUEUE : seg_lo) {
-        const int cnt = (int)min((uint32_t)QUEUE, hi - seg_lo);
-        __syncthreads();                              // previous queue fully consumed
-        if (tid < cnt) {
-            const uint32_t e = hi - 1 - tid;          // queue slot 0 = backmost entry
+    for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > QN ? hi - QN : seg_lo) {
+        const int cnt = (int)min((uint32_t)QN, hi - seg_lo);
+        if (WPB == 4) __syncthreads(); else wave_sync();     // previous queue fully consumed
+        if (qt < cnt) {
+            const uint32_t e = hi - 1 - qt;           // queue slot 0 = backmost entry
             const uint32_t id = (uint32_t)g.keys[u.tile_beg + e];
-            ids[tid] = id;
-            recs[tid] = a.rec[id];
+            ids[qt] = id;
+            recs[qt] = a.rec[id];
         }
-        __syncthreads();
+        if (WPB == 4) __syncthreads(); else wave_sync();
         if (m == 0) continue;                         // wave-uniform: quadrant has nothing in this unit
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
@@ -554,9 +566,17 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 4; }
     const bool invd = a.has_invd && a.dL_dinvd;
-    auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4> : blend_bwd_kernel<false, 4>)
-                          : (invd ? blend_bwd_kernel<true, 2> : blend_bwd_kernel<false, 2>);
-    GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
+    static int wpb = -1;
+    if (wpb < 0) { const char *e = getenv("GMS_BWD_WPB"); wpb = (e && atoi(e) == 4) ? 4 : 1; }
+    if (wpb == 4) {
+        auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4, 4> : blend_bwd_kernel<false, 4, 4>)
+                              : (invd ? blend_bwd_kernel<true, 2, 4> : blend_bwd_kernel<false, 2, 4>);
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
+    } else {
+        auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4, 1> : blend_bwd_kernel<false, 4, 1>)
+                              : (invd ? blend_bwd_kernel<true, 2, 1> : blend_bwd_kernel<false, 2, 1>);
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
+    }
     GMS_KERNEL_CHECK(debug, stream, "blend_bwd");
     return GMS_OK;
 }

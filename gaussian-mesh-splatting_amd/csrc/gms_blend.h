@@ -89,10 +89,9 @@ struct Unit {
 // heavy image centre and the empty border are spread over all of them (units are far from equal work).
 constexpr uint32_t UNIT_RUN_MAX = 64;   // grid padding granularity; the run length itself is g.unit_run
 
-__device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
+__device__ __forceinline__ bool load_unit_at(const BlendGrid &g, Unit &u, uint32_t s, uint32_t xcd)
 {
     const uint32_t nunits = g.unit_first[g.T];
-    const uint32_t s = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
     const uint32_t run = g.unit_run;
     const uint32_t idx = ((s / run) * 8u + xcd) * run + (s % run);
     if (idx >= nunits || idx >= g.max_units) return false;   // (max_units: overflowed optimistic launch)
@@ -109,6 +108,8 @@ __device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u)
     u.end = min(tile_end, u.beg + g.seg_len);
     return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
 }
+
+__device__ __forceinline__ bool load_unit(const BlendGrid &g, Unit &u) { return load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u); }
 
 // Experiment switches (env GMS_DBG) exist only in builds made with `make EXPERIMENTS=1`;
 // in the default build every `dbg_on()` is a compile-time false and the branches disappear from the kernels.
