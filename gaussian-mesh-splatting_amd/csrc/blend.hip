@@ -57,14 +57,11 @@ __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u) { ret
 //       ex^2 (A C - B^2) / C because ex^2 = 2 Sigma_xx (ln(255 op) + 1e-3) and Sigma_xx = C / det(conic).  Mesh-bound
 //       splats are flat and often diagonal on screen, where the box of the ellipse is loose.  The slack (1e-4 relative +
 //       0.01 absolute in Q, i.e. 0.005 in the exponent) covers the float error of both evaluations.
-__device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p, bool bbox_only = false)
+__device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float4 q2, const Pix &p, bool bbox_only = false)
 {
-    if (j >= cnt) return false;
-    const float4 q0 = recs[j].q0;
-    const float4 q2 = recs[j].q2;
     if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) return false;
     if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
-    const float A = q0.z, B = q0.w, C = recs[j].q1.x;
+    const float A = q0.z, B = q0.w;
     const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
     const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
@@ -80,31 +77,39 @@ __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cn
     }
     return qmin <= thr * 1.0001f + 0.01f;
 }
+__device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p, bool bbox_only = false)
+{
+    if (j >= cnt) return false;
+    return rect_hit(recs[j].q0, recs[j].q1.x, recs[j].q2, p, bbox_only);
+}
 
 // ------------------------------------------------------------------------------------ tloc
-template <int NE>
-__device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase)
+template <int NE, int WPB>
+__device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase, int wave)
 {
+    constexpr int QN = WPB == 4 ? QUEUE : WAVE;
     if (u.nseg == 1 || u.seg == u.nseg - 1) return;
     // phase 0: the first TLOC_HEAD segments of every tile; phase 1: the rest, unless the head already
     // finished every pixel of the tile (then the products are irrelevant: write 0, evaluate nothing)
     if (phase >= 0 && (u.seg < TLOC_HEAD) != (phase == 0)) return;     // phase -1: every segment in one launch
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int qt = threadIdx.x, lane = qt & 63, tid = wave * WAVE + lane;
     if (phase == 1 && g.tile_dead[u.tile]) {
         g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = 0.f;
         return;
     }
-    const Pix p = pixel_of(g, u);
+    const Pix p = pixel_of(g, u, wave);
     float Tl = 1.f;
-    for (uint32_t base = u.beg; base < u.end; base += QUEUE) {
-        __syncthreads();
-        const uint32_t idx = base + tid;
-        if (tid < QUEUE && idx < u.end) recs[tid] = rec[(uint32_t)g.keys[idx]];
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)QUEUE, u.end - base);
+    for (uint32_t base = u.beg; base < u.end; base += QN) {
         // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact
         // value: a quadrant whose pixels are all there (or outside the image) stops evaluating
-        if (__all(Tl < T_MIN || !p.inside)) continue;
+        const bool quad_done = __all(Tl < T_MIN || !p.inside);
+        if (WPB == 1 && quad_done) break;
+        if (WPB == 4) __syncthreads(); else wave_sync();
+        const uint32_t idx = base + qt;
+        if (qt < QN && idx < u.end) recs[qt] = rec[(uint32_t)g.keys[idx]];
+        if (WPB == 4) __syncthreads(); else wave_sync();
+        const int cnt = (int)min((uint32_t)QN, u.end - base);
+        if (quad_done) continue;
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)));
             while (mask) {
@@ -149,11 +154,12 @@ __global__ void __launch_bounds__(BLOCK) blend_tloc_check_kernel(BlendGrid g)
 }
 
 // ------------------------------------------------------------------------------------ fwd
-template <int NE>
-__device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs)
+template <int NE, int WPB>
+__device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs, int wave)
 {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const Pix p = pixel_of(g, u);
+    constexpr int QN = WPB == 4 ? QUEUE : WAVE;
+    const int qt = threadIdx.x, lane = qt & 63, tid = wave * WAVE + lane;
+    const Pix p = pixel_of(g, u, wave);
 
     float T = 1.f;
     {
@@ -172,12 +178,13 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
     uint32_t last = 0;
     bool done = !p.inside || dead_on_entry;
 
-    for (uint32_t base = u.beg; base < u.end; base += QUEUE) {
-        if (__syncthreads_and(done)) break;
-        const uint32_t idx = base + tid;
-        if (tid < QUEUE && idx < u.end) recs[tid] = o.rec[(uint32_t)g.keys[idx]];
-        __syncthreads();
-        const int cnt = (int)min((uint32_t)QUEUE, u.end - base);
+    for (uint32_t base = u.beg; base < u.end; base += QN) {
+        if (WPB == 4) { if (__syncthreads_and(done)) break; }
+        else { if (__all(done)) break; wave_sync(); }
+        const uint32_t idx = base + qt;
+        if (qt < QN && idx < u.end) recs[qt] = o.rec[(uint32_t)g.keys[idx]];
+        if (WPB == 4) __syncthreads(); else wave_sync();
+        const int cnt = (int)min((uint32_t)QN, u.end - base);
         if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)));
@@ -241,27 +248,31 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
 
 // First launch: every unit that depends on nothing -- the exact walk of each tile's FIRST segment (single-segment
 // tiles are finished by it) and, for the middle segments of multi-segment tiles, the transmittance products.
-template <int NE>
-__global__ void __launch_bounds__(BLOCK) blend_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
+template <int NE, int WPB>
+__global__ void __launch_bounds__(WPB * WAVE) blend_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
-    __shared__ SplatRec recs[QUEUE];
+    __shared__ SplatRec recs[WPB == 4 ? QUEUE : WAVE];
     Unit u;
-    if (!load_unit(g, u)) return;
+    const uint32_t bs = blockIdx.x >> 3;            // (WPB: see blend_bwd_kernel)
+    if (!load_unit_at(g, u, WPB == 4 ? bs : bs >> 2, blockIdx.x & 7u)) return;
+    const int wave = WPB == 4 ? (int)(threadIdx.x >> 6) : (int)(bs & 3u);
     Stamp stamp(dbg_on(g, 256u) ? g.dbg_buf : nullptr);
-    if (u.seg == 0) { if (phase <= 0 && !dbg_on(g, 32u)) fwd_unit<NE>(g, o, u, recs); }
-    else if (!dbg_on(g, 64u)) tloc_unit<NE>(g, o.rec, u, recs, phase);
+    if (u.seg == 0) { if (phase <= 0 && !dbg_on(g, 32u)) fwd_unit<NE, WPB>(g, o, u, recs, wave); }
+    else if (!dbg_on(g, 64u)) tloc_unit<NE, WPB>(g, o.rec, u, recs, phase, wave);
 }
 
 // Second launch: segments 1.. of the multi-segment tiles, from the prefix product of the segments in front.
-template <int NE>
-__global__ void __launch_bounds__(BLOCK) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
+template <int NE, int WPB>
+__global__ void __launch_bounds__(WPB * WAVE) blend_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
-    __shared__ SplatRec recs[QUEUE];
+    __shared__ SplatRec recs[WPB == 4 ? QUEUE : WAVE];
     Unit u;
-    if (!load_unit(g, u)) return;
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, WPB == 4 ? bs : bs >> 2, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
+    const int wave = WPB == 4 ? (int)(threadIdx.x >> 6) : (int)(bs & 3u);
     Stamp stamp(dbg_on(g, 128u) ? g.dbg_buf : nullptr);
-    fwd_unit<NE>(g, o, u, recs);
+    fwd_unit<NE, WPB>(g, o, u, recs, wave);
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -444,6 +455,61 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
     if (top == 0) return;
     if (dbg_on(g, 2u)) return;                              // experiment: prologue only
 
+    // the trips over one ballot mask of queue entries (slots chunk .. chunk+63 of the queue whose slot 0 is tile position hi-1)
+    auto walk = [&](uint64_t mask, const int chunk, const uint32_t hi) {
+    while (mask) {
+        // NE queue entries per trip: loads, exp and the wave reductions of different entries are independent
+        // and interleave; only the per-pixel recurrence is sequential (entry e is behind entry e+1)
+        int k[NE]; bool val[NE], act[NE], any[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            val[e] = mask != 0;
+            k[e] = val[e] ? chunk + __builtin_ctzll(mask) : k[e > 0 ? e - 1 : 0];
+            mask &= mask - 1;
+        }
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const float4 r0 = recs[k[e]].q0;
+            r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
+            dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
+            const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
+            G[e] = __expf(pw);
+            al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
+            const uint32_t pos = hi - 1 - (uint32_t)k[e];                  // 0-based tile position
+            act[e] = val[e] && pos < last && pw <= 0.f && al[e] >= ALPHA_MIN;
+            any[e] = __any(act[e]);
+        }
+        const bool noatomics = dbg_on(g, 1u);                           // experiment switch
+#pragma unroll
+        for (int e = 0; e < NE; e += 2) {
+            const int f = e + 1;
+            if (!(any[e] || any[f])) continue;
+            float va[10], vb[10];
+            if (any[e] && any[f]) {
+                bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
+                if (dbg_on(g, 8u)) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
+                float y0a, y1a, y0b, y1b;
+                wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
+                if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
+                const size_t ida = ids[k[e]], idb = ids[k[f]];
+                if (alane) {
+                    unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
+                    unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
+                }
+            } else {
+                // (static indices only: a runtime-selected element would push the arrays to scratch)
+                if (any[e]) bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                else bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
+                float y0, y1;
+                wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
+                if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
+                if (alane) unsafeAtomicAdd(abase + (size_t)ids[any[e] ? k[e] : k[f]] * GRAD_STRIDE, use_y1 ? y1 : y0);
+            }
+        }
+    }
+    };
+
     for (uint32_t hi = top; hi > seg_lo; hi = (hi - seg_lo) > QN ? hi - QN : seg_lo) {
         const int cnt = (int)min((uint32_t)QN, hi - seg_lo);
         if (WPB == 4) __syncthreads(); else wave_sync();     // previous queue fully consumed
@@ -457,59 +523,9 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
         if (m == 0) continue;                         // wave-uniform: quadrant has nothing in this unit
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             // m = furthest position any pixel of this quadrant composited: entries behind it are dead here
-            uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
+            const uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)) && (hi - 1 - (uint32_t)(chunk + lane)) < m);
             if (dbg_on(g, 4u)) { if (mask == 0x123456789ull) a.accum[1] = 1.f; continue; }   // experiment: queue fill + cull only
-            while (mask) {
-                // NE queue entries per trip: loads, exp and the wave reductions of different entries are independent
-                // and interleave; only the per-pixel recurrence is sequential (entry e is behind entry e+1)
-                int k[NE]; bool val[NE], act[NE], any[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE];
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    val[e] = mask != 0;
-                    k[e] = val[e] ? chunk + __builtin_ctzll(mask) : k[e > 0 ? e - 1 : 0];
-                    mask &= mask - 1;
-                }
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    const float4 r0 = recs[k[e]].q0;
-                    r1[e] = recs[k[e]].q1; r2[e] = recs[k[e]].q2;
-                    dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
-                    const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
-                    G[e] = __expf(pw);
-                    al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
-                    const uint32_t pos = hi - 1 - (uint32_t)k[e];                  // 0-based tile position
-                    act[e] = val[e] && pos < last && pw <= 0.f && al[e] >= ALPHA_MIN;
-                    any[e] = __any(act[e]);
-                }
-                const bool noatomics = dbg_on(g, 1u);                           // experiment switch
-#pragma unroll
-                for (int e = 0; e < NE; e += 2) {
-                    const int f = e + 1;
-                    if (!(any[e] || any[f])) continue;
-                    float va[10], vb[10];
-                    if (any[e] && any[f]) {
-                        bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
-                        bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, vb);
-                        if (dbg_on(g, 8u)) { float t = 0.f; for (int q = 0; q < 10; q++) t += va[q] + vb[q]; if (t == 123.456f) a.accum[0] = t; continue; }
-                        float y0a, y1a, y0b, y1b;
-                        wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
-                        if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
-                        const size_t ida = ids[k[e]], idb = ids[k[f]];
-                        if (alane) {
-                            unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
-                            unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
-                        }
-                    } else {
-                        // (static indices only: a runtime-selected element would push the arrays to scratch)
-                        if (any[e]) bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
-                        else bwd_step<INVD>(st8, act[f], r1[f], r2[f], dx[f], dy[f], G[f], al[f], dp0, dp1, dp2, dinvd, Tfinal_bgdot, va);
-                        float y0, y1;
-                        wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
-                        if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
-                        if (alane) unsafeAtomicAdd(abase + (size_t)ids[any[e] ? k[e] : k[f]] * GRAD_STRIDE, use_y1 ? y1 : y0);
-                    }
-                }
-            }
+            walk(mask, chunk, hi);
         }
     }
 }
@@ -534,17 +550,22 @@ int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 4; }
-    auto head = trip == 2 ? blend_head_kernel<2> : blend_head_kernel<4>;
-    auto fwd2 = trip == 2 ? blend_fwd_kernel<2> : blend_fwd_kernel<4>;
+    static int wpb = -1;
+    if (wpb < 0) { const char *e = getenv("GMS_FWD_WPB"); wpb = (e && atoi(e) == 4) ? 4 : 1; }
+    auto head = wpb == 4 ? (trip == 2 ? blend_head_kernel<2, 4> : blend_head_kernel<4, 4>)
+                         : (trip == 2 ? blend_head_kernel<2, 1> : blend_head_kernel<4, 1>);
+    auto fwd2 = wpb == 4 ? (trip == 2 ? blend_fwd_kernel<2, 4> : blend_fwd_kernel<4, 4>)
+                         : (trip == 2 ? blend_fwd_kernel<2, 1> : blend_fwd_kernel<4, 1>);
+    const unsigned wblocks = wpb == 4 ? blocks : 4u * blocks, wthreads = wpb == 4 ? BLOCK : WAVE;
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<wblocks, wthreads, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, blend_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<wblocks, wthreads, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, -1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<wblocks, wthreads, 0, stream>>>(g, o, -1));
     }
     GMS_KERNEL_CHECK(debug, stream, "blend_head");
-    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<blocks, BLOCK, 0, stream>>>(g, o));
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<wblocks, wthreads, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, blend_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "blend_finalize");

@@ -49,7 +49,22 @@ ext_y = np.sqrt(np.maximum(0, 2 * cyy * tau))
 
 acc = dict(instances=0, pix_pairs_total=0, active_fwd=0, active_bwd=0)
 blocks = {"16x16": (16, 16), "8x8": (8, 8), "8x4": (8, 4), "4x4": (4, 4), "16x4": (16, 4), "16x1": (16, 1), "4x2": (4, 2)}
-st = {k: dict(bbox=0, exact=0, anyact=0, act_lanes=0) for k in blocks}
+st = {k: dict(bbox=0, exact=0, circ=0, anyact=0, act_lanes=0) for k in blocks}
+# sub-wave streams: a wave owns an 8x8 quadrant; with S independent lane groups (S = 1: the whole quadrant, 2: two 8x4
+# halves, 4: four 4x4 blocks) a trip advances every group by one entry of ITS OWN culled list, so a 64-entry batch
+# costs max-over-groups trips instead of the size of the union list
+streams = {"1x(8x8)": (8, 8), "2x(8x4)": (8, 4), "4x(4x4)": (4, 4)}
+trips = {k: dict(exact=0, circ=0) for k in streams}
+
+
+def circ_hit(a, b, c, cx, cy, x0, y0, x1, y1, thr):
+    """conservative: centre distance in the splat's metric against sqrt(thr) + the metric radius of the block"""
+    mx, my = 0.5 * (x0 + x1), 0.5 * (y0 + y1)
+    hx, hy = 0.5 * (x1 - x0), 0.5 * (y1 - y0)
+    dx, dy = mx - cx, my - cy
+    qc = a * dx * dx + 2 * b * dx * dy + c * dy * dy
+    rho = np.sqrt(a * hx * hx + c * hy * hy + 2 * np.abs(b) * hx * hy)
+    return np.sqrt(qc) <= np.sqrt(thr) + rho
 
 
 def qmin_rect(a, b, c, cx, cy, x0, y0, x1, y1):
@@ -103,11 +118,32 @@ for t in tiles:
                        (xy[ids, 1] - ext_y[ids] > y1))
                 qm = qmin_rect(A[ids], B[ids], Cc[ids], xy[ids, 0], xy[ids, 1], x0, y0, x1, y1)
                 ex = bb & (qm <= 2 * tau[ids])
+                ci = bb & circ_hit(A[ids], B[ids], Cc[ids], xy[ids, 0], xy[ids, 1], x0, y0, x1, y1, 2 * tau[ids])
                 blk = act[:, by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw].reshape(n, -1)
                 # the block stops being walked after its furthest n_contrib
                 live = pos[:, 0, 0] < nc[by * bh:(by + 1) * bh, bx * bw:(bx + 1) * bw].max()
                 s["bbox"] += int((bb & live).sum()); s["exact"] += int((ex & live).sum())
+                s["circ"] += int((ci & live).sum())
                 s["anyact"] += int(blk.any(axis=1).sum()); s["act_lanes"] += int(blk.sum())
+    for name, (bw, bh) in streams.items():
+        for qy in range(2):
+            for qx in range(2):
+                cnt_e, cnt_c = [], []
+                qlive = pos[:, 0, 0] < nc[qy * 8:qy * 8 + 8, qx * 8:qx * 8 + 8].max()
+                for by in range(8 // bh):
+                    for bx in range(8 // bw):
+                        x0, y0 = tx * 16 + qx * 8 + bx * bw, ty * 16 + qy * 8 + by * bh
+                        x1, y1 = x0 + bw - 1, y0 + bh - 1
+                        bb = ~((xy[ids, 0] + ext_x[ids] < x0) | (xy[ids, 0] - ext_x[ids] > x1) |
+                               (xy[ids, 1] + ext_y[ids] < y0) | (xy[ids, 1] - ext_y[ids] > y1)) & qlive
+                        qm = qmin_rect(A[ids], B[ids], Cc[ids], xy[ids, 0], xy[ids, 1], x0, y0, x1, y1)
+                        cnt_e.append(bb & (qm <= 2 * tau[ids]))
+                        cnt_c.append(bb & circ_hit(A[ids], B[ids], Cc[ids], xy[ids, 0], xy[ids, 1], x0, y0, x1, y1, 2 * tau[ids]))
+                for key, lst in (("exact", cnt_e), ("circ", cnt_c)):
+                    m = np.stack(lst).astype(np.int64)                       # [groups, n]
+                    pad = (-n) % 64
+                    m = np.pad(m, ((0, 0), (0, pad))).reshape(m.shape[0], -1, 64).sum(axis=2)    # per 64-entry batch
+                    trips[name][key] += int(m.max(axis=0).sum())
 
 out = {"workload": wl, "tiles_sampled": int(len(tiles)), "tiles_nonempty": int(len(nonempty)), "N_total": int(d["N"]),
        "instances_sampled": acc["instances"], "active_pairs_sampled": acc["active_bwd"],
@@ -118,10 +154,12 @@ for name, (bw, bh) in blocks.items():
     out["blocks"][name] = {
         "pairs_bbox_per_instance": round(s["bbox"] / acc["instances"], 3),
         "pairs_exact_per_instance": round(s["exact"] / acc["instances"], 3),
+        "pairs_circle_per_instance": round(s["circ"] / acc["instances"], 3),
         "pairs_anyactive_per_instance": round(s["anyact"] / acc["instances"], 3),
         "exact_over_bbox": round(s["exact"] / max(1, s["bbox"]), 3),
         "lane_evals_bbox_per_instance": round(s["bbox"] * lanes / acc["instances"], 1),
         "lane_evals_exact_per_instance": round(s["exact"] * lanes / acc["instances"], 1),
         "active_lane_frac_bbox": round(s["act_lanes"] / max(1, s["bbox"] * lanes), 3),
         "active_lane_frac_exact": round(s["act_lanes"] / max(1, s["exact"] * lanes), 3)}
+out["wave_trips_per_instance"] = {k: {c: round(v[c] / acc["instances"], 3) for c in v} for k, v in trips.items()}
 print(json.dumps(out, indent=1))
