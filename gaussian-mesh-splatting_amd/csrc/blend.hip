@@ -1,10 +1,13 @@
 // blend.hip -- per-tile alpha compositing (forward and backward) for gfx950, segment-parallel.
 //
 // A tile's depth-sorted splat list is cut into segments of at most L entries (L = seg_len,
-// default 256); one work UNIT = (tile, segment) = one 256-thread block = 4 waves, each wave
-// owning an 8x8 pixel quadrant of the 16x16 tile.  Compositing is associative, so the segments of
-// a heavy tile (thousands of splats around mesh poles / silhouettes) run on different CUs instead
-// of serialising behind one block:
+// default 128); one work UNIT = (tile, segment).  A unit is walked by four independent waves, each owning an
+// 8x8 pixel quadrant of the 16x16 tile and launched as its OWN 64-thread block (the four quadrant blocks of a unit are
+// consecutive blocks of one XCD): no block barrier, no quadrant waiting at a barrier for a slower one, a finished
+// quadrant frees its slot, and the dispatcher places work at quadrant granularity.  (GMS_FWD_WPB=4 / GMS_BWD_WPB=4
+// select the older layout: one 256-thread block per unit, the four waves sharing one 256-entry queue.)
+// Compositing is associative, so the segments of a heavy tile (thousands of splats around mesh poles /
+// silhouettes) run on different CUs instead of serialising behind one block:
 //
 //   head     first launch, every unit that depends on nothing: the exact front-to-back walk of each tile's FIRST
 //            segment (reference skip/stop tests; single-segment tiles are finished by it, and the T it ends with is
@@ -21,10 +24,10 @@
 //            colour weights -- are reduced over the 64 lanes with a transposing DPP / permlane network and leave the
 //            wave as ONE atomic instruction into the splat's 64-byte record.
 //
-// Inside a unit the splat records are gathered 256 at a time into an LDS queue; every wave tests
-// 64 queue entries at once against its quadrant (exact ellipse-vs-rectangle test on the alpha >= 1/255
-// ellipse: it can only remove pairs the per-pixel test would skip) and walks the ballot survivors,
-// NE (= 4) entries per trip: their alpha evaluations are independent, only the recurrence is serial.
+// A wave gathers the unit's splat records 64 at a time into its LDS queue, tests the 64 entries at once against its
+// quadrant (exact ellipse-vs-rectangle test on the alpha >= 1/255 ellipse: it can only remove pairs the per-pixel test
+// would skip) and walks the ballot survivors, NE (= 4) entries per trip: their alpha evaluations are independent, only
+// the recurrence is serial.
 #include <stdlib.h>
 
 #include "gms_common.h"
@@ -89,9 +92,9 @@ __device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *re
 {
     constexpr int QN = WPB == 4 ? QUEUE : WAVE;
     if (u.nseg == 1 || u.seg == u.nseg - 1) return;
-    // phase 0: the first TLOC_HEAD segments of every tile; phase 1: the rest, unless the head already
+    // phase 0: the first tloc_head(L) segments of every tile; phase 1: the rest, unless the head already
     // finished every pixel of the tile (then the products are irrelevant: write 0, evaluate nothing)
-    if (phase >= 0 && (u.seg < TLOC_HEAD) != (phase == 0)) return;     // phase -1: every segment in one launch
+    if (phase >= 0 && (u.seg < tloc_head(u.L)) != (phase == 0)) return;     // phase -1: every segment in one launch
     const int qt = threadIdx.x, lane = qt & 63, tid = wave * WAVE + lane;
     if (phase == 1 && g.tile_dead[u.tile]) {
         g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = 0.f;
@@ -137,18 +140,19 @@ __device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *re
     g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid] = Tl;
 }
 
-// tile_dead[t] = 1 when the product of the first TLOC_HEAD segment transmittances is < 1e-4 for every pixel
+// tile_dead[t] = 1 when the product of the first tloc_head(L) segment transmittances is < 1e-4 for every pixel
 __global__ void __launch_bounds__(BLOCK) blend_tloc_check_kernel(BlendGrid g)
 {
     const int tile = blockIdx.x;
     const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
-    if (nseg <= TLOC_HEAD + 1) return;             // no phase-1 segment exists (the last one needs no product)
+    const int nhead = tloc_head(g.scan_out[3]);
+    if (nseg <= nhead + 1) return;                 // no phase-1 segment exists (the last one needs no product)
     if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xi = (tile % g.gx) * TILE + (wave & 1) * 8 + (lane & 7), yi = (tile / g.gx) * TILE + (wave >> 1) * 8 + (lane >> 3);
     const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float T = 1.f;
-    for (int k = 0; k < TLOC_HEAD; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
     const int dead = __syncthreads_and(T < T_MIN || xi >= g.W || yi >= g.H);
     if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
 }
@@ -546,7 +550,9 @@ int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
         if (!g_dbg_buf) (void)hipMalloc((void **)&g_dbg_buf, DBG_BYTES);
         if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
     }
-    const bool deep = g.capacity > 2ull * g.seg_len * (uint64_t)g.T;
+    static int deep_env = -2;
+    if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
+    const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 4; }

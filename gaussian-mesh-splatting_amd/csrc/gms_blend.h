@@ -13,7 +13,7 @@ constexpr size_t SEG_FLOATS = (size_t)SEG_FIELDS * TILE_PIX;     // 7 KiB per un
 
 struct BlendGrid {
     int W, H, gx, gy, T;
-    uint32_t seg_len;              // L: entries per segment (multiple of 256)
+    const uint32_t *scan_out;      // [4] {N, deepest tile, units, L} of this frame: L = entries per segment, chosen by the tile scan
     const uint32_t *tile_offset;   // [T+1]
     const uint32_t *unit_first;    // [T+1] first unit of each tile; unit_first[T] = number of units
     const uint32_t *mseg_first;    // [T+1] first segment-state slot of each multi-segment tile
@@ -48,8 +48,14 @@ struct BlendBwdArgs {
     int has_invd;
 };
 
-// segment length used by this process (env GMS_SEG_LEN, default 256; multiple of 256)
-uint32_t seg_len();
+// Segment length L (entries per work unit).  GMS_SEG_LEN forces it (multiple of 64); otherwise the tile scan picks it
+// per frame from the scene depth -- SEG_LEN_SHALLOW up to SEG_DEEP_PER_TILE list entries per tile on average,
+// SEG_LEN_DEEP above (short segments shorten the serial walk of a wave; deep scenes pay for them in per-segment state
+// and in the length of the finalize / suffix chains) -- and leaves it in scan_out[3], where every later kernel of the
+// frame, forward and backward, reads it.  Buffers are sized for the shortest L that can be chosen.
+constexpr uint32_t SEG_LEN_SHALLOW = 128, SEG_LEN_DEEP = 256, SEG_DEEP_PER_TILE = 512;
+uint32_t seg_len_forced();     // GMS_SEG_LEN, or 0
+uint32_t seg_len_min();        // the forced L, or SEG_LEN_SHALLOW: what BinningState is sized and carved with
 uint32_t unit_run();
 inline uint32_t max_units(uint32_t T, uint64_t instances, uint32_t L) { return T + (uint32_t)(instances / L) + 1u; }
 inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_t)(instances / L) + 2u; }
@@ -59,7 +65,8 @@ inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_
 #define GMS_QUEUE 256
 #endif
 constexpr int QUEUE = GMS_QUEUE;   // LDS splat-queue entries per batch (<= BLOCK)
-constexpr int TLOC_HEAD = 4;       // segments whose transmittance products are always evaluated
+constexpr uint32_t TLOC_HEAD_ENTRIES = 1024;   // list entries (per tile) whose transmittance products are always evaluated
+__host__ __device__ __forceinline__ int tloc_head(uint32_t L) { return (int)(TLOC_HEAD_ENTRIES / L > 0 ? TLOC_HEAD_ENTRIES / L : 1u); }
 
 // Exponent of the Gaussian at a pixel offset, in ONE documented operation order (discontinuity rule:
 // two explicit FMAs, every other product rounded on its own, no contraction; the CPU checker evaluates the same chain).  EVERY kernel that evaluates a
@@ -79,6 +86,7 @@ struct Unit {
     uint32_t tile_beg;     // first entry of the tile in the sorted list
     uint32_t beg, end;     // this unit's entries [beg, end)
     uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
+    uint32_t L;            // this frame's segment length
 };
 
 // Block -> unit.  The unit table lists full segments (seg_len entries) first, then the tiles' partial last
@@ -104,8 +112,9 @@ __device__ __forceinline__ bool load_unit_at(const BlendGrid &g, Unit &u, uint32
     u.tx = u.tile % g.gx; u.ty = u.tile / g.gx;
     u.tile_beg = r1.x;
     const uint32_t tile_end = r1.y;
-    u.beg = u.tile_beg + (uint32_t)u.seg * g.seg_len;
-    u.end = min(tile_end, u.beg + g.seg_len);
+    u.L = g.scan_out[3];
+    u.beg = u.tile_beg + (uint32_t)u.seg * u.L;
+    u.end = min(tile_end, u.beg + u.L);
     return (uint64_t)tile_end <= g.capacity;      // overflowed optimistic launch: host re-runs
 }
 

@@ -407,13 +407,13 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     GeomState geom = GeomState::carve(const_cast<void *>(A->geom_buffer), (size_t)P);
     ImageState img = ImageState::carve(const_cast<void *>(A->image_buffer), (size_t)W, (size_t)H);
     const int T = gx * gy;
-    const uint32_t L = seg_len();
+    const uint32_t L = seg_len_min();         // carving; the frame's own L is in img.scan_out[3]
     const uint64_t cap = (uint64_t)(A->binning_capacity > 0 ? A->binning_capacity : (A->num_rendered > 0 ? A->num_rendered : 1));
     BinningState bin = BinningState::carve(const_cast<void *>(A->binning_buffer), (size_t)cap, (size_t)T, L);
 
     if (A->num_rendered > 0) {
         BlendGrid g;
-        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
+        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = cap;
         g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;

@@ -413,13 +413,26 @@ __device__ __forceinline__ void publish_counts(int32_t *host_slot, int32_t seq, 
 // sums with DPP-free shuffles, the 16 wave totals are scanned by the first wave: two block barriers in all.
 __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count, uint32_t *offset, uint32_t *cursor,
                                                                  uint32_t *unit_first, uint32_t *mseg_first,
-                                                                 uint32_t *class_first, int T, uint32_t L, int32_t *host_slot,
+                                                                 uint32_t *class_first, int T, uint32_t L_forced, int32_t *host_slot,
                                                                  int32_t seq, int sort_np, uint32_t *scan_out)
 {
     __shared__ uint32_t wave_tot[NSCAN][SCAN_THREADS / WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
     const int b = tid * per, e = min(T, b + per);
+    // segment length of this frame: forced, or chosen from the average list length per tile (gms_blend.h)
+    uint32_t L = L_forced;
+    if (L == 0) {
+        __shared__ uint32_t wave_n[SCAN_THREADS / WAVE];
+        uint32_t n = 0;
+        for (int t = b; t < e; t++) n += count[t];
+        for (int d = 32; d >= 1; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+        if (lane == 0) wave_n[wave] = n;
+        __syncthreads();
+        uint64_t total = 0;
+        for (int w = 0; w < SCAN_THREADS / WAVE; w++) total += wave_n[w];
+        L = total > (uint64_t)SEG_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_DEEP : SEG_LEN_SHALLOW;
+    }
     uint32_t run[NSCAN], own[NSCAN];
     uint32_t deepest = 0;
 #pragma unroll
@@ -472,7 +485,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
         // then has the rest of the forward (emit, sort, compositing: ~220 us on the headline scene) to get the backward
         // enqueued before the GPU runs dry.  (Publishing from the emit launch instead was measured: the scan is not
         // shortened by it -- 15.7 -> 15.4 us -- and the host loses 24 us of that slack.)  The device copy serves that variant.
-        scan_out[0] = tot[0]; scan_out[1] = dm; scan_out[2] = tot[1];
+        scan_out[0] = tot[0]; scan_out[1] = dm; scan_out[2] = tot[1]; scan_out[3] = L;
         if (host_slot) publish_counts(host_slot, seq, tot[0], dm, tot[1]);
     }
     for (int t = b; t < e; t++) {
@@ -504,7 +517,8 @@ struct FillUnitsArgs {
     uint2 *deep_tab;
     uint32_t *multi_tab;
     int T, sort_np;
-    uint32_t L, max_units, max_deep, max_multi;
+    const uint32_t *scan_out;      // [3] = this frame's segment length
+    uint32_t max_units, max_deep, max_multi;
 };
 
 __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
@@ -513,7 +527,7 @@ __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
     uint4 *unit_tile = f.unit_tile;
     uint2 *deep_tab = f.deep_tab;
     const int T = f.T, sort_np = f.sort_np;
-    const uint32_t L = f.L, max_units = f.max_units, max_deep = f.max_deep;
+    const uint32_t L = f.scan_out[3], max_units = f.max_units, max_deep = f.max_deep;
     const int t = block * BLOCK + threadIdx.x;
     if (t >= T) return;
     const uint32_t c = offset[t + 1] - offset[t], nfull = c / L;      // (the counters were cleared by the scan)
@@ -968,17 +982,17 @@ static uint32_t deepest_tile(const int32_t *slot)
     return (uint32_t)(__atomic_load_n(reinterpret_cast<const unsigned long long *>(slot) + 1, __ATOMIC_RELAXED) & 0xffffffffull);
 }
 
-uint32_t seg_len()
+uint32_t seg_len_forced()
 {
-    static uint32_t L = 0;
-    if (L == 0) {
-        uint32_t v = 256;
-        if (const char *e = getenv("GMS_SEG_LEN")) v = (uint32_t)atoi(e);
-        if (v < 64) v = 64;
-        L = (v + 63u) / 64u * 64u;
+    static int64_t L = -1;
+    if (L < 0) {
+        uint32_t v = 0;
+        if (const char *e = getenv("GMS_SEG_LEN")) { v = (uint32_t)atoi(e); if (v < 64) v = 64; v = (v + 63u) / 64u * 64u; }
+        L = v;
     }
-    return L;
+    return (uint32_t)L;
 }
+uint32_t seg_len_min() { const uint32_t f = seg_len_forced(); return f ? f : SEG_LEN_SHALLOW; }
 
 uint32_t unit_run()
 {
@@ -1009,7 +1023,7 @@ extern "C" size_t gms_image_n_contrib_offset(int32_t w, int32_t h)
 extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 {
     const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
-    return BinningState::bytes((size_t)(n > 0 ? n : 0), T, seg_len());
+    return BinningState::bytes((size_t)(n > 0 ? n : 0), T, seg_len_min());
 }
 
 extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *stream_)
@@ -1119,7 +1133,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     }
 #undef GMS_PRE
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
-    const uint32_t L = seg_len();
+    const uint32_t L = seg_len_min();         // sizes and carving; the frame's own L is chosen by the scan (scan_out[3])
     int32_t *slot = pinned_slot();
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
     // merge-path passes for tiles deeper than SORT_BIG_CHUNK keys: as many as the deepest tile of the previous frame
@@ -1129,7 +1143,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     static thread_local int32_t seq_counter = 0;
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, img.class_first, T, L,
+                                                                                   img.unit_first, img.mseg_first, img.class_first, T, seg_len_forced(),
                                                                                    slot, seq, sort_np, img.scan_out));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
     ctr->dirty = false;
@@ -1152,7 +1166,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         FillUnitsArgs fu;
         fu.class_first = img.class_first; fu.offset = img.tile_offset; fu.mseg_first = img.mseg_first;
         fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.multi_tab = bin.multi_tab;
-        fu.max_multi = (uint32_t)BinningState::n_multi((size_t)capacity); fu.T = T; fu.sort_np = sort_np; fu.L = L; fu.max_units = mu;
+        fu.max_multi = (uint32_t)BinningState::n_multi((size_t)capacity); fu.T = T; fu.sort_np = sort_np; fu.scan_out = img.scan_out; fu.max_units = mu;
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
@@ -1174,7 +1188,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
                                                                                              capacity, sort_np));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
-        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.seg_len = L; g.tile_offset = img.tile_offset;
+        g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
         return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);

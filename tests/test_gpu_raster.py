@@ -313,12 +313,15 @@ def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
         assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, (frame, rep)
 
 
-@pytest.mark.parametrize("env", [{"GMS_SEG_LEN": "128"}, {"GMS_SEG_LEN": "512"}, {"GMS_TRIP": "2", "GMS_TRIP_BWD": "2"},
+@pytest.mark.parametrize("env", [{"GMS_SEG_LEN": "64"}, {"GMS_SEG_LEN": "256"}, {"GMS_SEG_LEN": "512", "GMS_DEEP": "1"},
+                                 {"GMS_TRIP": "2", "GMS_TRIP_BWD": "2"}, {"GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4"},
+                                 {"GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4", "GMS_SEG_LEN": "256", "GMS_DEEP": "1"},
                                  {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}, {"GMS_BINDING": "ctypes"},
                                  {"GMS_BINDING": "ctypes", "GMS_SYNC_BINNING": "1"}])
 def test_tuning_knobs_do_not_change_results(env):
     """The knobs of INTEGRATION.md section 6 are read once per process: run the parity check in a child process per
-    setting (segment lengths other than the default, 2-entry trips, no XCD run interleave, synchronous binning)."""
+    setting (segment lengths other than the default, forced two-phase products, 2-entry trips, the four-waves-per-block
+    layout, no XCD run interleave, synchronous binning)."""
     import os
     import subprocess
     import sys
