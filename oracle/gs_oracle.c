@@ -128,8 +128,11 @@ typedef struct {
     long *ranges;         /* [T,2] */
     real *final_T;        /* [HW] */
     int *n_contrib;       /* [HW] */
-    uint8_t *gauss_ambig; /* [P]  discrete per-Gaussian decision near a threshold */
+    uint8_t *gauss_ambig; /* [P]  bit 0: discrete per-Gaussian decision near a threshold; bit 1: a (pixel, Gaussian) skip /
+                           *      stop decision within exp() rounding; bit 2: composited in a pixel that holds such a
+                           *      decision of ANY Gaussian (see the compositing loop) */
     uint8_t *pix_ambig;   /* [HW] a per-pixel skip/stop test was near its threshold */
+    int amb_policy;       /* how this frame decided the pairs whose skip test is within exp() rounding (or_set_amb_policy) */
     double interactions;  /* pixel x Gaussian pairs evaluated */
 } OrState;
 
@@ -207,6 +210,24 @@ static inline int near_int(real v, real tol)
     return f < tol || f > 1 - tol;
 }
 
+/* Decision policy for the (pixel, Gaussian) pairs whose skip test lies within exp() rounding of its threshold (the same
+ * bands that set pix_ambig bit 0): 0 = decide them as computed; +1 = they all contribute; -1 = none of them does.  An
+ * independent float32 implementation lands on either side of each such test, and the outcome changes that pixel's term
+ * in the gradient of EVERY Gaussian composited there (transmittance behind the pair, colour behind for those in front):
+ * tests accept a row that agrees with the oracle under one of the two forced outcomes (tests/_util.py). */
+static int g_amb_policy = 0;
+void or_set_amb_policy(int p) { g_amb_policy = p < 0 ? -1 : (p > 0 ? 1 : 0); }
+static inline int skip_by_power(int policy, real power)
+{
+    if (policy && R_FABS(power) < (real)1e-6) return policy < 0;
+    return power > 0;
+}
+static inline int skip_by_alpha(int policy, real araw, real alpha)
+{
+    if (policy && R_FABS(araw * 255 - 1) < (real)4e-5) return policy < 0;
+    return alpha < ALPHA_MIN;
+}
+
 typedef struct { uint32_t tile; uint32_t dbits; uint32_t id; } Inst;
 
 static int inst_cmp(const void *a, const void *b)
@@ -252,6 +273,8 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
     st->final_T = (real *)calloc((size_t)W * H, sizeof(real));
     st->n_contrib = (int *)calloc((size_t)W * H, sizeof(int));
     st->pix_ambig = (uint8_t *)calloc((size_t)W * H, 1);
+    st->amb_policy = g_amb_policy;
+    const int policy = st->amb_policy;
 
     const real *V = sc->viewmatrix, *Mx = sc->projmatrix;
     const real fx = (real)W / (2 * sc->tanfovx), fy = (real)H / (2 * sc->tanfovy);
@@ -406,9 +429,16 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
                      * comparisons whose inputs went through different float32 code in front use bit 1. */
                     real cond = (real)0.5 * (R_FABS(co[0] * dx * dx) + R_FABS(co[2] * dy * dy)) + R_FABS(co[1] * dx * dy);
                     real in_band = (real)8 * (real)6e-8 * cond;
-                    if (R_FABS(power) < (real)1e-6) amb |= 1;
+                    if (R_FABS(power) < (real)1e-6) {
+                        /* the pixel centre sits on the splat's mean: `power > 0 -> skip` is decided by the last ulp of the
+                         * rasterizer inputs, and what is skipped or not is a splat at its FULL opacity.  gauss_ambig bit 1 for
+                         * this Gaussian (marked here, before the skip, so that a skipped pair is marked too). */
+                        amb |= 1;
+#pragma omp atomic
+                        st->gauss_ambig[g] |= 2;
+                    }
                     if (R_FABS(power) < (real)1e-6 + in_band) amb |= 2;
-                    if (power > 0) continue;
+                    if (skip_by_power(policy, power)) continue;
                     real ex = R_EXP(power);
                     real araw = co[3] * ex;
                     real alpha = araw < ALPHA_MAX ? araw : ALPHA_MAX;
@@ -420,7 +450,7 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
 #pragma omp atomic
                         st->gauss_ambig[g] |= 2;
                     }
-                    if (alpha < ALPHA_MIN) continue;
+                    if (skip_by_alpha(policy, araw, alpha)) continue;
                     real testT = Tr * (1 - alpha);
                     if (R_FABS(testT - T_MIN) < (real)1e-8) {
                         amb |= 3;
@@ -433,6 +463,20 @@ OrState *or_forward(const OrScene *sc, real *out_color /*[3,H,W]*/, real *out_in
                     Dp += (1 / st->depth[g]) * w;
                     Tr = testT;
                     last = contributor;
+                }
+                if (amb & 1) {
+                    /* gauss_ambig bit 2: composited in a pixel that holds a within-rounding decision (in front of the
+                     * pair: the colour behind changes; behind it: the transmittance does) */
+                    for (long s = r0; s < r0 + last; s++) {
+                        uint32_t g = st->point_list[s];
+                        real dx = st->xy[2 * (size_t)g] - (real)xx, dy = st->xy[2 * (size_t)g + 1] - (real)yy;
+                        const real *co = st->conic_op + 4 * (size_t)g;
+                        real power = pair_power(co[0], co[1], co[2], dx, dy);
+                        if (power > (real)1e-6) continue;
+                        if (co[3] * R_EXP(power) * 255 < 1 - (real)4e-5) continue;
+#pragma omp atomic
+                        st->gauss_ambig[g] |= 4;
+                    }
                 }
                 size_t pid = (size_t)yy * W + xx;
                 st->final_T[pid] = Tr; st->n_contrib[pid] = last; st->pix_ambig[pid] = amb;
@@ -493,11 +537,11 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                     real dx = st->xy[2 * (size_t)g] - (real)xx, dy = st->xy[2 * (size_t)g + 1] - (real)yy;
                     const real *co = st->conic_op + 4 * (size_t)g;
                     real power = pair_power(co[0], co[1], co[2], dx, dy);
-                    if (power > 0) continue;
+                    if (skip_by_power(st->amb_policy, power)) continue;
                     real Gv = R_EXP(power);
                     real araw = co[3] * Gv;
                     real alpha = araw < ALPHA_MAX ? araw : ALPHA_MAX;
-                    if (alpha < ALPHA_MIN) continue;
+                    if (skip_by_alpha(st->amb_policy, araw, alpha)) continue;
                     Tr = Tr / (1 - alpha);
                     real w = alpha * Tr;
                     acc_t *gi = ginst + (size_t)s * G_NUM;

@@ -70,6 +70,7 @@ def _lib(precision: str):
         lib.or_state_interactions.argtypes = [C.c_void_p]
         lib.or_state_copy.argtypes = [C.c_void_p] * 14
         lib.or_max_threads.restype = C.c_int
+        lib.or_set_amb_policy.argtypes = [C.c_int]
         assert lib.or_real_size() == C.sizeof(real)
         _LIBS[precision] = (lib, real, _scene_struct(real))
     return _LIBS[precision]
@@ -130,7 +131,7 @@ class OracleState:
 def rasterize(*, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
               cov3D_precomp=None, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier=1.0,
               viewmatrix, projmatrix, sh_degree=0, campos, prefiltered=False, debug=False,
-              antialiasing=False, precision="f32", nthreads=0) -> OracleOutput:
+              antialiasing=False, precision="f32", nthreads=0, amb_policy=0) -> OracleOutput:
     """Forward pass.  Array-likes are converted to contiguous numpy of the chosen precision."""
     lib, real, Scene = _lib(precision)
     dt = np.float64 if precision == "f64" else np.float32       # "f32acc": float32 with float32 gradient accumulators
@@ -163,7 +164,13 @@ def rasterize(*, means3D, opacities, shs=None, colors_precomp=None, scales=None,
                antialiasing=int(bool(antialiasing)), nthreads=int(nthreads))
     keep = [means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, vm, pm, cp, bgc]
     color = np.zeros((3, H, W), dt); invd = np.zeros((1, H, W), dt); radii = np.zeros(max(P, 1), np.int32)
-    h = lib.or_forward(C.byref(sc), _ptr(color), _ptr(invd), _ptr(radii))
+    # amb_policy: how pairs whose skip test is within exp() rounding are decided (0 as computed, +1 all in, -1 all out);
+    # the state remembers it for the backward pass
+    lib.or_set_amb_policy(int(amb_policy))
+    try:
+        h = lib.or_forward(C.byref(sc), _ptr(color), _ptr(invd), _ptr(radii))
+    finally:
+        lib.or_set_amb_policy(0)
     st = OracleState(lib, h, sc, keep, dt, P, W, H)
     return OracleOutput(color, radii[:P], invd, int(lib.or_state_N(h)), float(lib.or_state_interactions(h)), st)
 
