@@ -309,6 +309,15 @@ def main():
                 allreduce_times[which] = round(1000 * float(t.item()), 4)
             except Exception as e:  # noqa: BLE001 - an algorithm the backend cannot run is simply not chosen
                 allreduce_times[which] = f"failed: {e!r}"[:200]
+            if which != "ring":
+                # every rank must reach the same verdict (one rank's failure must not leave the others with a different choice)
+                try:
+                    flag = torch.tensor([1.0 if isinstance(allreduce_times[which], float) else 0.0], device=device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if float(flag.item()) == 0.0 and isinstance(allreduce_times[which], float):
+                        allreduce_times[which] = "failed on another rank"
+                except Exception as e:  # noqa: BLE001
+                    allreduce_times[which] = f"failed: {e!r}"[:200]
         ok = {k: v for k, v in allreduce_times.items() if isinstance(v, float)}
         algo = min(ok, key=ok.get) if ok else "ring"
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
