@@ -1,5 +1,6 @@
 """GPU tests of the factorised SH gradient (include/gmsplat.h: dL_dcolors on the SH path + gms_sh_grad_expand): the HIP path
-against its own dense SH gradient (bit for bit with one view) and against the oracle's factor."""
+against its own dense SH gradient and against the oracle's factor.  Two backward calls never agree bit for bit (float
+atomics in blend_bwd), so HIP-vs-HIP comparisons carry a 1e-5 tolerance relative to the tensor's scale."""
 import numpy as np
 import pytest
 import torch
@@ -16,6 +17,10 @@ def _scene(P=4000, size=96, view=1, deg=3):
     kw = U.settings_kwargs(cam, torch.tensor([0.1, 0.3, 0.2]), sh_degree=deg)
     inputs = dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
     return sc, cam, kw, inputs
+
+
+def _close(a, b, rel=1e-5):
+    return float((a - b).abs().max()) <= rel * float(b.abs().max()) + 1e-30
 
 
 def _run(inputs, kw, gc, split=False):
@@ -48,7 +53,7 @@ def _run(inputs, kw, gc, split=False):
 
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("deg", [3, 1])
-def test_one_view_factor_then_expand_equals_the_dense_sh_gradient_bit_for_bit(split, deg):
+def test_one_view_factor_then_expand_equals_the_dense_sh_gradient(split, deg):
     import diff_gaussian_rasterization as dgr
     if dgr._C is None:
         pytest.skip("factorised mode needs the _C binding")
@@ -67,25 +72,27 @@ def test_one_view_factor_then_expand_equals_the_dense_sh_gradient_bit_for_bit(sp
     # no SH gradient from autograd in this mode; every other gradient is unchanged
     assert all(fac[k] is None for k in (("dc", "rest") if split else ("shs",)))
     for k in ("means3D", "means2D", "opacities", "scales", "rotations"):
-        assert torch.equal(fac[k], dense[k]), k
+        assert _close(fac[k], dense[k]), k
     P = sc.means3D.shape[0]
     assert torch.equal(queued[0][P].cpu(), kw["campos"].float().reshape(3))
     ref = torch.from_numpy(np.asarray(o["sh_factor"], np.float32))
     got = queued[0][:P].cpu()
     assert float((got - ref).abs().max()) <= 1e-3 * float(ref.abs().max()) + 1e-12          # (float atomics: tolerance of the suite)
-    # expand == dense, bit for bit (same basis expressions, one product per coefficient)
+    # expand == dense (same basis expressions, one product per coefficient; the factor itself is a second run's atomics)
     dev = queued[0].device
     if split:
         dc, rest = torch.full((P, 1, 3), 7.0, device=dev), torch.full((P, 15, 3), 7.0, device=dev)
         dgr.sh_grad_expand(queued[0][None].contiguous(), t["means3D"], deg, dc, rest)
-        assert torch.equal(dc, dense["dc"]) and torch.equal(rest, dense["rest"])
+        assert _close(dc, dense["dc"]) and _close(rest, dense["rest"])
+        assert float(rest[:, (deg + 1) ** 2 - 1:].abs().max() if deg < 3 else 0.0) == 0.0          # above the active degree: exact zeros
     else:
         full = torch.full((P, 16, 3), 7.0, device=dev)
         dgr.sh_grad_expand(queued[0][None].contiguous(), t["means3D"], deg, full)
-        assert torch.equal(full, dense["shs"])
+        assert _close(full, dense["shs"])
+        assert float(full[:, (deg + 1) ** 2:].abs().max() if deg < 3 else 0.0) == 0.0
         acc = dense["shs"].clone()
         dgr.sh_grad_expand(queued[0][None].contiguous(), t["means3D"], deg, acc, accumulate=True)
-        assert torch.allclose(acc, 2 * dense["shs"], rtol=1e-6, atol=0)
+        assert _close(acc, 2 * dense["shs"])
 
 
 def test_two_views_expand_equals_the_sum_of_the_dense_gradients_and_the_exchange_sets_grads():
