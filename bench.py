@@ -169,6 +169,10 @@ def parse_args(argv=None):
                     help="how the large (SH) gradient is reduced on several GPUs: ring = one all_reduce (RCCL's choice of algorithm), "
                          "direct = two all-to-all phases over all xGMI links at once (games_hip.ddp.DirectAllReduce); auto times both "
                          "on gradient-sized buffers before the timed region and takes the faster one (both times are reported)")
+    ap.add_argument("--sh-exchange", default="auto", choices=["auto", "dense", "factor"],
+                    help="several ranks: how the SH gradient (54 of the 64 MB) crosses ranks.  dense: inside the gradient all-reduce; "
+                         "factor: all-gather of the per-view [P,3] colour-gradient factors + local expansion (gms_sh_grad_expand); "
+                         "auto = factor when there is more than one rank")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -249,7 +253,7 @@ def main():
 
     from diff_gaussian_rasterization import _lib, last_stats
     from games_hip import synthetic as syn
-    from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce
+    from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce, ShFactorExchange
     from games_hip.render import PipelineParams, render
 
     workload = args.workload or ("c2_hotdog_like" if world == 1 else "c4_ficus_like")
@@ -274,10 +278,13 @@ def main():
         torch.cuda.synchronize(device)
 
     # ---- several ranks: which collective for the large gradient (timed on gradient-sized buffers, outside the timed region)
+    sh_factor = distributed and (args.sh_exchange == "factor" or (args.sh_exchange == "auto" and (world > 1 or force_ddp)))
     algo, allreduce_times = "ring", {}
     if distributed:
-        big = [torch.zeros_like(p) for p in params if p.numel() >= (1 << 22)]
-        small_n = sum(p.numel() for p in params if p.numel() < (1 << 22))
+        # (factorised SH exchange: the feature tensors take no part in the all-reduce)
+        dense_params = [p for p in params if not (sh_factor and (p is model._features_dc or p is model._features_rest))]
+        big = [torch.zeros_like(p) for p in dense_params if p.numel() >= (1 << 22)]
+        small_n = sum(p.numel() for p in dense_params if p.numel() < (1 << 22))
         flat = torch.zeros(max(small_n, 1), device=device)
 
         def collectives_once(which):
@@ -332,8 +339,11 @@ def main():
         inv_norm = 1.0 / (3.0 * size * size * vps * world)
         neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
         reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed) else None
+        exchange = ShFactorExchange(model._features_dc, model._features_rest, world, force=force_ddp) if (reducer is not None and sh_factor) else None
 
         def step():
+            if exchange is not None:
+                exchange.enable()
             model.update_alpha()
             model.prepare_scaling_rot()
             images = [render(c, model, pipe, bg)["render"] for c in cams]
@@ -346,8 +356,13 @@ def main():
                 with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
                     grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
                 torch.autograd.backward(images, grads)
+            if exchange is not None:
+                exchange.start()      # all-gather of this rank's [P+1,3] factors
             if reducer is not None:
                 reducer.finish()      # collectives were started from autograd hooks during backward
+            if exchange is not None:
+                exchange.finish(model.get_xyz, model.active_sh_degree)
+                exchange.disable()
             if args.optimizer != "none":
                 model.optimizer.step()
                 model.optimizer.zero_grad(set_to_none=True)
@@ -443,6 +458,10 @@ def main():
         extra["allreduce_algorithms_ms"] = allreduce_times
         extra["allreduce_algorithm"] = algo
         extra["allreduce_bytes"] = allreduce_bytes
+        extra["sh_exchange"] = ("factor: all-gather of [P+1,3] colour-gradient factors + gms_sh_grad_expand" if sh_factor
+                                else "dense: the SH gradient travels inside the all-reduce")
+        if sh_factor:
+            extra["sh_factor_gather_bytes"] = 4 * 3 * (int(model.get_xyz.shape[0]) + 1) * vps * world
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)

@@ -36,6 +36,7 @@ struct PreBwdArgs {
     int rezero;             // clear each record after reading it
     float *dL_dmean2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscales, *dL_drots;
+    float *dL_dcolor_sh;    // SH path, factorised mode: clamp-masked dL/dcolour [P,3] INSTEAD of the SH gradient rows
 };
 
 // SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
@@ -167,6 +168,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dscale[3] = {0.f, 0.f, 0.f};
     float drot[4] = {0.f, 0.f, 0.f, 0.f};
+    float dcol_sh[3] = {0.f, 0.f, 0.f};
     // the Gaussian's 64-byte gradient record (three coalesced float4 loads)
     float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga, gc4 = ga;
     if (valid) {
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
             const unsigned cl = a.clamped[i];
             float dRGB[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) dRGB[c] = ((cl >> c) & 1u) ? 0.f : acc_col[c];
+            for (int c = 0; c < 3; c++) { dRGB[c] = ((cl >> c) & 1u) ? 0.f : acc_col[c]; dcol_sh[c] = dRGB[c]; }
             float gdir[3] = {0.f, 0.f, 0.f};
             switch (a.D) {
             case 0: sh_backward<0>(row, x, y, z, dRGB, gdir); break;
@@ -326,7 +328,9 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     }
 
     // ---- SH gradient rows: zero what was not written, then stream the wave's rows out coalesced
-    if (use_sh && split) {
+    // (factorised mode: dL/dsh = Y(dir) x dL/dcolour is formed later, by sh_grad_expand, from the [P,3] factor written below)
+    if (use_sh && a.dL_dcolor_sh) {
+    } else if (use_sh && split) {
         for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < 12; q++)
             *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         wave_sync();      // the rows are this wave's own
@@ -368,6 +372,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     a.dL_dopacity[i] = dop;
     a.dL_dmean2D[3 * (size_t)i] = acc_mx; a.dL_dmean2D[3 * (size_t)i + 1] = acc_my; a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
     if (a.dL_dcolors) { a.dL_dcolors[3 * (size_t)i] = acc_col[0]; a.dL_dcolors[3 * (size_t)i + 1] = acc_col[1]; a.dL_dcolors[3 * (size_t)i + 2] = acc_col[2]; }
+    if (a.dL_dcolor_sh) { a.dL_dcolor_sh[3 * (size_t)i] = dcol_sh[0]; a.dL_dcolor_sh[3 * (size_t)i + 1] = dcol_sh[1]; a.dL_dcolor_sh[3 * (size_t)i + 2] = dcol_sh[2]; }
     a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1]; a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     if (a.cov3Dp) {
         if (a.dL_dcov3D)
@@ -376,6 +381,82 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     } else {
         a.dL_dscales[3 * (size_t)i] = dscale[0]; a.dL_dscales[3 * (size_t)i + 1] = dscale[1]; a.dL_dscales[3 * (size_t)i + 2] = dscale[2];
         *reinterpret_cast<float4 *>(a.dL_drots + 4 * (size_t)i) = make_float4(drot[0], drot[1], drot[2], drot[3]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------ factorised SH gradient
+// dL/dsh[k][c] of one view is the outer product Y_k(dir) * dL/dcolour_c (clamp mask folded into dL/dcolour), and dir depends
+// only on the Gaussian's position and that view's camera centre.  A multi-view step therefore exchanges the [P,3] factors of
+// its views (3 floats per Gaussian per view instead of 48) and forms  sum_v Y(dir_v) (x) g_v  here, views in index order.
+// The basis values are the `bv` terms of sh_backward above, same expressions: with one view this reproduces the dense
+// gradient bit for bit.
+struct ShExpandArgs {
+    int P, D, M, V;
+    const float *means3D;      // [P,3]
+    const float *campos;       // [V,3]
+    const float *factors;      // [V,P,3] clamp-masked dL/dcolour of every view
+    size_t stride;             // floats between views
+    float *dL_dsh;             // [P,M,3], or [P,1,3] with dL_dsh_rest = [P,M-1,3]
+    float *dL_dsh_rest;
+    int accumulate;            // add to the destination instead of overwriting it
+};
+
+template <int DEG>
+__device__ __forceinline__ void sh_basis(float x, float y, float z, float *Y)
+{
+    Y[0] = SH_C0;
+    if (DEG > 0) { Y[1] = -SH_C1 * y; Y[2] = SH_C1 * z; Y[3] = -SH_C1 * x; }
+    if (DEG > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        Y[4] = SH_C2[0] * x * y; Y[5] = SH_C2[1] * y * z; Y[6] = SH_C2[2] * (2.f * zz - xx - yy);
+        Y[7] = SH_C2[3] * x * z; Y[8] = SH_C2[4] * (xx - yy);
+    }
+    if (DEG > 2) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        Y[9] = SH_C3[0] * y * (3.f * xx - yy); Y[10] = SH_C3[1] * x * y * z; Y[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+        Y[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); Y[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+        Y[14] = SH_C3[5] * z * (xx - yy); Y[15] = SH_C3[6] * x * (xx - 3.f * yy);
+    }
+}
+
+template <int DEG>
+__global__ void __launch_bounds__(BLOCK) sh_grad_expand_kernel(ShExpandArgs a)
+{
+    constexpr int NB = (DEG + 1) * (DEG + 1);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= a.P) return;
+    const float px = a.means3D[3 * (size_t)i], py = a.means3D[3 * (size_t)i + 1], pz = a.means3D[3 * (size_t)i + 2];
+    float acc[NB * 3];
+#pragma unroll
+    for (int k = 0; k < NB * 3; k++) acc[k] = 0.f;
+    for (int v = 0; v < a.V; v++) {
+        const float *gp = a.factors + (size_t)v * a.stride + (size_t)i * 3;
+        const float g[3] = {gp[0], gp[1], gp[2]};
+        if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;      // not seen by this view (adds exact zeros)
+        const float ddx = px - a.campos[3 * v], ddy = py - a.campos[3 * v + 1], ddz = pz - a.campos[3 * v + 2];
+        const float inv = 1.f / sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+        float Y[16];
+        sh_basis<DEG>(ddx * inv, ddy * inv, ddz * inv, Y);
+#pragma unroll
+        for (int k = 0; k < NB; k++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) acc[k * 3 + c] += Y[k] * g[c];
+    }
+    // destination rows (all indices of `acc` static); coefficients above the active degree get zero
+    float *d0 = a.dL_dsh + (size_t)i * (a.dL_dsh_rest ? 3 : a.M * 3);
+    float *d1 = a.dL_dsh_rest ? a.dL_dsh_rest + (size_t)i * ((a.M - 1) * 3) : d0 + 3;
+    if (a.accumulate) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) d0[c] += acc[c];
+#pragma unroll
+        for (int k = 3; k < NB * 3; k++) d1[k - 3] += acc[k];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) d0[c] = acc[c];
+#pragma unroll
+        for (int k = 3; k < NB * 3; k++) d1[k - 3] = acc[k];
+        for (int k = NB * 3; k < a.M * 3; k++) d1[k - 3] = 0.f;
     }
 }
 
@@ -397,7 +478,8 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     const bool sr = A->scales && A->rotations;
     if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
         !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || !A->dL_dopacity || (A->colors_precomp && !A->dL_dcolors) ||
-        !A->dL_dmeans3D || (A->shs && !A->dL_dsh) || (A->shs_rest && (!A->dL_dsh_rest || A->M != 16)) || ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
+        !A->dL_dmeans3D || (A->shs && !A->dL_dsh && !A->dL_dcolors) || (A->shs_rest && ((!A->dL_dsh_rest && !A->dL_dcolors) || A->M != 16)) ||
+        ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
         (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
         (A->cov3D_precomp && !A->dL_dcov3D)) {
         set_error("gms_rasterize_backward: null or inconsistent pointer arguments");
@@ -432,9 +514,35 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
-    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
+    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = A->shs ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
+    return GMS_OK;
+}
+
+extern "C" int32_t gms_sh_grad_expand(const GmsShGradExpandArgs *A, void *stream_)
+{
+    gms::TraceRange trace_range("gms_sh_grad_expand");
+    hipStream_t stream = (hipStream_t)stream_;
+    set_error("%s", "");
+    if (!A || A->P < 0 || A->V < 1 || A->D < 0 || A->D > 3 || A->M < (A->D + 1) * (A->D + 1) || !A->means3D || !A->campos || !A->factors || (A->factor_stride != 0 && A->factor_stride < (int64_t)A->P * 3) ||
+        !A->dL_dsh || (A->dL_dsh_rest && A->M < 2)) {
+        set_error("gms_sh_grad_expand: invalid sizes or null pointer arguments");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    if (A->P == 0) return GMS_OK;
+    ShExpandArgs e;
+    e.P = A->P; e.D = A->D; e.M = A->M; e.V = A->V; e.means3D = A->means3D; e.campos = A->campos; e.factors = A->factors;
+    e.stride = A->factor_stride > 0 ? (size_t)A->factor_stride : (size_t)A->P * 3;
+    e.dL_dsh = A->dL_dsh; e.dL_dsh_rest = A->dL_dsh_rest; e.accumulate = A->accumulate;
+    const unsigned blocks = (unsigned)((A->P + BLOCK - 1) / BLOCK);
+    switch (A->D) {
+    case 0: GMS_LAUNCH(GMS_K_SH_EXPAND, stream, sh_grad_expand_kernel<0><<<blocks, BLOCK, 0, stream>>>(e)); break;
+    case 1: GMS_LAUNCH(GMS_K_SH_EXPAND, stream, sh_grad_expand_kernel<1><<<blocks, BLOCK, 0, stream>>>(e)); break;
+    case 2: GMS_LAUNCH(GMS_K_SH_EXPAND, stream, sh_grad_expand_kernel<2><<<blocks, BLOCK, 0, stream>>>(e)); break;
+    default: GMS_LAUNCH(GMS_K_SH_EXPAND, stream, sh_grad_expand_kernel<3><<<blocks, BLOCK, 0, stream>>>(e)); break;
+    }
+    GMS_KERNEL_CHECK(A->debug, stream, "sh_grad_expand");
     return GMS_OK;
 }

@@ -18,9 +18,11 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 #include "../../include/gmsplat.h"
 
@@ -148,6 +150,12 @@ struct Backward { Tensor dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dsh
 // The gradient outputs of a backward call.  The autograd fast path allocates them in FORWARD, before the C call (there the
 // host runs ahead of the GPU and then waits for the instance count anyway), so that between "N has arrived" and "blend_bwd is
 // enqueued" -- the stretch in which a slow host lets the GPU run dry -- no allocation remains.
+// ---- factorised SH gradient (multi-view steps; gms_sh_grad_expand in include/gmsplat.h).  While the mode is on, a backward on
+// the SH path writes no dL/dsh: it leaves a [P+1,3] tensor -- rows 0..P-1 the clamp-masked dL/dcolour of that view, row P the
+// view's camera centre -- in a per-process list that the caller takes (take_sh_factors), exchanges between ranks and expands.
+static std::atomic<bool> g_sh_factor{false};
+static std::vector<Tensor> g_factors;
+
 Backward alloc_backward(const Tensor &means3D, const Tensor &opac, const Tensor &sh, const Tensor &sh_rest, const Tensor &cov)
 {
     const int64_t P = means3D.size(0);
@@ -158,9 +166,11 @@ Backward alloc_backward(const Tensor &means3D, const Tensor &opac, const Tensor 
     b.dmeans2D = torch::empty({P, 3}, fopt);
     b.dopacity = torch::empty(opac.sizes(), fopt);
     b.dmeans3D = torch::empty({P, 3}, fopt);
+    const bool factor = has_sh && g_sh_factor.load();
     if (!has_sh) b.dcolors = torch::empty({P, 3}, fopt);
-    if (has_sh) b.dsh = torch::empty(sh.sizes(), fopt);
-    if (split) b.dsh_rest = torch::empty(sh_rest.sizes(), fopt);
+    if (factor) b.dcolors = torch::empty({P + 1, 3}, fopt);
+    if (has_sh && !factor) b.dsh = torch::empty(sh.sizes(), fopt);
+    if (split && !factor) b.dsh_rest = torch::empty(sh_rest.sizes(), fopt);
     if (has_cov) b.dcov3D = torch::empty({P, 6}, fopt);
     else { b.dscales = torch::empty({P, 3}, fopt); b.drots = torch::empty({P, 4}, fopt); }
     return b;
@@ -209,6 +219,11 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
     a.dL_dscales = mf(b.dscales); a.dL_drotations = mf(b.drots);
     a.grad_accum_rezero = 1; a.num_units = num_units;
     if (P > 0) check_rc(gms_rasterize_backward(&a, stream), "gms_rasterize_backward");
+    if (has_sh && b.dcolors.defined()) {          // factorised mode: append the camera centre, queue the factor for the exchange
+        b.dcolors.narrow(0, P, 1).copy_(campos.reshape({1, 3}));
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_factors.push_back(b.dcolors);
+    }
     {   // only a call that completed hands its (re-zeroed) buffer back
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_accum.size() >= 8) g_accum.clear();
@@ -313,6 +328,7 @@ public:
                                    ctx->saved_data["units"].toInt(), binning, image, ctx->saved_data["aa"].toBool(),
                                    ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
         Tensor none;
+        if (sh.defined() && sh.numel() > 0) b.dcolors = none;          // (factorised mode: the factor is not a gradient of `colors`)
         return {b.dmeans3D, b.dmeans2D, b.dsh, b.dsh_rest, b.dcolors, b.dopacity, b.dscales, b.drots, b.dcov3D,
                 none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
@@ -330,6 +346,43 @@ std::tuple<Tensor, Tensor, Tensor> rasterize(const Tensor &means3D, const Tensor
     auto out = RasterizeFn::apply(means3D, means2D, sh, sh_rest, colors, opacities, scales, rotations, cov3D, bg, view, proj, campos, H,
                                   W, tanx, tany, mod, D, prefiltered, aa, debug, visible_out, use_hint, will_backward);
     return std::make_tuple(out[0], out[1], out[2]);
+}
+
+void set_sh_factor_mode(bool on)
+{
+    g_sh_factor = on;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_factors.clear();
+}
+bool sh_factor_mode() { return g_sh_factor.load(); }
+std::vector<Tensor> take_sh_factors()
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<Tensor> out;
+    out.swap(g_factors);
+    return out;
+}
+
+// dsh (+)= sum_v Y(dir_v) (x) factor_v;  factors = [V,P+1,3] as queued by the backward calls (possibly gathered from all ranks)
+void sh_grad_expand(const Tensor &factors, const Tensor &means3D, int64_t D, Tensor dsh, Tensor dsh_rest, bool accumulate)
+{
+    require_gpu(means3D);
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(means3D.device());
+    TORCH_CHECK(factors.dim() == 3 && factors.size(2) == 3 && factors.size(1) == means3D.size(0) + 1 && factors.is_contiguous() &&
+                factors.scalar_type() == torch::kFloat && factors.device() == means3D.device(),
+                "sh_grad_expand: factors must be a contiguous float32 [V, P+1, 3] tensor on the device of means3D");
+    TORCH_CHECK(dsh.defined() && dsh.is_contiguous() && dsh.scalar_type() == torch::kFloat, "sh_grad_expand: dsh must be contiguous float32");
+    const int64_t P = means3D.size(0), V = factors.size(0);
+    const bool split = dsh_rest.defined() && dsh_rest.numel() > 0;
+    if (split) TORCH_CHECK(dsh_rest.is_contiguous() && dsh_rest.scalar_type() == torch::kFloat, "sh_grad_expand: dsh_rest must be contiguous float32");
+    const int64_t M = split ? dsh.numel() / std::max<int64_t>(P * 3, 1) + dsh_rest.numel() / std::max<int64_t>(P * 3, 1) : dsh.numel() / std::max<int64_t>(P * 3, 1);
+    Tensor pos = f32c(means3D.detach());
+    Tensor campos = factors.select(1, P).contiguous();        // [V,3]
+    GmsShGradExpandArgs a{};
+    a.P = (int32_t)P; a.D = (int32_t)D; a.M = (int32_t)M; a.V = (int32_t)V; a.means3D = cf(pos); a.campos = cf(campos);
+    a.factors = cf(factors); a.factor_stride = (P + 1) * 3; a.dL_dsh = mf(dsh); a.dL_dsh_rest = split ? mf(dsh_rest) : nullptr;
+    a.accumulate = accumulate; a.debug = 0;
+    if (P > 0 && V > 0) check_rc(gms_sh_grad_expand(&a, stream_of(means3D)), "gms_sh_grad_expand");
 }
 
 py::dict last_stats()
@@ -527,6 +580,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization");
     m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]");
     m.def("adam_step", &adam_step);
+    m.def("set_sh_factor_mode", &set_sh_factor_mode, "factorised SH gradient: backward calls queue [P+1,3] factors instead of writing dL/dsh");
+    m.def("sh_factor_mode", &sh_factor_mode);
+    m.def("take_sh_factors", &take_sh_factors);
+    m.def("sh_grad_expand", &sh_grad_expand, "dsh (+)= sum_v Y(dir_v) (x) factor_v over the [V,P+1,3] factors");
     m.def("last_stats", &last_stats);
     m.def("set_capacity", &set_capacity);
     m.def("clear_capacity", &clear_capacity);

@@ -115,6 +115,35 @@ def clear_capacity_hints() -> None:
     _capacity_cache.clear()
 
 
+def set_sh_factor_mode(on: bool) -> None:
+    """Factorised SH gradient for multi-view steps (include/gmsplat.h, gms_sh_grad_expand).  While on, a backward on the SH path
+    writes NO dL/dsh (the `shs` gradient is None): it queues a [P+1,3] tensor -- rows 0..P-1 the clamp-masked dL/dcolour of that
+    view, row P its camera centre.  Take the queue with `take_sh_factors()`, exchange it between ranks (3 floats per Gaussian
+    per view instead of 48) and form the SH gradient with `sh_grad_expand`.  games_hip.ddp.ShFactorExchange does all of it."""
+    if _C is None:
+        raise NotImplementedError("the factorised SH gradient needs the _C extension module (GMS_BINDING=ctypes has no such path)")
+    _C.set_sh_factor_mode(bool(on))
+
+
+def sh_factor_mode() -> bool:
+    return _C is not None and bool(_C.sh_factor_mode())
+
+
+def take_sh_factors() -> list:
+    """The factors queued by the backward calls since the last take (or since the mode was switched on), oldest first."""
+    return list(_C.take_sh_factors()) if _C is not None else []
+
+
+def sh_grad_expand(factors: torch.Tensor, means3D: torch.Tensor, sh_degree: int, dL_dsh: torch.Tensor,
+                   dL_dsh_rest: Optional[torch.Tensor] = None, accumulate: bool = False) -> None:
+    """dL_dsh (+)= sum_v Y(normalize(means3D - campos_v)) (x) factor_v for `factors` = [V,P+1,3] (as queued by the backward
+    calls, stacked; possibly gathered from all ranks), views in index order.  dL_dsh is [P,M,3], or the [P,1,3] DC block
+    together with dL_dsh_rest = [P,M-1,3] (the split storage of `_features_dc` / `_features_rest`)."""
+    if _C is None:
+        raise NotImplementedError("sh_grad_expand needs the _C extension module")
+    _C.sh_grad_expand(factors, means3D, int(sh_degree), dL_dsh, dL_dsh_rest if dL_dsh_rest is not None else torch.Tensor(), bool(accumulate))
+
+
 def raw_buffers() -> dict:
     """The scratch tensors of the most recent forward (geom / binning / image byte buffers): diagnostics only."""
     d = _C.last_stats() if _C is not None else _last_stats

@@ -73,6 +73,15 @@ class LossArgs(C.Structure):
     ]
 
 
+class ShGradExpandArgs(C.Structure):
+    """GmsShGradExpandArgs (include/gmsplat.h)."""
+    _fields_ = [
+        ("P", C.c_int32), ("D", C.c_int32), ("M", C.c_int32), ("V", C.c_int32), ("means3D", C.c_void_p), ("campos", C.c_void_p),
+        ("factors", C.c_void_p), ("factor_stride", C.c_int64), ("dL_dsh", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
+        ("accumulate", C.c_int32), ("debug", C.c_int32),
+    ]
+
+
 class AdamTensor(C.Structure):
     _fields_ = [
         ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
@@ -87,8 +96,9 @@ EXPORTS = (
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
+    "gms_sh_grad_expand",
 )
-K_COUNT = 15
+K_COUNT = 16
 
 _lock = threading.Lock()
 _lib = None
@@ -138,6 +148,8 @@ def load():
         lib.gms_l1_ssim_backward.argtypes = [C.POINTER(LossArgs)] + [C.c_void_p] * 4
         lib.gms_adam_step.restype = C.c_int32
         lib.gms_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        lib.gms_sh_grad_expand.restype = C.c_int32
+        lib.gms_sh_grad_expand.argtypes = [C.POINTER(ShGradExpandArgs), C.c_void_p]
         lib.gms_last_deepest_tile.restype = C.c_int64
         lib.gms_wait_stats.restype = None
         lib.gms_wait_stats.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]

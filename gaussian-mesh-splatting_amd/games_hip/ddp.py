@@ -177,3 +177,68 @@ class OverlappedGradAllReduce:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+
+class ShFactorExchange:
+    """Multi-view steps without the 54 MB SH-gradient all-reduce (include/gmsplat.h, gms_sh_grad_expand).
+
+    Per view, dL/d(sh coefficients) is an outer product: Y(dir) (x) dL/dcolour, where dir depends only on the Gaussian's
+    position and the view's camera centre -- replicated knowledge.  While this exchange is enabled the rasterizer's backward
+    writes no SH gradient; it queues the [P+1,3] factor of each view (row P = camera centre).  `start()` all-gathers the
+    factors of this rank's views (3.6 MB per view at 300 k Gaussians instead of 57.5 MB of dense SH gradient), `finish()`
+    forms  sum over all views of all ranks  Y(dir_v) (x) g_v  on every rank, views in (rank, view) order -- bit-identical
+    everywhere -- and stores it as `.grad` of the two feature tensors (accumulating into an existing `.grad`).
+
+    The other gradients (alpha, scale, opacity, vertices: ~6 MB) stay with `OverlappedGradAllReduce`, whose hooks never see
+    the feature tensors in this mode (autograd produces no gradient for them).
+
+    `ops` = (set_mode, take, expand) defaults to the HIP path of `diff_gaussian_rasterization`; the CPU tests inject the
+    oracle's restatements (tests/test_ddp_cpu.py)."""
+
+    def __init__(self, features_dc: torch.Tensor, features_rest: torch.Tensor, world: int, group=None, force: bool = False, ops=None):
+        if ops is None:
+            import diff_gaussian_rasterization as dgr
+            ops = (dgr.set_sh_factor_mode, dgr.take_sh_factors, dgr.sh_grad_expand)
+        self._set_mode, self._take, self._expand = ops
+        self.f_dc, self.f_rest = features_dc, features_rest
+        self.world, self.group = int(world), group
+        self._comm = (self.world > 1 or force) and dist.is_initialized()
+        self._work, self._gathered = None, None
+
+    def enable(self) -> "ShFactorExchange":
+        self._set_mode(True)
+        return self
+
+    def disable(self) -> None:
+        self._set_mode(False)
+
+    def start(self) -> None:
+        """Right after `backward()`: take the factors this rank's views left behind and start gathering everybody's."""
+        facs = self._take()
+        if not facs:
+            raise RuntimeError("ShFactorExchange.start(): no factor was queued -- was backward() run on the SH path with the mode on?")
+        local = facs[0].unsqueeze(0) if len(facs) == 1 else torch.stack(facs)          # [v, P+1, 3]
+        if self._comm:
+            self._gathered = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            self._work = dist.all_gather_into_tensor(self._gathered, local.contiguous(), group=self.group, async_op=True)
+        else:
+            self._gathered, self._work = local.contiguous(), None
+
+    def finish(self, means3D: torch.Tensor, sh_degree: int, scale: float = 1.0) -> None:
+        """Wait for the gather and write the SH gradients.  `scale` multiplies the sum (1/world for an averaged loss whose
+        upstream gradient was not pre-divided)."""
+        if self._gathered is None:
+            self.start()
+        if self._work is not None:
+            self._work.wait()
+        P = means3D.shape[0]
+        dc = torch.empty((P, 1, 3), dtype=torch.float32, device=means3D.device)
+        rest = torch.empty((P, self.f_rest.shape[1], 3), dtype=torch.float32, device=means3D.device)
+        self._expand(self._gathered, means3D.detach(), int(sh_degree), dc, rest, False)
+        if scale != 1.0:
+            dc.mul_(scale); rest.mul_(scale)
+        for p, g in ((self.f_dc, dc), (self.f_rest, rest)):
+            g = g.view(p.shape).to(p.dtype)
+            p.grad = g if p.grad is None else p.grad.add_(g)
+        self._gathered, self._work = None, None
+

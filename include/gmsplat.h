@@ -137,7 +137,11 @@ typedef struct GmsRasterBackwardArgs {
     /* outputs (device), all fully overwritten (no zero-fill needed) */
     float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column = 0 */
     float *dL_dopacity;    /* [P] */
-    float *dL_dcolors;     /* [P,3] written only when colors_precomp != NULL (else may be NULL) */
+    float *dL_dcolors;     /* [P,3] colors_precomp path: gradient of the colours.  SH path: NULL for the dense SH gradient; when
+                              non-NULL the call runs in FACTORISED mode -- it writes the clamp-masked dL/dcolour of this view here and
+                              does NOT write dL_dsh / dL_dsh_rest (they may be NULL): dL/dsh = Y(dir) (x) dL/dcolour is formed later by
+                              gms_sh_grad_expand, for one view or for the gathered factors of many (multi-GPU: 3 floats per Gaussian
+                              per view travel instead of 48) */
     float *dL_dmeans3D;    /* [P,3] */
     float *dL_dcov3D;      /* [P,6] written only when cov3D_precomp != NULL (else may be NULL) */
     float *dL_dsh;         /* [P,M,3] written only when shs != NULL ([P,1,3] DC block in split storage) */
@@ -152,6 +156,25 @@ typedef struct GmsRasterBackwardArgs {
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);
+
+/* SH gradient from per-view colour-gradient factors (see dL_dcolors above):
+ *   dL_dsh[i][k][c] (+)= sum_v Y_k(normalize(means3D[i] - campos[v])) * factors[v][i][c],  views in index order.
+ * With V = 1 and the factor of the same backward call this equals the dense dL_dsh of gms_rasterize_backward bit for bit.
+ * The reference has no counterpart (it is single-GPU, train.py:90-92 pops one camera per step); the dense result it
+ * replaces is the dL_dsh of submodules/diff-gaussian-rasterization (computeColorFromSH backward), SURVEY.md A.5. */
+typedef struct GmsShGradExpandArgs {
+    int32_t P, D, M;           /* Gaussians, active SH degree (0..3), coefficients per Gaussian in the destination rows */
+    int32_t V;                 /* views */
+    const float *means3D;      /* [P,3] */
+    const float *campos;       /* [V,3] camera centres (device) */
+    const float *factors;      /* [V,P,3] clamp-masked dL/dcolour of every view (device); view v starts at factors + v*factor_stride */
+    int64_t factor_stride;     /* floats between consecutive views; 0 = 3*P (densely packed) */
+    float *dL_dsh;             /* [P,M,3]; or the [P,1,3] DC block when dL_dsh_rest is given */
+    float *dL_dsh_rest;        /* [P,M-1,3] or NULL */
+    int32_t accumulate;        /* 0: overwrite the destination, 1: add to it */
+    int32_t debug;
+} GmsShGradExpandArgs;
+int32_t gms_sh_grad_expand(const GmsShGradExpandArgs *args, void *stream);
 
 /* present[i] = 1 iff Gaussian i passes the near-plane test (view-space z > 0.2). */
 int32_t gms_mark_visible(int32_t P, const float *means3D, const float *viewmatrix, const float *projmatrix,
@@ -270,7 +293,8 @@ int32_t gms_adam_step(const GmsAdamTensor *tensors /* HOST array */, int32_t cou
 #define GMS_K_LOSS_FWD 12
 #define GMS_K_LOSS_BWD 13
 #define GMS_K_ADAM 14
-#define GMS_K_COUNT 15
+#define GMS_K_SH_EXPAND 15
+#define GMS_K_COUNT 16
 void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);

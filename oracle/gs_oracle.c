@@ -506,7 +506,9 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                  real *dL_dmeans3D, real *dL_dmeans2D /*[P,3]*/, real *dL_dsh /*[P,M,3]*/,
                  real *dL_dcolors /*[P,3]*/, real *dL_dopacity /*[P]*/, real *dL_dscales /*[P,3]*/,
                  real *dL_drotations /*[P,4]*/, real *dL_dcov3D /*[P,6]*/,
-                 real *dL_dconic_out /*[P,4] optional debug*/)
+                 real *dL_dconic_out /*[P,4] optional debug*/,
+                 real *dL_dcolor_sh /*[P,3] optional, SH path: the clamp-masked dL/dcolour (zero-initialised by the caller) --
+                                      the per-view factor of the factorised SH gradient, dL/dsh[k][c] = Y_k(dir) * this[c] */)
 {
     set_threads(sc->nthreads);
     const int P = st->P, W = st->W, H = st->H, gx = st->gx;
@@ -696,6 +698,7 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
                 const real *sh = sc->shs + (size_t)i * M * 3;
                 real dRGB[3];
                 for (int cc = 0; cc < 3; cc++) dRGB[cc] = st->clamped[3 * (size_t)i + cc] ? 0 : (real)ga[G_R + cc];
+                if (dL_dcolor_sh) for (int cc = 0; cc < 3; cc++) dL_dcolor_sh[3 * (size_t)i + cc] = dRGB[cc];
                 real basis[16], bdx[16], bdy[16], bdz[16];
                 for (int q = 0; q < 16; q++) basis[q] = bdx[q] = bdy[q] = bdz[q] = 0;
                 basis[0] = SH_C0;

@@ -62,7 +62,7 @@ def _lib(precision: str):
         lib.or_forward.restype = C.c_void_p
         lib.or_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.or_backward.restype = None
-        lib.or_backward.argtypes = [C.c_void_p] * 13
+        lib.or_backward.argtypes = [C.c_void_p] * 14
         lib.or_free.argtypes = [C.c_void_p]
         lib.or_state_N.restype = C.c_long
         lib.or_state_N.argtypes = [C.c_void_p]
@@ -194,8 +194,9 @@ def backward(out: OracleOutput, grad_color, grad_invdepth=None) -> dict:
         means3D=np.zeros((Pn, 3), dt), means2D=np.zeros((Pn, 3), dt), sh=np.zeros((Pn, max(M, 1), 3), dt),
         colors_precomp=np.zeros((Pn, 3), dt), opacities=np.zeros((Pn, 1), dt), scales=np.zeros((Pn, 3), dt),
         rotations=np.zeros((Pn, 4), dt), cov3D_precomp=np.zeros((Pn, 6), dt), conic=np.zeros((Pn, 4), dt),
+        sh_factor=np.zeros((Pn, 3), dt),       # SH path: clamp-masked dL/dcolour (dL/dsh[k][c] = Y_k(dir) * sh_factor[c])
     )
     lib.or_backward(C.byref(sc), st._h, _ptr(gc), _ptr(gd), _ptr(g["means3D"]), _ptr(g["means2D"]),
                     _ptr(g["sh"]) if M > 0 else None, _ptr(g["colors_precomp"]), _ptr(g["opacities"]),
-                    _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(g["conic"]))
+                    _ptr(g["scales"]), _ptr(g["rotations"]), _ptr(g["cov3D_precomp"]), _ptr(g["conic"]), _ptr(g["sh_factor"]))
     return {k: v[:P] for k, v in g.items()}

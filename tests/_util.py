@@ -53,6 +53,7 @@ def oracle_render(inputs: dict, kw: dict, grad_color=None, grad_invdepth=None, p
         res["grads"] = dict(means3D=g["means3D"], means2D=g["means2D"], shs=g["sh"], colors_precomp=g["colors_precomp"],
                             opacities=g["opacities"], scales=g["scales"], rotations=g["rotations"],
                             cov3D_precomp=g["cov3D_precomp"])
+        res["sh_factor"] = g["sh_factor"]      # SH path: clamp-masked dL/dcolour per Gaussian (factorised SH gradient)
     return res
 
 

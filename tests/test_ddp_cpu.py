@@ -166,3 +166,83 @@ def test_direct_two_phase_allreduce_equals_allreduce():
             mean = sum(torch.from_numpy(r[2][k]) for r in res) / world
             for r in res:
                 torch.testing.assert_close(torch.from_numpy(r[3][k]), mean, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------- factorised SH-gradient exchange
+def _sh_view(rank_view, P=300, size=48):
+    """One view of a shared random SH-degree-3 scene through the C oracle: dense dL/dsh, the [P+1,3] factor, positions."""
+    import numpy as np
+    import _util as U
+    from games_hip import synthetic as syn
+    sc = syn.random_scene(P, seed=77, scale_lo=0.05, scale_hi=0.4, opacity_lo=0.3, opacity_hi=0.9)
+    cam = syn.orbit_camera(rank_view, width=size, height=size)
+    kw = U.settings_kwargs(cam, torch.tensor([0.2, 0.4, 0.1]), sh_degree=3)
+    inputs = dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    o = U.oracle_render(inputs, kw)
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 100.0
+    o = U.oracle_render(inputs, kw, gc, None)
+    factor = torch.cat([torch.from_numpy(np.asarray(o["sh_factor"], np.float32)), cam.camera_center.reshape(1, 3).float()])
+    return sc, torch.from_numpy(np.asarray(o["grads"]["shs"], np.float32)), factor, o
+
+
+def test_sh_gradient_is_the_sum_of_per_view_outer_products():
+    """The identity behind gms_sh_grad_expand: dense dL/dsh of every view, summed == expand(stacked [P+1,3] factors).  The
+    oracle's clamp mask is exercised (some colour channels clamp at 0 in this scene) and so are invisible Gaussians."""
+    from oracle import sh_expand_ref
+    views = [_sh_view(v) for v in (0, 3, 5)]
+    sc = views[0][0]
+    dense = sum(v[1] for v in views)
+    got = sh_expand_ref.expand(torch.stack([v[2] for v in views]), sc.means3D, 3, 16)
+    scale = float(dense.abs().max())
+    assert scale > 0 and float((got - dense).abs().max()) <= 2e-6 * scale
+    assert any((v[3]["details"]["clamped"] != 0).any() for v in views)                   # the mask mattered
+    one = sh_expand_ref.expand(views[1][2][None], sc.means3D, 3, 16)
+    assert float((one - views[1][1]).abs().max()) <= 2e-6 * float(views[1][1].abs().max())
+
+
+def _factor_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from games_hip.ddp import ShFactorExchange
+        from oracle import sh_expand_ref
+        vps = 2                                                     # two views per rank: rank r renders views 2r, 2r+1
+        mine = [_sh_view(rank * vps + j) for j in range(vps)]
+        sc = mine[0][0]
+        queue = [m[2] for m in mine]
+        state = {"mode": False}
+
+        def expand(factors, means3D, deg, dc, rest, accumulate):
+            full = sh_expand_ref.expand(factors, means3D, deg, 16)
+            dc.copy_(full[:, :1]); rest.copy_(full[:, 1:])
+
+        f_dc = torch.zeros(sc.means3D.shape[0], 1, 3, requires_grad=True)
+        f_rest = torch.zeros(sc.means3D.shape[0], 15, 3, requires_grad=True)
+        ex = ShFactorExchange(f_dc, f_rest, world, ops=(lambda on: state.update(mode=on), lambda: [queue.pop(0) for _ in range(len(queue))], expand))
+        ex.enable()
+        ex.start()
+        ex.finish(sc.means3D, 3)
+        ex.disable()
+        q.put((rank, torch.cat([f_dc.grad, f_rest.grad], dim=1).clone(), sum(m[1] for m in mine), state["mode"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sh_factor_exchange_world2_equals_the_sum_of_dense_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_factor_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    dense = res[0][2] + res[1][2]                                   # four views in all
+    scale = float(dense.abs().max())
+    for rank, got, _, mode in res:
+        assert mode is False
+        assert float((got - dense).abs().max()) <= 2e-6 * scale, rank
+    assert torch.equal(res[0][1], res[1][1])                        # same views, same order: bit-identical on every rank
