@@ -138,6 +138,19 @@ def cpu_baseline(workload, state, max_seconds=12.0):
                       f"({oracle_threads} threads, fastest of 16/32/64/128) + torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
 
 
+def kernel_source_hash():
+    """sha256 (16 hex) over the kernel sources: profiles/pmc_traffic.json records the hash of the build its counters were
+    collected on (tools/make_pmc_traffic.py); counters from another build are NOT reported against this build's durations."""
+    import hashlib
+    d = os.path.join(ROOT, "gaussian-mesh-splatting_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 BASELINE_METRIC = "train iters/s (fwd+bwd raster) @800×800, 300k Gaussians; HBM GB/s vs roofline"
 VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-op/s (MI355X_MICROARCH.md)
 
@@ -251,7 +264,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     distributed = world > 1 or force_ddp
 
-    from diff_gaussian_rasterization import _lib, last_stats
+    from diff_gaussian_rasterization import _lib, keep_buffers, last_stats
     from games_hip import synthetic as syn
     from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce, ShFactorExchange
     from games_hip.render import PipelineParams, render
@@ -303,6 +316,9 @@ def main():
                 d.finish()
 
         for which in (("ring", "direct", "direct_ag") if args.allreduce == "auto" else (args.allreduce,)):
+            # a local failure is caught FIRST; then ONE agreement collective runs on every rank unconditionally (same dtype,
+            # same op everywhere): t = +inf on the rank that failed, MAX over ranks -> every rank reaches the same verdict
+            t_local, err = float("inf"), None
             try:
                 for _ in range(3):
                     collectives_once(which)
@@ -311,20 +327,15 @@ def main():
                 for _ in range(10):
                     collectives_once(which)
                 sync()
-                t = torch.tensor([(time.perf_counter() - t0) / 10], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                allreduce_times[which] = round(1000 * float(t.item()), 4)
+                t_local = (time.perf_counter() - t0) / 10
             except Exception as e:  # noqa: BLE001 - an algorithm the backend cannot run is simply not chosen
-                allreduce_times[which] = f"failed: {e!r}"[:200]
-            if which != "ring":
-                # every rank must reach the same verdict (one rank's failure must not leave the others with a different choice)
-                try:
-                    flag = torch.tensor([1.0 if isinstance(allreduce_times[which], float) else 0.0], device=device)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    if float(flag.item()) == 0.0 and isinstance(allreduce_times[which], float):
-                        allreduce_times[which] = "failed on another rank"
-                except Exception as e:  # noqa: BLE001
-                    allreduce_times[which] = f"failed: {e!r}"[:200]
+                err = f"failed: {e!r}"[:200]
+            t = torch.tensor([t_local], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            if math.isfinite(float(t.item())):
+                allreduce_times[which] = round(1000 * float(t.item()), 4)
+            else:
+                allreduce_times[which] = err or "failed on another rank"
         ok = {k: v for k, v in allreduce_times.items() if isinstance(v, float)}
         algo = min(ok, key=ok.get) if ok else "ring"
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
@@ -416,7 +427,7 @@ def main():
     # untimed pre-warm (~0.3 s of steps before the W warm-up steps): allocator pools, capacity / unit hints and the GPU's
     # clocks reach their steady state; two back-to-back runs on one box otherwise differ by 6 % (first run slower)
     if distributed:                      # the same number of steps on every rank: each step contains collectives
-        for _ in range(40):
+        for _ in range(int(os.environ.get("GMS_BENCH_PREWARM_STEPS", "300"))):
             step()
         torch.cuda.synchronize(device)
     else:
@@ -428,7 +439,10 @@ def main():
     elapsed = timed(step, args.steps, args.warmup)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * vps * args.steps / elapsed
+    keep_buffers(True)          # one untimed step whose scratch stays referenced: visible count / interactions for the JSON
+    step()
     stats = last_stats()
+    keep_buffers(False)
 
     # ---- several ranks: what the collective costs, measured in the same job
     extra = {}
@@ -480,9 +494,18 @@ def main():
         ab = algorithmic_bytes(P, N, F, size, size)
         pmc = {}
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        pmc_note = "no PMC counters committed for this workload"
         if os.path.exists(pmc_path):
             with open(pmc_path) as f:
-                pmc = json.load(f).get(f"{workload}/{args.state}", {})
+                pmc_all = json.load(f)
+            pmc = pmc_all.get(f"{workload}/{args.state}", {})
+            have, want = pmc.get("_source_hash"), kernel_source_hash()
+            if pmc and have != want:
+                # counters of another build say nothing about this build's kernels: report durations only
+                pmc_note = f"profiles/pmc_traffic.json was collected on kernel sources {have}, this build is {want}: counters withheld"
+                pmc = {}
+            elif pmc:
+                pmc_note = f"separate rocprofv3 --pmc passes of this workload on kernel sources {have} (= this build)"
         sq = pmc.get("_sq", {})
         if ktimes.get("mesh_bwd_splat", (0, 0))[1] == 0:       # K0 backward ran as one fused launch (booked as mesh_bwd_face)
             ab["mesh_bwd_face"] += ab["mesh_bwd_splat"]
@@ -491,7 +514,10 @@ def main():
             if n == 0:
                 continue
             avg_us = 1000.0 * ms / n
-            gbs = ab[name] / (avg_us * 1e-6) / 1e9
+            lps = n / max(args.profile_steps * vps, 1)       # launches per rendered view
+            # a stage that takes several launches per view (tile_sort: presort + merge; blend_head on deep scenes) is priced on
+            # the SUM of its launches: its algorithmic bytes are per view, not per launch
+            gbs = ab[name] / (avg_us * max(lps, 1.0) * 1e-6) / 1e9
             kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
                              "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
                              "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": pmc.get(name)}
@@ -507,25 +533,23 @@ def main():
         sum_kernel_us = sum(k["avg_us"] * k["launches_per_step"] for k in kernels.values())
         whole_bytes = vps * (877 * P + 156 * N + 48 * size * size) + 152 * P + 72 * F      # K0 runs once per step
         interactions = stats.get("interactions")
-        roofline = {"kernel": dom, "avg_launch_us": kd["avg_us"]}
+        # roofline of the dominant kernel, SURVEY.md 8(d): ALGORITHMIC bytes per launch / average launch duration (HIP events on
+        # the launch stream, measured in this run) against 8 TB/s; `traffic` = HBM bytes from the PMC passes (null when the
+        # committed counters belong to another build).  The compositing kernels have no dense contraction and gather 48-byte
+        # records out of L2 -- what actually bounds them is VALU issue, reported next to it under `valu`.
+        roofline = {"kernel": dom, "avg_launch_us": kd["avg_us"], "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0,
+                    "unit": "GB/s", "frac": kd["frac_of_8TBps"], "algorithmic_bytes": kd["algorithmic_bytes"],
+                    "traffic": kd["traffic"], "pmc": pmc_note}
         if dom.startswith("blend"):
-            # the compositing kernels have no dense contraction and gather 48-byte records out of L2: they are bound by VALU
-            # issue, not by HBM.  achieved = vector lane-operations per second (SQ_INSTS_VALU x 64 lanes from the committed
-            # rocprofv3 --pmc pass of this workload / the HIP-event duration measured here); peak = 256 CU x 4 SIMD-32 x 2.4 GHz
             vi = kd.get("valu_wave_insts")
             ach = vi * 64.0 / (kd["avg_us"] * 1e-6) / 1e12 if vi else None
-            pairs = sq.get(dom, {}).get("active_pairs")
-            roofline.update({"bound": "valu", "achieved": round(ach, 2) if ach else None, "peak": round(VALU_PEAK_TLANEOPS, 1),
-                             "unit": "Tlane-op/s", "frac": round(ach / VALU_PEAK_TLANEOPS, 4) if ach else None,
-                             "traffic": kd["traffic"], "interactions_sum_n_contrib": interactions,
-                             "active_lane_frac": sq.get(dom, {}).get("active_lane_frac"), "active_pairs": pairs,
-                             "hbm": {"achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s", "frac": kd["frac_of_8TBps"],
-                                     "algorithmic_bytes": kd["algorithmic_bytes"], "traffic": kd["traffic"]},
-                             "note": "VALU wave-instruction counts come from profiles/pmc_traffic.json (separate --pmc pass, same "
-                                     "workload); HBM-bound kernels are listed under `kernels` with their own fractions"})
-        else:
-            roofline.update({"bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                             "frac": kd["frac_of_8TBps"], "traffic": kd["traffic"]})
+            roofline["valu"] = {"achieved": round(ach, 2) if ach else None, "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s",
+                                "frac": round(ach / VALU_PEAK_TLANEOPS, 4) if ach else None,
+                                "interactions_sum_n_contrib": interactions,
+                                "active_lane_frac": sq.get(dom, {}).get("active_lane_frac"),
+                                "active_pairs": sq.get(dom, {}).get("active_pairs"),
+                                "note": "vector lane-operations/s = SQ_INSTS_VALU x 64 / the HIP-event duration measured here; "
+                                        "peak = 256 CU x 4 SIMD-32 x 2.4 GHz"}
         std = workload in ("c2_hotdog_like", "c4_ficus_like") and size == 800
         out = {
             "metric": BASELINE_METRIC if std else f"train iters/s (fwd+bwd raster) @{size}×{size}, {round(P / 1000)}k Gaussians; HBM GB/s vs roofline",

@@ -365,7 +365,9 @@ __device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1
 // in lockstep (two block barriers per queue).  1: one block per (unit, quadrant) -- a wave on its own 64-entry queue: no
 // block barrier, no waiting for a slower quadrant, a quadrant that is done frees its slot, and the scheduler places
 // work at a quarter of the granularity; the price is that each quadrant gathers the unit's records itself (from L2).
-template <bool INVD, int NE, int WPB>
+// FAULT: 0 in production; 2 = the negative control "drop the colour composited behind a segment restart" (gmsplat.h,
+// gms_set_fault): a separate instantiation, so the production kernel carries no fault branch.
+template <bool INVD, int NE, int WPB, int FAULT = 0>
 __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     constexpr int QN = WPB == 4 ? QUEUE : WAVE;
@@ -421,7 +423,7 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
                 }
                 if (__all(stop)) break;
             }
-            const float inv = 1.f / te;
+            const float inv = FAULT == 2 ? 0.f : 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
         }
     }
@@ -595,7 +597,9 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     const bool invd = a.has_invd && a.dL_dinvd;
     static int wpb = -1;
     if (wpb < 0) { const char *e = getenv("GMS_BWD_WPB"); wpb = (e && atoi(e) == 4) ? 4 : 1; }
-    if (wpb == 4) {
+    if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (blend_bwd_kernel<false, 4, 1, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+    } else if (wpb == 4) {
         auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4, 4> : blend_bwd_kernel<false, 4, 4>)
                               : (invd ? blend_bwd_kernel<true, 2, 4> : blend_bwd_kernel<false, 2, 4>);
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));

@@ -334,6 +334,9 @@ __device__ __forceinline__ float dot3p(float a, float b, float c, float d, float
     return t + g;
 }
 
+// fault injection for the parity criterion's negative controls (gmsplat.h, gms_set_fault); 0 in production
+int fault_mode();
+
 // thread-local error text for gms_last_error()
 void set_error(const char *fmt, ...);
 

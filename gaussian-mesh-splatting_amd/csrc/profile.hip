@@ -49,6 +49,14 @@ TraceRange::~TraceRange() { if (on) g_pop(); }
 
 bool g_profile_on = false;
 
+// ---- fault injection (negative controls of the parity criterion; gmsplat.h)
+static int g_fault = -1;        // -1: not yet read from the environment
+int fault_mode()
+{
+    if (g_fault < 0) { const char *e = getenv("GMS_FAULT"); g_fault = e ? atoi(e) : 0; if (g_fault < 0) g_fault = 0; }
+    return g_fault;
+}
+
 namespace {
 struct Pair { int kid; hipEvent_t e0, e1; };
 std::mutex g_mu;
@@ -129,3 +137,6 @@ extern "C" const char *gms_profile_kernel_name(int32_t kid)
 {
     return (kid >= 0 && kid < GMS_K_COUNT) ? k_names[kid] : "";
 }
+
+extern "C" void gms_set_fault(int32_t fault) { gms::g_fault = fault > 0 ? fault : 0; }
+extern "C" int32_t gms_get_fault(void) { return gms::fault_mode(); }

@@ -385,6 +385,15 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
 }
 
 
+// ------------------------------------------------------------------------------------ fault injection
+// Negative controls of the parity criterion (gmsplat.h, gms_set_fault): scale one field of every `every`-th row.  A
+// separate launch between / after the production kernels, which therefore carry no fault branch.
+__global__ void fault_scale_kernel(float *base, int rows, int stride, int field, int every, float factor)
+{
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * every;
+    if (i < rows) base[(size_t)i * stride + field] *= factor;
+}
+
 // ------------------------------------------------------------------------------------ factorised SH gradient
 // dL/dsh[k][c] of one view is the outer product Y_k(dir) * dL/dcolour_c (clamp mask folded into dL/dcolour), and dir depends
 // only on the Gaussian's position and that view's camera centre.  A multi-view step therefore exchanges the [P,3] factors of
@@ -507,17 +516,21 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         if (A->num_units > 0 && (uint64_t)A->num_units < mu) mu = (uint32_t)A->num_units;      // exact count from the forward
         int32_t rc = launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
+        if (fault_mode() == 1)      // negative control: sum(q dx^2) of every 1000th Gaussian off by 2e-3
+            fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->grad_accum, P, GRAD_STRIDE, GRAD_CA, 1000, 1.002f);
     }
     PreBwdArgs p;
     p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;
     p.means3D = A->means3D; p.shs = A->shs; p.shs_rest = A->shs_rest; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
-    p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
+    p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = fault_mode() == 3 ? 0 : A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
     p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = A->shs ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
+    if (fault_mode() == 4 && A->dL_dscales)      // negative control: dL/dscale.x of every 1000th Gaussian off by 2e-3
+        fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->dL_dscales, P, 3, 0, 1000, 1.002f);
     return GMS_OK;
 }
 

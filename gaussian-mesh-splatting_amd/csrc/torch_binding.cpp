@@ -75,7 +75,11 @@ std::map<std::tuple<int, int, int, int64_t>, int64_t> g_capacity;
 // (device, stream, P) -> zeroed [P,16] gradient-record buffer (the backward kernels leave it zero again)
 std::map<std::tuple<int, void *, int64_t>, Tensor> g_accum;
 
+// Counters of the most recent forward.  The scratch tensors themselves are referenced only while `keep_buffers` is on
+// (diagnostics: last_stats()["interactions"], raw_buffers()): a permanent reference would keep the previous frame's scratch
+// alive while the next forward allocates its own, i.e. double the scratch working set of the caching allocator.
 struct LastCall { int64_t num_rendered = 0, num_units = 0, hint = 0, P = 0; int W = 0, H = 0; Tensor radii, image, binning, geom; } g_last;
+std::atomic<bool> g_keep_buffers{false};
 
 struct Forward {
     int64_t num_rendered = 0, num_units = 0, capacity = 0;
@@ -140,7 +144,7 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
         int64_t &c = g_capacity[key];
         c = std::max(n, (int64_t)(0.97 * (double)c));
         g_last.num_rendered = n; g_last.num_units = num_units; g_last.hint = hint; g_last.P = P; g_last.W = (int)W; g_last.H = (int)H;
-        g_last.radii = f.radii; g_last.image = f.image; g_last.binning = f.binning; g_last.geom = f.geom;
+        if (g_keep_buffers.load()) { g_last.radii = f.radii; g_last.image = f.image; g_last.binning = f.binning; g_last.geom = f.geom; }
     }
     return f;
 }
@@ -385,13 +389,21 @@ void sh_grad_expand(const Tensor &factors, const Tensor &means3D, int64_t D, Ten
     if (P > 0 && V > 0) check_rc(gms_sh_grad_expand(&a, stream_of(means3D)), "gms_sh_grad_expand");
 }
 
+void set_keep_buffers(bool on)
+{
+    g_keep_buffers = on;
+    if (!on) { std::lock_guard<std::mutex> lk(g_mu); g_last.radii = Tensor(); g_last.image = Tensor(); g_last.binning = Tensor(); g_last.geom = Tensor(); }
+}
+// drop the cached (all-zero between calls) gradient-record buffers, e.g. after a fault-injection test dirtied one
+void clear_accum() { std::lock_guard<std::mutex> lk(g_mu); g_accum.clear(); }
+
 py::dict last_stats()
 {
     std::lock_guard<std::mutex> lk(g_mu);
     py::dict d;
     d["num_rendered"] = g_last.num_rendered; d["num_units"] = g_last.num_units; d["capacity_hint"] = g_last.hint;
     d["P"] = g_last.P; d["width"] = g_last.W; d["height"] = g_last.H; d["deepest_tile"] = gms_last_deepest_tile();
-    d["radii"] = g_last.radii; d["image"] = g_last.image; d["binning"] = g_last.binning; d["geom"] = g_last.geom;
+    if (g_last.radii.defined()) { d["radii"] = g_last.radii; d["image"] = g_last.image; d["binning"] = g_last.binning; d["geom"] = g_last.geom; }
     return d;
 }
 
@@ -573,17 +585,24 @@ void adam_step(const std::vector<Tensor> &params, const std::vector<Tensor> &gra
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "MI355X-native diff_gaussian_rasterization._C (PyTorch-ROCm binding of libgmsplat.so)";
-    m.def("rasterize_gaussians", &rasterize_gaussians);
-    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
-    m.def("mark_visible", &mark_visible);
-    m.def("rasterize", &rasterize, "differentiable rasterization (autograd node in C++)");
-    m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization");
-    m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]");
-    m.def("adam_step", &adam_step);
+    // The GIL is released for the whole of every call that reaches the kernels ("Threading / streams"): the
+    // forward polls the pinned read-back slot for the instance count (~one step of GPU time) and must not hold other Python
+    // threads (data loaders, a second stream's renderer) meanwhile.  Nothing below touches a Python object: tensors are
+    // at::Tensor handles, allocation goes through the ATen caching allocator, the autograd graph is C++.
+    using nogil = py::call_guard<py::gil_scoped_release>;
+    m.def("rasterize_gaussians", &rasterize_gaussians, nogil());
+    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward, nogil());
+    m.def("mark_visible", &mark_visible, nogil());
+    m.def("rasterize", &rasterize, "differentiable rasterization (autograd node in C++)", nogil());
+    m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization", nogil());
+    m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]", nogil());
+    m.def("adam_step", &adam_step, nogil());
+    m.def("set_keep_buffers", &set_keep_buffers, "keep references to the last forward's scratch tensors (diagnostics only)");
+    m.def("clear_accum", &clear_accum);
     m.def("set_sh_factor_mode", &set_sh_factor_mode, "factorised SH gradient: backward calls queue [P+1,3] factors instead of writing dL/dsh");
     m.def("sh_factor_mode", &sh_factor_mode);
     m.def("take_sh_factors", &take_sh_factors);
-    m.def("sh_grad_expand", &sh_grad_expand, "dsh (+)= sum_v Y(dir_v) (x) factor_v over the [V,P+1,3] factors");
+    m.def("sh_grad_expand", &sh_grad_expand, "dsh (+)= sum_v Y(dir_v) (x) factor_v over the [V,P+1,3] factors", nogil());
     m.def("last_stats", &last_stats);
     m.def("set_capacity", &set_capacity);
     m.def("clear_capacity", &clear_capacity);

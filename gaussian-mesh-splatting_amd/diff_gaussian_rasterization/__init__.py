@@ -45,7 +45,7 @@ except ImportError as _e:          # not built (make -C csrc) or disabled: the c
         raise
     _C = None
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats", "SplitSH",
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "last_stats", "SplitSH", "keep_buffers",
            "set_capacity_hint", "clear_capacity_hints"]
 
 
@@ -144,15 +144,33 @@ def sh_grad_expand(factors: torch.Tensor, means3D: torch.Tensor, sh_degree: int,
     _C.sh_grad_expand(factors, means3D, int(sh_degree), dL_dsh, dL_dsh_rest if dL_dsh_rest is not None else torch.Tensor(), bool(accumulate))
 
 
+_keep_buffers = False
+
+
+def keep_buffers(on: bool = True) -> None:
+    """Diagnostics: while on, the most recent forward's scratch tensors (and radii) stay referenced, so that `last_stats()`
+    can report `visible` / `interactions` and `raw_buffers()` returns them.  Off by default: holding them would keep the
+    previous frame's scratch alive while the next forward allocates its own (double the scratch working set)."""
+    global _keep_buffers
+    _keep_buffers = bool(on)
+    if _C is not None:
+        _C.set_keep_buffers(bool(on))
+    if not on:
+        for k in ("radii", "image", "binning", "geom"):
+            _last_stats.pop(k, None)
+
+
 def raw_buffers() -> dict:
-    """The scratch tensors of the most recent forward (geom / binning / image byte buffers): diagnostics only."""
+    """The scratch tensors of the most recent forward (geom / binning / image byte buffers): diagnostics only; needs
+    `keep_buffers(True)` before that forward."""
     d = _C.last_stats() if _C is not None else _last_stats
     return {k: d.get(k) for k in ("geom", "binning", "image")}
 
 
 def last_stats() -> dict:
     """Counters of the most recent forward call: num_rendered (N), capacity hint used, deepest_tile (instances in the
-    deepest tile) and `visible` (Gaussians with radius > 0; computed on request: one device sync)."""
+    deepest tile); after `keep_buffers(True)` also `visible` (Gaussians with radius > 0) and `interactions` (computed
+    on request: one device sync)."""
     d = dict(_C.last_stats()) if _C is not None else dict(_last_stats)
     radii = d.pop("radii", None)
     if radii is not None:
@@ -330,9 +348,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(num_rendered, "gms_rasterize_forward")
         _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
         _last_stats.update(num_rendered=int(num_rendered), num_units=int(num_units.value), capacity_hint=hint, P=P, width=W, height=H,
-                           deepest_tile=int(lib.gms_last_deepest_tile()), radii=radii,
-                           image=scratch.tensors.get("image"), binning=scratch.tensors.get("binning"),
-                           geom=scratch.tensors.get("geom"))
+                           deepest_tile=int(lib.gms_last_deepest_tile()))
+        if _keep_buffers:
+            _last_stats.update(radii=radii, image=scratch.tensors.get("image"), binning=scratch.tensors.get("binning"),
+                               geom=scratch.tensors.get("geom"))
 
         ctx.raster_settings = rs
         ctx.num_rendered = int(num_rendered)

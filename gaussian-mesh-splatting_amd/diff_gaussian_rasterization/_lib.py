@@ -160,6 +160,9 @@ def load():
         lib.gms_profile_read.restype = C.c_int32
         lib.gms_profile_kernel_name.argtypes = [C.c_int32]
         lib.gms_profile_kernel_name.restype = C.c_char_p
+        lib.gms_set_fault.argtypes = [C.c_int32]
+        lib.gms_set_fault.restype = None
+        lib.gms_get_fault.restype = C.c_int32
         if lib.gms_abi_version() != GMS_ABI_VERSION:
             raise RuntimeError(f"libgmsplat.so ABI {lib.gms_abi_version()} != binding ABI {GMS_ABI_VERSION}; rebuild")
         _lib = lib

@@ -317,6 +317,20 @@ size_t gms_image_bytes(int32_t width, int32_t height);
 size_t gms_image_n_contrib_offset(int32_t width, int32_t height);
 size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
+/* ---- fault injection (test infrastructure of the PARITY CRITERION, not of the kernels) -------------------------------
+ * tests/test_gpu_negative_controls.py must show that the gradient criterion of tests/_util.py can FAIL: a deliberately
+ * wrong backward has to trip it.  `fault` selects one defect for the calling process until reset to 0 (the default; also
+ * settable through the environment variable GMS_FAULT read at the first backward).  The faulty code lives in separate
+ * template instantiations of the kernels: the production instantiations contain no fault branch.
+ *   1  blend_bwd: the second moment sum(q dx^2) of every 1000th Gaussian (id % 1000 == 0) is scaled by 1 + 2e-3
+ *   2  blend_bwd: a unit that restarts the back-to-front recurrence at a segment boundary drops the colour composited
+ *      behind it (the suffix of the later segments)
+ *   3  the gradient records are NOT cleared after preprocess_bwd consumed them: the next backward of this (device,
+ *      stream, P) adds the previous frame's moments to its own
+ *   4  preprocess_bwd: dL/dscale of every 1000th Gaussian is scaled by 1 + 2e-3 */
+void gms_set_fault(int32_t fault);
+int32_t gms_get_fault(void);
+
 #ifdef __cplusplus
 }
 #endif

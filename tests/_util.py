@@ -91,10 +91,16 @@ GRAD_REL = 1e-3          # north_star: 1e-3 relative on gradients
 # double: per-term rounding only) and the float32-accumulator one (libgs_oracle_f32acc: the sums themselves in float32, as
 # any float-atomics implementation -- the reference's CUDA kernels, these HIP kernels -- has them).  The affected rows are
 # thin, long splats whose cov2D gradient is a difference of terms ~5000x its size.
-# Float atomics make the HIP sums order-dependent: on ~1e6 such rows x several frames the worst ratio observed varies run
-# to run (4 ... 360), so K = 64 and at most 2 entries per million may stay unexplained (reported in parity_report.jsonl).
-ADJUDICATE_K = 64.0
-UNEXPLAINED_PER_MILLION = 2.0
+# Round 3: every constant below was tightened to <= 2x the maximum observed over the round-2 report (27 comparisons incl.
+# three config-5-size frames, profiles/r02_parity_report.jsonl) and the 3 600-case fuzz sweep; DESIGN.md section 2 holds
+# the table (constant, the failure that introduced it, observed maximum).  tests/test_gpu_negative_controls.py shows the
+# criterion FAILS for four injected defects (gmsplat.h, gms_set_fault).
+ADJUDICATE_K = 16.0               # observed worst ratio 8.0 (scales, config-5 size)
+UNEXPLAINED_PER_MILLION = 1.0     # observed 0
+RARE_FRAC = 5e-4                  # explained outliers per tensor: observed <= 5.2e-5 (scales); small tensors: <= RARE_MIN entries
+RARE_MIN = 8
+ROW_FRAC = 5e-3                   # rows taking the excused / alternate-outcome rules: observed <= 1.3e-5 of the entries
+Q_MIN_SIZE = 500                  # the 0.999 quantile is asserted for every tensor with at least this many entries
 
 
 def excused_rows(details):
@@ -182,7 +188,15 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
             with np.errstate(divide="ignore", invalid="ignore"):
                 ratio = np.where(e_o32 > 0, (e_hip - slack) / e_o32, np.where(e_hip > slack, np.inf, 0.0))
             worst = float(np.max(ratio)) if ratio.size else 0.0
-        rep[k] = dict(scale=scale, max_abs=float(err.max()), q_rel=float(np.quantile(rel, q)), max_rel=float(rel.max()),
+        # (the quantile is also taken over the entries that did NOT need an excuse: on a tensor of a few hundred entries
+        # one excused fringe-pixel row would otherwise BE the 0.999 quantile)
+        clean_mask = np.ones(rel.shape, bool)
+        if n_exc:
+            clean_mask &= ~(row_exc & (rel > GRAD_REL))
+        if n_alt:
+            clean_mask &= ~(row_alt & agrees & (rel > GRAD_REL))
+        q_clean = float(np.quantile(rel[clean_mask], q)) if clean_mask.any() else 0.0
+        rep[k] = dict(scale=scale, max_abs=float(err.max()), q_rel=float(np.quantile(rel, q)), q_rel_clean=q_clean, max_rel=float(rel.max()),
                       frac_bad=float(bad.mean()), outliers=n_out, unexplained=unexplained, zero_violation=False,
                       worst_ratio=worst, excused=n_exc, alt_explained=n_alt, size=int(b.size))
     return rep
@@ -190,8 +204,9 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
 
 def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_fn=None, alt=None):
     """The gradient criterion of every parity test: quantile <= 1e-3 AND no unexplained outlier AND no non-zero gradient
-    where the oracle's is identically zero.  `go64_fn()` (lazy: only evaluated if some entry is an outlier) returns the
-    float64 oracle's gradients."""
+    where the oracle's is identically zero AND explained / excused entries rare.  `go64_fn()` (lazy: only evaluated if
+    some entry is an outlier) returns the float64 oracle's gradients.  Constants: top of this file; their history and
+    observed maxima: DESIGN.md section 2; proof that the criterion can fail: tests/test_gpu_negative_controls.py."""
     rep = grad_report(gh, go, q=q, excuse=excuse)
     if go64_fn is not None and any(v["outliers"] for v in rep.values()):
         alt_rows, alts = (alt[0], alt[1]()) if alt is not None and alt[0].any() else (None, None)
@@ -203,8 +218,12 @@ def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_f
         # sweep's worst populations, faint large splats, reach 0.5 % of the rotation gradients at error ratios 1-3 against the
         # float32 oracle); on tensors of a few hundred
         # entries the 0.999 quantile IS the maximum, so the rarity rule is a count there
-        assert v["outliers"] <= max(8, int(1e-2 * v["size"])), (where, k, v)
-        assert v["q_rel"] <= GRAD_REL or v["size"] < 8000, (where, k, v)
+        assert v["outliers"] <= max(RARE_MIN, int(RARE_FRAC * v["size"])), (where, k, v)
+        # entries that needed the excused-row or the alternate-outcome rule are counted and capped too
+        assert v.get("excused", 0) + v.get("alt_explained", 0) <= max(RARE_MIN, int(ROW_FRAC * v["size"])), (where, k, v)
+        # small tensors: the quantile over the non-excused entries (for < 1000 entries it is their maximum)
+        assert v["q_rel"] <= GRAD_REL or v["size"] < Q_MIN_SIZE or \
+            (v["size"] < 8000 and v.get("q_rel_clean", v["q_rel"]) <= GRAD_REL), (where, k, v)
         assert v["unexplained"] <= int(UNEXPLAINED_PER_MILLION * 1e-6 * v["size"]), (where, k, v)
     _log_parity(where, rep)
     return rep
@@ -220,7 +239,7 @@ def _log_parity(where, rep):
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "parity_report.jsonl"), "a") as f:
             f.write(json.dumps({"where": where, "tensors": {k: {m: v[m] for m in ("scale", "q_rel", "max_rel", "outliers",
-                                                                                 "unexplained", "worst_ratio", "excused", "alt_explained", "size") if m in v}
+                                                                                 "unexplained", "worst_ratio", "excused", "alt_explained", "size", "q_rel_clean") if m in v}
                                                              for k, v in rep.items()}}) + "\n")
     except OSError:
         pass

@@ -1,0 +1,111 @@
+"""Negative controls of the gradient-parity criterion (tests/_util.py::assert_grads).
+
+A criterion that was iterated until the suite went green must be shown to go RED when a kernel is wrong.  libgmsplat.so
+carries four injectable defects (include/gmsplat.h, gms_set_fault; separate launches / template instantiations, the
+production kernels hold no fault branch).  Each test renders a scene the fault-free build passes -- asserted first, same
+inputs -- then switches one defect on and asserts that `assert_grads` raises."""
+import numpy as np
+import pytest
+import torch
+
+import _util as U
+from games_hip import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def fault():
+    from diff_gaussian_rasterization import _lib
+    lib = _lib.load()
+    assert lib.gms_get_fault() == 0, "a production run must start with no fault selected"
+
+    def set_fault(k):
+        lib.gms_set_fault(int(k))
+    yield set_fault
+    lib.gms_set_fault(0)
+    try:        # a dirtied gradient-record buffer (fault 3) must not survive into other tests
+        from diff_gaussian_rasterization import _C
+        _C.clear_accum()
+    except ImportError:
+        import diff_gaussian_rasterization as dgr
+        dgr._accum_cache.clear()
+
+
+def _case(P, seed, W, H, **scene_kw):
+    sc = syn.random_scene(P, seed=seed, **scene_kw)
+    cam = syn.orbit_camera(seed % 8, width=W, height=H, radius=3.0)
+    inputs = dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    kw = U.settings_kwargs(cam, torch.tensor([0.2, 0.4, 0.6]))
+    o = U.oracle_render(inputs, kw)
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
+    o = U.oracle_render(inputs, kw, gc)
+    return inputs, kw, gc, o
+
+
+def _assert(inputs, kw, gc, o, h, where):
+    return U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, precision="f64")["grads"], where=where,
+                          excuse=U.excused_rows(o["details"]),
+                          go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, precision="f32acc")["grads"],
+                          alt=U.alt_oracles(inputs, kw, gc, None, o["details"]))
+
+
+@pytest.mark.parametrize("k,what", [(1, "second moment of every 1000th Gaussian off by 2e-3"),
+                                    (4, "dL/dscale.x of every 1000th Gaussian off by 2e-3")])
+def test_a_2e3_error_on_one_splat_in_a_thousand_fails_the_criterion(fault, k, what):
+    """North star: 1e-3 relative on gradients.  2e-3 on 0.1 % of the Gaussians is the smallest defect worth the name."""
+    inputs, kw, gc, o = _case(20000, 21, 320, 256, scale_lo=0.01, scale_hi=0.06)
+    h = U.hip_render(inputs, kw, grad_color=gc)
+    _assert(inputs, kw, gc, o, h, where=f"negative control {k}: fault-free")          # the same inputs pass without the fault
+    fault(k)
+    h_bad = U.hip_render(inputs, kw, grad_color=gc)
+    fault(0)
+    # the defect really is that small: only every 1000th row differs, by ~2e-3 relative
+    # (two fault-free runs differ by the order of the float atomics: ~1e-6 relative)
+    ga, gb = h["grads"]["scales"], h_bad["grads"]["scales"]
+    d = np.abs(gb - ga) / (np.abs(ga) + 1e-3 * np.abs(ga).max())
+    rows = np.nonzero(d.max(axis=1) > 5e-4)[0]
+    assert 0 < len(rows) <= 20 and (rows % 1000 == 0).all() and (k != 4 or d.max() < 2.5e-3), (what, rows[:10], d.max())
+    with pytest.raises(AssertionError):
+        _assert(inputs, kw, gc, o, h_bad, where=f"negative control {k}: {what}")
+
+
+def test_dropping_the_colour_behind_a_segment_restart_fails_the_criterion(fault):
+    """Deep tiles: the back-to-front recurrence is restarted at segment boundaries from the suffix colour; losing it
+    changes dL/dalpha of every splat in front of a boundary."""
+    g = torch.Generator().manual_seed(3)
+    P = 6000
+    means = torch.randn(P, 3, generator=g) * 0.05          # a few tiles, > 128 entries each: several segments per tile
+    sc = syn.random_scene(P, seed=12, scale_lo=0.004, scale_hi=0.02, opacity_lo=0.02, opacity_hi=0.2)
+    cam = syn.look_at_camera((0.0, -3.0, 0.0), width=96, height=96, fovx=0.5)
+    inputs = dict(means3D=means, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    kw = U.settings_kwargs(cam, torch.zeros(3))
+    o = U.oracle_render(inputs, kw)
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
+    o = U.oracle_render(inputs, kw, gc)
+    rng = o["details"]["ranges"]
+    assert (rng[:, 1] - rng[:, 0]).max() > 512           # multi-segment tiles exist
+    h = U.hip_render(inputs, kw, grad_color=gc)
+    _assert(inputs, kw, gc, o, h, where="negative control 2: fault-free")
+    fault(2)
+    h_bad = U.hip_render(inputs, kw, grad_color=gc)
+    fault(0)
+    assert np.abs(h_bad["color"] - h["color"]).max() == 0.0          # the forward is untouched
+    with pytest.raises(AssertionError):
+        _assert(inputs, kw, gc, o, h_bad, where="negative control 2: suffix colour dropped at segment restarts")
+
+
+def test_a_skipped_re_zero_of_the_gradient_records_fails_the_criterion(fault):
+    """The [P,16] gradient records are cleared by preprocess_bwd after use; if one clear is skipped, the NEXT backward of the
+    same (device, stream, P) adds the stale moments to its own."""
+    inputs, kw, gc, o = _case(1777, 33, 160, 128, scale_lo=0.01, scale_hi=0.1)       # P = 1777: a buffer no other test shares
+    h = U.hip_render(inputs, kw, grad_color=gc)
+    _assert(inputs, kw, gc, o, h, where="negative control 3: fault-free")
+    fault(3)
+    U.hip_render(inputs, kw, grad_color=gc)          # this backward is still correct, but leaves its records behind
+    fault(0)
+    h_bad = U.hip_render(inputs, kw, grad_color=gc)  # fault-free kernels on a dirty buffer
+    with pytest.raises(AssertionError):
+        _assert(inputs, kw, gc, o, h_bad, where="negative control 3: stale gradient records")
+    h_ok = U.hip_render(inputs, kw, grad_color=gc)   # ... which that backward re-zeroed: the following frame is clean again
+    _assert(inputs, kw, gc, o, h_ok, where="negative control 3: recovered")

@@ -11,6 +11,7 @@ from games_hip.model import HipGaussianMeshModel
 from games_hip.render import PipelineParams, render
 from oracle import gs_oracle, mesh_oracle
 import diff_gaussian_rasterization as dgr
+dgr.keep_buffers(True)        # this tool reads the scratch buffers of the last forward
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "c5_flame_like_1m"
 scene = syn.mesh_scene(wl, state="trained")
