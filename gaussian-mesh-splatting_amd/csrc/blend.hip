@@ -56,11 +56,13 @@ __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u) { ret
 // pair the per-pixel test skips, never the reverse):
 //   (1) bounding box of the {alpha >= 1/255} ellipse against the quadrant (rejects most far entries with 4 compares);
 //   (2) EXACT ellipse-vs-rectangle: the minimum over the rectangle of Q(d) = A dx^2 + 2 B dx dy + C dy^2 (convex: the
-//       centre if inside, else the best of the four edges' clamped 1-D minima) against 2 (ln(255 op) + 1e-3), which is
-//       ex^2 (A C - B^2) / C because ex^2 = 2 Sigma_xx (ln(255 op) + 1e-3) and Sigma_xx = C / det(conic).  Mesh-bound
-//       splats are flat and often diagonal on screen, where the box of the ellipse is loose.  The slack (1e-4 relative +
-//       0.01 absolute in Q, i.e. 0.005 in the exponent) covers the float error of both evaluations.
-__device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float4 q2, const Pix &p, bool bbox_only = false)
+//       centre if inside, else the best of the four edges' clamped 1-D minima) against 2 (ln(255 op) + 1e-3), recomputed
+//       from the record's opacity with the SAME intrinsic the preprocess kernel used for the extents (deriving it from
+//       ex^2 det(conic) / C loses it to the cancellation in A C - B^2 for long thin splats).  Mesh-bound splats are flat and
+//       often diagonal on screen, where the box of the ellipse is loose.  The slack covers the float error of the edge
+//       minima: 0.01 absolute + 1e-4 relative in Q, plus 4e-6 of the GROSS terms |A| mx^2 + 2 |B| mx my + |C| my^2 at the
+//       far corner (the three terms cancel for a thin splat whose centre is hundreds of pixels away).
+__device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float op, const float4 q2, const Pix &p, bool bbox_only = false)
 {
     if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) return false;
     if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
@@ -68,7 +70,7 @@ __device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const f
     const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
     if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
     const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
-    const float thr = q2.z * q2.z * (A * C - B * B) * iC;
+    const float thr = 2.f * (__logf(255.f * op) + 1e-3f);
     const float B2 = 2.f * B;
     float qmin;
     {
@@ -78,12 +80,14 @@ __device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const f
         const float e2 = xa * (A * xa + B2 * dy0) + C * dy0 * dy0, e3 = xb * (A * xb + B2 * dy1) + C * dy1 * dy1;
         qmin = fminf(fminf(e0, e1), fminf(e2, e3));
     }
-    return qmin <= thr * 1.0001f + 0.01f;
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float gross = mx * (A * mx + fabsf(B2) * my) + C * my * my;
+    return qmin <= thr * 1.0001f + 0.01f + 4e-6f * gross;
 }
 __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p, bool bbox_only = false)
 {
     if (j >= cnt) return false;
-    return rect_hit(recs[j].q0, recs[j].q1.x, recs[j].q2, p, bbox_only);
+    return rect_hit(recs[j].q0, recs[j].q1.x, recs[j].q1.y, recs[j].q2, p, bbox_only);
 }
 
 // ------------------------------------------------------------------------------------ tloc

@@ -96,7 +96,7 @@ EXPORTS = (
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
-    "gms_sh_grad_expand",
+    "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault",
 )
 K_COUNT = 16
 

@@ -5,7 +5,12 @@ unless `out_dir` is given.
 
     frames = render_time_animated(model, views, pipe, bg, transform=transform_hotdog_fly)
 
-The vertex transforms are the reference's (scripts/render_time_animated.py:28-66), restated without in-place writes.
+The vertex transforms are the reference's (scripts/render_time_animated.py:28-66) with the reference's semantics:
+`transform_hotdog_fly` and `make_smaller` return a deformed COPY of the rest pose; `transform_ficus_sinus`,
+`transform_ficus_pot` and `transform_ship_sinus` write IN PLACE into the tensor they are given, so -- as in the reference,
+which hands them `gaussians.vertices` itself -- their deformation ACCUMULATES from frame to frame.  The one deviation: the
+driver below hands them a working copy made once per call, so the model's own `vertices` parameter is left untouched
+(the reference's loop leaves the model deformed after rendering).
 """
 from __future__ import annotations
 
@@ -18,23 +23,36 @@ import torch
 from .render import render, render_animated
 
 
-def transform_hotdog_fly(vertices, t, idxs=None):          # scripts/render_time_animated.py:35-41
+def _sel(idxs):
+    return slice(None) if idxs is None else idxs
+
+
+def transform_hotdog_fly(vertices, t, idxs=None):          # scripts/render_time_animated.py:35-41 (copy of the rest pose)
     v = vertices.clone()
-    v[:, 2] = v[:, 2] + t * (vertices[:, 1] ** 2 + vertices[:, 1] ** 2) ** 0.5 * 0.01
+    v[:, 2] += float(t) * (vertices[:, 1] ** 2 + vertices[:, 1] ** 2) ** 0.5 * 0.01
     return v
 
 
-def transform_ship_sinus(vertices, t, idxs=None):          # :52-55
-    v = vertices.clone()
+def transform_ship_sinus(vertices, t, idxs=None):          # :52-55 (in place: accumulates over the frames)
     f = math.sin(float(t)) * 0.5
-    v[:, 2] = v[:, 2] + 0.05 * torch.sin(vertices[:, 0] * math.pi + f)
-    return v
+    vertices[:, 2] += 0.05 * torch.sin(vertices[:, 0] * math.pi + f)
+    return vertices
 
 
-def transform_ficus_sinus(vertices, t, idxs):              # :28-32
-    v = vertices.clone()
-    v[idxs, 2] = v[idxs, 2] + 0.005 * torch.sin(vertices[idxs, 1] * 5 * math.pi + float(t))
-    return v
+def transform_ficus_sinus(vertices, t, idxs=None):         # :28-32 (two sinus terms, in place: accumulates)
+    i = _sel(idxs)
+    vertices[i, 2] += 0.005 * torch.sin(vertices[i, 0] * 2 * math.pi + float(t))
+    vertices[i, 2] += 0.005 * torch.sin(vertices[i, 1] * 5 * math.pi + float(t))
+    return vertices
+
+
+def transform_ficus_pot(vertices, t, idxs=None):           # :44-49 (in place: accumulates)
+    i = _sel(idxs)
+    if float(t) > 8 * math.pi:
+        vertices[i, 2] += 0.005 * torch.sin(vertices[i, 1] * 5 * math.pi + float(t))
+    else:
+        vertices[i, 2] -= (0.005 + float(t)) * (vertices[i, 0] / 10) ** 2
+    return vertices
 
 
 def make_smaller(vertices, t, idxs=None):                  # :58-62
@@ -55,7 +73,7 @@ def render_time_animated(gaussians, views: Iterable, pipeline, background: torch
     """scripts/render_time_animated.py:68-87.  Returns the rendered frames (device tensors [3,H,W])."""
     views = list(views)
     ts = torch.linspace(0, t_max, max(len(views), 1))
-    vertices = gaussians.vertices.detach()
+    vertices = gaussians.vertices.detach().clone()      # working copy: the in-place transforms accumulate in it, as in the reference
     faces = gaussians.faces.long()
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)

@@ -439,10 +439,26 @@ def test_animated_drivers_follow_the_reference_loops(tmp_path):
                                           out_dir=str(tmp_path / "anim"))
     assert len(frames) == 4 and sorted(os.listdir(tmp_path / "anim")) == [f"{k:05d}.png" for k in range(4)]
     ts = torch.linspace(0, 10 * torch.pi, 4)
+    rest = model.vertices.detach().clone()
     with torch.no_grad():
-        v2 = animate.transform_ship_sinus(model.vertices.detach(), ts[2])
+        # the reference's ship / ficus transforms write in place (scripts/render_time_animated.py:52-55): frame k shows the
+        # deformation ACCUMULATED over frames 0..k
+        v2 = rest.clone()
+        for k in range(3):
+            v2 = animate.transform_ship_sinus(v2, ts[k])
         ref = render_animated(None, v2[model.faces].float(), views[2], model, PipelineParams(), bg)["render"]
     assert torch.equal(frames[2], ref) and not torch.equal(frames[2], frames[1])
+    assert torch.equal(model.vertices.detach(), rest)           # the model's own vertices are left alone
+    # the copy-returning transforms restart from the rest pose each frame (:35-41)
+    frames_fly = animate.render_time_animated(model, views, PipelineParams(), bg, transform=animate.transform_hotdog_fly)
+    with torch.no_grad():
+        ref_fly = render_animated(None, animate.transform_hotdog_fly(rest, ts[3])[model.faces].float(), views[3], model, PipelineParams(), bg)["render"]
+    assert torch.equal(frames_fly[3], ref_fly)
+    # both sinus terms of the ficus transform (:28-32)
+    z0 = rest[:, 2].clone()
+    vf = animate.transform_ficus_sinus(rest.clone(), ts[1], None)
+    want = z0 + 0.005 * torch.sin(rest[:, 0] * 2 * torch.pi + ts[1]) + 0.005 * torch.sin(rest[:, 1] * 5 * torch.pi + ts[1])
+    assert float((vf[:, 2] - want).abs().max()) <= 1e-6
     fm = HipGaussianFlameModel.from_scene(syn.mesh_scene("tiny"), "cuda")
 
     def drive(g, k):
