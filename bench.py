@@ -45,6 +45,7 @@ def algorithmic_bytes(P, N, F, W, H):
         # algorithmic bytes of the whole forward walk are booked on the first launch, the other two are implementation passes
         "blend_head": 44 * N + 24 * HW,            # id 4 + gathered record 40 per instance; 24 B per pixel
         "blend_finalize": 0,
+        "micro_filter": 52 * N,                    # micro-tile mode: key 8 + gathered record 40 per instance in, ~one id out
         "l1_ssim_fwd": 20 * 3 * HW,   # --loss l1_ssim only: read image + gt, write three derivative maps
         "l1_ssim_bwd": 24 * 3 * HW,   # read image + gt + three maps, write dL/dimage
         "adam": 28 * (3 * F // 2 + 6 + 52 * P),   # --optimizer fused_adam: 16 B read + 12 B written per parameter element
@@ -292,6 +293,7 @@ def main():
 
     # ---- several ranks: which collective for the large gradient (timed on gradient-sized buffers, outside the timed region)
     sh_factor = distributed and (args.sh_exchange == "factor" or (args.sh_exchange == "auto" and (world > 1 or force_ddp)))
+    sh_factor_default = sh_factor
     algo, allreduce_times = "ring", {}
     if distributed:
         # (factorised SH exchange: the feature tensors take no part in the all-reduce)
@@ -341,7 +343,8 @@ def main():
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
         del big, flat
 
-    def make_step(vps, reduce_grads):
+    def make_step(vps, reduce_grads, sh_factor=None):
+        sh_factor = sh_factor_default if sh_factor is None else sh_factor
         """One step = K0 forward (once: the parameters are the same for all its views) + vps x (render fwd + bwd) on this rank's
         views + [reduce_grads] ONE gradient all-reduce.  Rank r renders cameras (r*vps + v) % 8 (config 4: 8 views)."""
         cams = [all_cams[(rank * vps + v) % 8] for v in range(vps)]
@@ -358,6 +361,8 @@ def main():
             model.update_alpha()
             model.prepare_scaling_rot()
             images = [render(c, model, pipe, bg)["render"] for c in cams]
+            if exchange is not None:
+                exchange.watch(model.get_xyz)     # the gather starts inside backward, right after the last rasterizer backward
             if args.loss == "l1_ssim":
                 loss = l1_ssim_loss(images[0], gt_image, 0.2)
                 for im in images[1:]:
@@ -367,8 +372,6 @@ def main():
                 with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
                     grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each
                 torch.autograd.backward(images, grads)
-            if exchange is not None:
-                exchange.start()      # all-gather of this rank's [P+1,3] factors
             if reducer is not None:
                 reducer.finish()      # collectives were started from autograd hooks during backward
             if exchange is not None:
@@ -423,6 +426,16 @@ def main():
         return
 
     vps = max(1, args.views_per_step)
+    sh_exchange_ms = {}
+    if distributed and args.sh_exchange == "auto":
+        # like the all-reduce algorithm: measured, not assumed -- a short run of the step with each exchange, the same on every rank
+        for mode in (False, True):
+            s_try, r_try = make_step(vps, True, sh_factor=mode)
+            el_try = timed(s_try, 30, 10)
+            sh_exchange_ms["factor" if mode else "dense"] = round(1000 * el_try / 30, 4)
+            if r_try is not None:
+                r_try.remove()
+        sh_factor_default = sh_factor = sh_exchange_ms["factor"] < sh_exchange_ms["dense"]
     step, reducer = make_step(vps, True)
     # untimed pre-warm (~0.3 s of steps before the W warm-up steps): allocator pools, capacity / unit hints and the GPU's
     # clocks reach their steady state; two back-to-back runs on one box otherwise differ by 6 % (first run slower)
@@ -474,8 +487,12 @@ def main():
         extra["allreduce_bytes"] = allreduce_bytes
         extra["sh_exchange"] = ("factor: all-gather of [P+1,3] colour-gradient factors + gms_sh_grad_expand" if sh_factor
                                 else "dense: the SH gradient travels inside the all-reduce")
+        extra["sh_exchange_ms_per_step"] = sh_exchange_ms or None
+        gather_bytes = 4 * 3 * (int(model.get_xyz.shape[0]) + 1) * vps * world if sh_factor else 0
         if sh_factor:
-            extra["sh_factor_gather_bytes"] = 4 * 3 * (int(model.get_xyz.shape[0]) + 1) * vps * world
+            extra["sh_factor_gather_bytes"] = gather_bytes
+        dense_numel = sum(p.numel() for p in params if not (sh_factor and (p is model._features_dc or p is model._features_rest)))
+        extra["exchange_bytes"] = 4 * dense_numel + gather_bytes      # per rank per step: all-reduced gradient + gathered factors
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)

@@ -52,42 +52,10 @@ __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u, int w
 }
 __device__ __forceinline__ Pix pixel_of(const BlendGrid &g, const Unit &u) { return pixel_of(g, u, (int)(threadIdx.x >> 6)); }
 
-// Does any pixel centre of the wave's 8x8 quadrant see this splat with alpha >= 1/255?  Conservative (it may keep a
-// pair the per-pixel test skips, never the reverse):
-//   (1) bounding box of the {alpha >= 1/255} ellipse against the quadrant (rejects most far entries with 4 compares);
-//   (2) EXACT ellipse-vs-rectangle: the minimum over the rectangle of Q(d) = A dx^2 + 2 B dx dy + C dy^2 (convex: the
-//       centre if inside, else the best of the four edges' clamped 1-D minima) against 2 (ln(255 op) + 1e-3), recomputed
-//       from the record's opacity with the SAME intrinsic the preprocess kernel used for the extents (deriving it from
-//       ex^2 det(conic) / C loses it to the cancellation in A C - B^2 for long thin splats).  Mesh-bound splats are flat and
-//       often diagonal on screen, where the box of the ellipse is loose.  The slack covers the float error of the edge
-//       minima: 0.01 absolute + 1e-4 relative in Q, plus 4e-6 of the GROSS terms |A| mx^2 + 2 |B| mx my + |C| my^2 at the
-//       far corner (the three terms cancel for a thin splat whose centre is hundreds of pixels away).
-__device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float op, const float4 q2, const Pix &p, bool bbox_only = false)
-{
-    if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) return false;
-    if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
-    const float A = q0.z, B = q0.w;
-    const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
-    const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
-    const float thr = 2.f * (__logf(255.f * op) + 1e-3f);
-    const float B2 = 2.f * B;
-    float qmin;
-    {
-        const float ya = fminf(fmaxf(-B * dx0 * iC, dy0), dy1), yb = fminf(fmaxf(-B * dx1 * iC, dy0), dy1);
-        const float xa = fminf(fmaxf(-B * dy0 * iA, dx0), dx1), xb = fminf(fmaxf(-B * dy1 * iA, dx0), dx1);
-        const float e0 = dx0 * (A * dx0 + B2 * ya) + C * ya * ya, e1 = dx1 * (A * dx1 + B2 * yb) + C * yb * yb;
-        const float e2 = xa * (A * xa + B2 * dy0) + C * dy0 * dy0, e3 = xb * (A * xb + B2 * dy1) + C * dy1 * dy1;
-        qmin = fminf(fminf(e0, e1), fminf(e2, e3));
-    }
-    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
-    const float gross = mx * (A * mx + fabsf(B2) * my) + C * my * my;
-    return qmin <= thr * 1.0001f + 0.01f + 4e-6f * gross;
-}
 __device__ __forceinline__ bool quadrant_hit(const SplatRec *recs, int j, int cnt, const Pix &p, bool bbox_only = false)
 {
     if (j >= cnt) return false;
-    return rect_hit(recs[j].q0, recs[j].q1.x, recs[j].q1.y, recs[j].q2, p, bbox_only);
+    return rect_hit(recs[j].q0, recs[j].q1.x, recs[j].q1.y, recs[j].q2, RectF{p.wx0, p.wy0, p.wx1, p.wy1}, bbox_only);
 }
 
 // ------------------------------------------------------------------------------------ tloc
@@ -329,42 +297,6 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
 }
 
 // ------------------------------------------------------------------------------------ bwd
-// per-pixel state of the back-to-front recurrence
-struct BwdState {
-    float T, acc0, acc1, acc2, accd;      // transmittance after, and colour / inverse depth composited behind, the cursor
-};
-
-// One splat against one pixel, branch-free: updates the recurrence and returns ten partial sums
-// v = (q dx, q dy, q dx^2, q dx dy, q dy^2, q, w r', w g', w b', w d') with q = dL/dG * G: the geometric part is
-// accumulated as MOMENTS of q -- the map to the gradients of (mean2D, conic, opacity) is linear with per-splat
-// constants and is applied once per Gaussian in preprocess_bwd.  A lane for which the pair is inactive runs the
-// same code with alpha = G = 0: a zero-alpha splat is transparent to the recurrence (T and the colour behind stay
-// exactly as they were) and every output becomes exactly 0.
-template <bool INVD>
-__device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1, const float4 &r2, float dx, float dy,
-                                         float G_in, float alpha_in, float dp0, float dp1, float dp2, float dinvd,
-                                         float Tfinal_bgdot, float *v)
-{
-    const float alpha = act ? alpha_in : 0.f;
-    const float Gop = act ? G_in * r1.y : 0.f;                 // alpha = min(0.99, op*G) is straight-through
-    const float om = 1.f - alpha;
-    const float rcp1ma = __builtin_amdgcn_rcpf(om);            // 1 - alpha >= 0.01; rcp(1) == 1
-    s.T = s.T * rcp1ma;                                        // transmittance in front of this splat
-    const float w = alpha * s.T;
-    float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2;
-    if (INVD) dL_dalpha += (r2.y - s.accd) * dinvd;
-    dL_dalpha = dL_dalpha * s.T - Tfinal_bgdot * rcp1ma;
-    // colour composited behind the NEXT (nearer) splat
-    s.acc0 = alpha * r1.z + om * s.acc0;
-    s.acc1 = alpha * r1.w + om * s.acc1;
-    s.acc2 = alpha * r2.x + om * s.acc2;
-    if (INVD) s.accd = alpha * r2.y + om * s.accd;
-    v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = INVD ? w * dinvd : 0.f;
-    const float q = Gop * dL_dalpha;
-    const float qx = q * dx, qy = q * dy;
-    v[0] = qx; v[1] = qy; v[2] = qx * dx; v[3] = qx * dy; v[4] = qy * dy; v[5] = q;
-}
-
 // WPB = waves per block.  4: one block per unit, the four quadrant waves share one 256-entry queue and move through it
 // in lockstep (two block barriers per queue).  1: one block per (unit, quadrant) -- a wave on its own 64-entry queue: no
 // block barrier, no waiting for a slower quadrant, a quadrant that is done frees its slot, and the scheduler places

@@ -103,14 +103,21 @@ struct BinningState {
     float *seg_state;      // [2N/L + 2][7][256]
     uint2 *deep_tab;       // [N/1024 + T + 2] (tile, run): every 1024-key sort run / merge chunk of every tile with >= 2 keys
     uint32_t *multi_tab;   // [N/1024 + 2] tiles with more than one run (they need merging)
+    // micro-tile compositing (blend_micro.hip): per (unit, 4x4 pixel block) the Gaussian ids of the unit's entries whose
+    // {alpha >= 1/255} ellipse touches the block, in list (depth) order.  Block b of the unit whose entries are
+    // [beg, beg + cn) starts at mlist[16 beg + b cn]: worst-case capacity (every entry in every block) at a fixed address,
+    // no scan; only the lines actually written (~2.3 ids per entry on mesh scenes) ever move.
+    uint32_t *mlist;       // [16 N]
+    uint32_t *mcount;      // [units][16] ids per (unit, block)
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
     static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 1024 + T + 2; }
     static __host__ __device__ size_t n_multi(size_t N) { return N / 1024 + 2; }
-    static __host__ __device__ size_t bytes(size_t N, size_t T, size_t L)
+    static __host__ __device__ size_t bytes(size_t N, size_t T, size_t L, bool micro)
     {
         return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 32, 256) +
-               align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256) + align_up(n_multi(N) * 4, 256);
+               align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256) + align_up(n_multi(N) * 4, 256) +
+               (micro ? align_up((N > 0 ? N : 1) * 64, 256) + align_up(n_units(N, T, L) * 64, 256) : 0);
     }
     static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
     {
@@ -120,7 +127,9 @@ struct BinningState {
         b.unit_tile = (uint4 *)p;    p += align_up(n_units(N, T, L) * 32, 256);
         b.seg_state = (float *)p;    p += align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
         b.deep_tab = (uint2 *)p;     p += align_up(n_deep(N, T) * 8, 256);
-        b.multi_tab = (uint32_t *)p;
+        b.multi_tab = (uint32_t *)p; p += align_up(n_multi(N) * 4, 256);
+        b.mlist = (uint32_t *)p;     p += align_up((N > 0 ? N : 1) * 64, 256);       // (present only in micro mode)
+        b.mcount = (uint32_t *)p;
         return b;
     }
 };

@@ -112,7 +112,7 @@ void profile_end(int kid, hipStream_t stream)
 static const char *const k_names[GMS_K_COUNT] = {
     "preprocess_fwd", "tile_scan", "emit_instances", "tile_sort", "blend_fwd",
     "blend_bwd", "preprocess_bwd", "mesh_fwd", "mesh_bwd_splat", "mesh_bwd_face", "blend_head", "blend_finalize",
-    "l1_ssim_fwd", "l1_ssim_bwd", "adam", "sh_grad_expand"};
+    "l1_ssim_fwd", "l1_ssim_bwd", "adam", "sh_grad_expand", "micro_filter"};
 
 extern "C" void gms_profile_enable(int32_t on) { gms::g_profile_on = on != 0; }
 

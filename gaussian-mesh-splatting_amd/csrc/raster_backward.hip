@@ -37,6 +37,7 @@ struct PreBwdArgs {
     float *dL_dmean2D, *dL_dopacity, *dL_dcolors;
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscales, *dL_drots;
     float *dL_dcolor_sh;    // SH path, factorised mode: clamp-masked dL/dcolour [P,3] INSTEAD of the SH gradient rows
+    int campos_row;         // factorised mode: also write the camera centre into row P of dL_dcolor_sh
 };
 
 // SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
@@ -372,6 +373,9 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     a.dL_dopacity[i] = dop;
     a.dL_dmean2D[3 * (size_t)i] = acc_mx; a.dL_dmean2D[3 * (size_t)i + 1] = acc_my; a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
     if (a.dL_dcolors) { a.dL_dcolors[3 * (size_t)i] = acc_col[0]; a.dL_dcolors[3 * (size_t)i + 1] = acc_col[1]; a.dL_dcolors[3 * (size_t)i + 2] = acc_col[2]; }
+    if (a.dL_dcolor_sh && a.campos_row && i == 0) {
+        a.dL_dcolor_sh[3 * (size_t)a.P] = a.campos[0]; a.dL_dcolor_sh[3 * (size_t)a.P + 1] = a.campos[1]; a.dL_dcolor_sh[3 * (size_t)a.P + 2] = a.campos[2];
+    }
     if (a.dL_dcolor_sh) { a.dL_dcolor_sh[3 * (size_t)i] = dcol_sh[0]; a.dL_dcolor_sh[3 * (size_t)i + 1] = dcol_sh[1]; a.dL_dcolor_sh[3 * (size_t)i + 2] = dcol_sh[2]; }
     a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1]; a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     if (a.cov3Dp) {
@@ -508,13 +512,14 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = cap;
         g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
+        g.mlist = bin.mlist; g.mcount = bin.mcount;
         BlendBwdArgs b;
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
         b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.accum = A->grad_accum;
         b.has_invd = A->dL_dout_invdepth != nullptr;
         uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
         if (A->num_units > 0 && (uint64_t)A->num_units < mu) mu = (uint32_t)A->num_units;      // exact count from the forward
-        int32_t rc = launch_blend_backward(g, b, mu, A->debug != 0, stream);
+        int32_t rc = micro_mode() ? launch_micro_backward(g, b, mu, A->debug != 0, stream) : launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
         if (fault_mode() == 1)      // negative control: sum(q dx^2) of every 1000th Gaussian off by 2e-3
             fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->grad_accum, P, GRAD_STRIDE, GRAD_CA, 1000, 1.002f);
@@ -525,7 +530,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = fault_mode() == 3 ? 0 : A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
-    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = A->shs ? A->dL_dcolors : nullptr; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
+    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = A->shs ? A->dL_dcolors : nullptr; p.campos_row = A->factor_campos_row; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");

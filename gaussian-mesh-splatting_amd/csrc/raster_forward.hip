@@ -982,12 +982,20 @@ static uint32_t deepest_tile(const int32_t *slot)
     return (uint32_t)(__atomic_load_n(reinterpret_cast<const unsigned long long *>(slot) + 1, __ATOMIC_RELAXED) & 0xffffffffull);
 }
 
+bool micro_mode()
+{
+    static int m = -1;
+    if (m < 0) { const char *e = getenv("GMS_MICRO"); m = e ? (atoi(e) != 0 ? 1 : 0) : GMS_MICRO_DEFAULT; }
+    return m == 1;
+}
+
 uint32_t seg_len_forced()
 {
     static int64_t L = -1;
     if (L < 0) {
         uint32_t v = 0;
         if (const char *e = getenv("GMS_SEG_LEN")) { v = (uint32_t)atoi(e); if (v < 64) v = 64; v = (v + 63u) / 64u * 64u; }
+        if (micro_mode()) { if (v == 0) v = SEG_LEN_MICRO; if (v > 1024u) v = 1024u; }      // one L for every frame
         L = v;
     }
     return (uint32_t)L;
@@ -1023,7 +1031,7 @@ extern "C" size_t gms_image_n_contrib_offset(int32_t w, int32_t h)
 extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 {
     const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
-    return BinningState::bytes((size_t)(n > 0 ? n : 0), T, seg_len_min());
+    return BinningState::bytes((size_t)(n > 0 ? n : 0), T, seg_len_min(), micro_mode());
 }
 
 extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *stream_)
@@ -1191,6 +1199,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
+        g.mlist = bin.mlist; g.mcount = bin.mcount;
+        if (micro_mode()) return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
         return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);
     };
 
@@ -1198,7 +1208,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     if (A->binning_capacity_hint > 0) {
         // optimistic path: enqueue the whole tail before looking at N (no pipeline bubble)
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
-        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L, micro_mode()));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
         int32_t rc = enqueue_tail(bin_mem, cap, false);
         if (rc != GMS_OK) return rc;
@@ -1214,7 +1224,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
             if (rc != GMS_OK) return rc;
         }
         if ((uint64_t)N > cap) {                         // rare: re-run the tail at the right size
-            bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L));
+            bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)N, (size_t)T, L, micro_mode()));
             if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
             GMS_HIP_CHECK(hipMemsetAsync(img.tile_cursor, 0, (size_t)T * 4, stream));
             rc = enqueue_tail(bin_mem, (uint64_t)N, true);
@@ -1228,7 +1238,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         units_seen = unit_count(slot);
         units_hint = max(units_seen, (uint32_t)(0.97 * units_hint));
         const uint64_t cap = (uint64_t)(N > 0 ? N : 1);
-        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L));
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L, micro_mode()));
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
         int32_t rc = enqueue_tail(bin_mem, cap, true);         // N is exact here, so the table-sized launch is tight
         if (rc != GMS_OK) return rc;

@@ -222,9 +222,9 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
     a.dL_dmeans3D = mf(b.dmeans3D); a.dL_dcov3D = mf(b.dcov3D); a.dL_dsh = mf(b.dsh); a.dL_dsh_rest = mf(b.dsh_rest);
     a.dL_dscales = mf(b.dscales); a.dL_drotations = mf(b.drots);
     a.grad_accum_rezero = 1; a.num_units = num_units;
+    a.factor_campos_row = (has_sh && b.dcolors.defined() && b.dcolors.size(0) == P + 1) ? 1 : 0;      // row P = the camera centre
     if (P > 0) check_rc(gms_rasterize_backward(&a, stream), "gms_rasterize_backward");
-    if (has_sh && b.dcolors.defined()) {          // factorised mode: append the camera centre, queue the factor for the exchange
-        b.dcolors.narrow(0, P, 1).copy_(campos.reshape({1, 3}));
+    if (has_sh && b.dcolors.defined()) {          // factorised mode: queue the factor (rows 0..P-1 + camera centre) for the exchange
         std::lock_guard<std::mutex> lk(g_mu);
         g_factors.push_back(b.dcolors);
     }

@@ -54,6 +54,7 @@ class RasterBackwardArgs(C.Structure):
         ("dL_dmeans2D", C.c_void_p), ("dL_dopacity", C.c_void_p), ("dL_dcolors", C.c_void_p),
         ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("grad_accum_rezero", C.c_int32), ("num_units", C.c_int64),
+        ("factor_campos_row", C.c_int32),
     ]
 
 
@@ -98,7 +99,7 @@ EXPORTS = (
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
     "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault",
 )
-K_COUNT = 16
+K_COUNT = 17
 
 _lock = threading.Lock()
 _lib = None

@@ -203,11 +203,24 @@ class ShFactorExchange:
         self.f_dc, self.f_rest = features_dc, features_rest
         self.world, self.group = int(world), group
         self._comm = (self.world > 1 or force) and dist.is_initialized()
-        self._work, self._gathered = None, None
+        self._work, self._gathered, self._local = None, None, None
 
     def enable(self) -> "ShFactorExchange":
         self._set_mode(True)
         return self
+
+    def watch(self, means3D: torch.Tensor) -> None:
+        """Start the gather from inside the backward pass: `means3D` is the (non-leaf) position tensor the rasterizer was
+        given; its gradient is complete exactly when the last view's rasterizer backward has returned -- the factors are
+        queued by then -- so the all-gather travels while the mesh->Gaussian backward still runs.  Call once per step,
+        after the forward of the step's views; without it `start()` must be called after `backward()`."""
+        if means3D.requires_grad:
+            means3D.register_hook(self._hook)
+
+    def _hook(self, grad):
+        if self._gathered is None:
+            self.start()
+        return None
 
     def disable(self) -> None:
         self._set_mode(False)
@@ -218,6 +231,7 @@ class ShFactorExchange:
         if not facs:
             raise RuntimeError("ShFactorExchange.start(): no factor was queued -- was backward() run on the SH path with the mode on?")
         local = facs[0].unsqueeze(0) if len(facs) == 1 else torch.stack(facs)          # [v, P+1, 3]
+        self._local = local                       # (kept alive until the gather has completed)
         if self._comm:
             self._gathered = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             self._work = dist.all_gather_into_tensor(self._gathered, local.contiguous(), group=self.group, async_op=True)
@@ -240,5 +254,5 @@ class ShFactorExchange:
         for p, g in ((self.f_dc, dc), (self.f_rest, rest)):
             g = g.view(p.shape).to(p.dtype)
             p.grad = g if p.grad is None else p.grad.add_(g)
-        self._gathered, self._work = None, None
+        self._gathered, self._work, self._local = None, None, None
 

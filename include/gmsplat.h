@@ -153,6 +153,9 @@ typedef struct GmsRasterBackwardArgs {
     int32_t grad_accum_rezero;
     /* work units reported by the forward (num_units_out), or 0: the backward launch is then sized from binning_capacity */
     int64_t num_units;
+    /* factorised mode only: 1 = dL_dcolors has P+1 rows and the call writes the view's camera centre into row P (the factor then
+     * carries everything gms_sh_grad_expand needs about its view: one buffer to exchange, no separate copy) */
+    int32_t factor_campos_row;
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);
@@ -294,7 +297,8 @@ int32_t gms_adam_step(const GmsAdamTensor *tensors /* HOST array */, int32_t cou
 #define GMS_K_LOSS_BWD 13
 #define GMS_K_ADAM 14
 #define GMS_K_SH_EXPAND 15
-#define GMS_K_COUNT 16
+#define GMS_K_MICRO_FILTER 16
+#define GMS_K_COUNT 17
 void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);

@@ -120,9 +120,10 @@ def test_config4_exchanged_gradients_equal_the_sum_of_the_single_view_gradients(
         for k, (a, b) in enumerate(zip(grads, serial)):
             a, b = a.double().numpy(), b.numpy()
             scale = np.abs(b).max()
-            # float atomics: two runs of ONE view already differ in the last bits, more on ill-conditioned rows; the exchange
-            # itself adds one float32 rounding per element.  Bound: 1e-5 of the tensor's scale at the 0.999 quantile, 1e-4
-            # relative (floor: 1 % of the scale) on every entry
+            # float atomics: two runs of ONE view already differ in the last bits, more on ill-conditioned rows (measured on the
+            # MI355X: 0.999 quantile 3e-7 of the tensor's scale, worst entry 1.6e-4 relative); the exchange itself adds one
+            # float32 rounding per element.  Bound: 1e-5 of the tensor's scale at the 0.999 quantile, and the north-star 1e-3
+            # relative (floor: 1 % of the scale) on EVERY entry
             rel = np.abs(a - b) / (np.abs(b) + 1e-2 * scale + 1e-30)
-            assert np.quantile(np.abs(a - b), 0.999) <= 1e-5 * scale + 1e-30 and rel.max() <= 1e-4, (workload, variant, k, float(rel.max()))
+            assert np.quantile(np.abs(a - b), 0.999) <= 1e-5 * scale + 1e-30 and rel.max() <= 1e-3, (workload, variant, k, float(rel.max()))
     assert "ring" in ran and "factor" in ran, res.keys()
