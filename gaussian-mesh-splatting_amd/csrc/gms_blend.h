@@ -28,6 +28,8 @@ struct BlendGrid {
     unsigned long long *dbg_buf;   // GMS_DBG&16: per block {start, end} wall clock (100 MHz), else NULL
     uint32_t *mlist;               // micro mode: [16 capacity] ids per (unit, 4x4 block), see BinningState
     uint32_t *mcount;              // micro mode: [units][16]
+    uint32_t *wtab_fwd, *wtab_bwd; // micro mode: (unit, block) pieces grouped by list length, see BinningState
+    uint32_t *whist;               // micro mode: piece histogram / cursors / class totals
 };
 
 struct BlendFwdOut {
