@@ -31,56 +31,23 @@ namespace gms {
 constexpr int QROW = 17;          // LDS queue slots per row (16 used): 17 x 12 dwords staggers the four rows over the banks
 constexpr int QSLOTS = 4 * QROW;
 
-// Piece classes (which launches walk a (unit, block) piece) and the length buckets of the counting sort
-enum { PC_FIRST = 0, PC_MID_EARLY, PC_MID_LATE, PC_LAST, PC_BWD, PC_COUNT };
-constexpr int MBUCKETS = (int)BinningState::MICRO_BUCKETS;
-static_assert(PC_COUNT == (int)BinningState::MICRO_CLASSES, "piece classes");
-constexpr int WH_CURSOR = PC_COUNT * MBUCKETS, WH_TOTAL = 2 * PC_COUNT * MBUCKETS;
-__device__ __forceinline__ int piece_bucket(uint32_t count, uint32_t L) { return (int)min(32u, (count * 32u + L - 1u) / L); }
-__device__ __forceinline__ int piece_class(int seg, int nseg, uint32_t L)
-{
-    if (seg == 0) return PC_FIRST;
-    if (seg == nseg - 1) return PC_LAST;
-    return seg < tloc_head(L) ? PC_MID_EARLY : PC_MID_LATE;
-}
-
-// pixel `li` of 4x4 block `b` of a tile; index of the pixel in the per-(unit, pixel) segment state = b * 16 + li
-__device__ __forceinline__ void block_pixel(int tx, int ty, int b, int li, int &xi, int &yi)
-{
-    xi = tx * TILE + (b & 3) * 4 + (li & 3);
-    yi = ty * TILE + (b >> 2) * 4 + (li >> 2);
-}
-
-// One row (16 lanes) of a wave = one (unit, block) piece; all fields are uniform across the row's lanes.
-struct Row {
-    bool on;               // the row has a piece
-    int b, tile, seg, nseg, xi, yi, tid; bool inside;
-    uint32_t idx, slot0, beg, cn, cnt, L;
-    const uint32_t *ml;    // the piece's ids
+struct MPix {
+    int xi, yi, tid, b; bool inside; float xf, yf;
 };
 
-// rows 4 w .. 4 w + 3 of the sorted piece table `tab[first .. first + count)` for wave w
-__device__ __forceinline__ Row load_row(const BlendGrid &g, const uint32_t *tab, uint32_t first, uint32_t count)
+// wave q of a unit = the tile's 8x8 quadrant q; row r of the wave = block r of the quadrant; lane i of the row = pixel i
+__device__ __forceinline__ MPix micro_pixel(const BlendGrid &g, int tx, int ty, int q, int lane)
 {
-    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    Row r;
-    const uint32_t pi = 4u * blockIdx.x + (uint32_t)row;
-    r.on = pi < count;
-    const uint32_t desc = r.on ? tab[first + pi] : 0u;
-    r.idx = desc >> 4; r.b = (int)(desc & 15u);
-    const uint4 r0 = g.unit_tile[2 * (size_t)r.idx], r1 = g.unit_tile[2 * (size_t)r.idx + 1];
-    r.tile = (int)r0.x; r.seg = (int)r0.y; r.nseg = (int)r0.z; r.slot0 = r0.w;
-    r.L = g.scan_out[3];
-    r.beg = r1.x + (uint32_t)r.seg * r.L;
-    const uint32_t end = min(r1.y, r.beg + r.L);
-    r.cn = end > r.beg ? end - r.beg : 0u;
-    if ((uint64_t)r1.y > g.capacity) r.on = false;          // overflowed optimistic launch: the host re-runs
-    r.cnt = r.on ? g.mcount[(size_t)r.idx * 16 + r.b] : 0u;
-    r.ml = g.mlist + (size_t)16 * r.beg + (size_t)r.b * r.cn;
-    block_pixel(r.tile % g.gx, r.tile / g.gx, r.b, li, r.xi, r.yi);
-    r.inside = r.on && r.xi < g.W && r.yi < g.H;
-    r.tid = r.b * 16 + li;
-    return r;
+    const int row = lane >> 4, li = lane & 15;
+    const int bx = (q & 1) * 2 + (row & 1), by = (q >> 1) * 2 + (row >> 1);
+    MPix p;
+    p.b = by * 4 + bx;
+    p.xi = tx * TILE + bx * 4 + (li & 3);
+    p.yi = ty * TILE + by * 4 + (li >> 2);
+    p.inside = p.xi < g.W && p.yi < g.H;
+    p.xf = (float)p.xi; p.yf = (float)p.yi;
+    p.tid = q * WAVE + lane;          // index of the pixel in the per-(unit, pixel) segment state
+    return p;
 }
 
 __device__ __forceinline__ uint32_t max4rows(uint32_t v)          // v is row-uniform
@@ -91,155 +58,240 @@ __device__ __forceinline__ uint32_t max4rows(uint32_t v)          // v is row-un
 }
 
 // ------------------------------------------------------------------------------------ filter
-// which of the tile's sixteen 4x4 blocks can see the splat with alpha >= 1/255 (bit by * 4 + bx)
+// Which of the tile's sixteen 4x4 blocks can see the splat with alpha >= 1/255 (bit by * 4 + bx).  Conservative: it may keep
+// a (splat, block) pair no pixel of the block accepts, never the reverse.
+//
+// The region {alpha >= 1/255} is the ellipse Q(d) = A dx^2 + 2 B dx dy + C dy^2 <= thr, thr = 2 (ln(255 op) + 1e-3) (the same
+// inflated threshold the record's extents were built from).  A block spans a whole band of four pixel rows, so it meets the
+// (convex) ellipse iff the x-projection of (ellipse intersected with the band) overlaps the block's columns.  The slice of the
+// ellipse at height dy is dx in (-B dy -+ sqrt(D)) / A with D(dy) = A thr - det dy^2; the right end is concave in dy with its
+// maximum at the ellipse's rightmost point dy_R = -B ex / C, the left end convex with its minimum at -dy_R, so the band's
+// projection is [left(clamp(-dy_R)), right(clamp(dy_R))] with the clamp to the band, and the band misses the ellipse iff D
+// is negative at the clamped point.  Four bands x (2 square roots + 8 compares) instead of sixteen rectangle tests.
+// det = A C - B^2 cancels badly for long thin splats; it is taken from the record's extent instead (ey^2 = thr A / det,
+// computed from the covariance in the preprocess kernel).  Slack as in rect_hit: 0.01 + 1e-4 thr + 4e-6 x the gross terms of Q
+// at the far corner of the tile (the float error of the per-pixel exponent itself), plus 1e-3 pixel on the interval ends.
 __device__ __forceinline__ uint32_t block_mask(const SplatRec &r, float tx0, float ty0)
 {
+    const float px = r.q0.x, py = r.q0.y, A = r.q0.z, B = r.q0.w, C = r.q1.x, ex = r.q2.z, ey = r.q2.w;
+    const float thr = 2.f * (__logf(255.f * r.q1.y) + 1e-3f);
+    // bounding box of the ellipse against the tile (also rejects the ext = -1e30 records of splats below 1/255 everywhere)
+    if (px + ex < tx0 || px - ex > tx0 + 15.f || py + ey < ty0 || py - ey > ty0 + 15.f) return 0u;
     uint32_t m = 0;
-    const float px = r.q0.x, py = r.q0.y, ex = r.q2.z, ey = r.q2.w;
+    if (!(thr > 1e-4f)) {
+        // a splat that reaches 1/255 only within rounding of its centre: the bounding box alone (it carries the inflation)
+#pragma unroll
+        for (int by = 0; by < 4; by++) {
+            const float y0 = ty0 + 4.f * by;
+            const bool yhit = !(py + ey < y0 || py - ey > y0 + 3.f);
+#pragma unroll
+            for (int bx = 0; bx < 4; bx++) {
+                const float x0 = tx0 + 4.f * bx;
+                if (yhit && !(px + ex < x0 || px - ex > x0 + 3.f)) m |= 1u << (by * 4 + bx);
+            }
+        }
+        return m;
+    }
+    const float mx = fmaxf(fabsf(tx0 - px), fabsf(tx0 + 15.f - px)), my = fmaxf(fabsf(ty0 - py), fabsf(ty0 + 15.f - py));
+    const float gross = mx * (A * mx + 2.f * fabsf(B) * my) + C * my * my;
+    const float thr2 = thr * 1.0001f + 0.01f + 4e-6f * gross;            // inflated threshold
+    const float grow = thr2 * __builtin_amdgcn_rcpf(thr);                // ex'^2 / ex^2 = ey'^2 / ey^2
+    const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+    const float AT = A * thr2;
+    const float inv_ey2 = __builtin_amdgcn_rcpf(ey * ey * grow);        // 1 / ey'^2  (det = A thr2 / ey'^2)
+    const float dyR = -B * ex * __builtin_amdgcn_sqrtf(grow) * iC;       // height of the rightmost point (the leftmost: -dyR)
 #pragma unroll
     for (int by = 0; by < 4; by++) {
-        const float y0 = ty0 + 4.f * by, y1 = y0 + 3.f;
-        if (py + ey < y0 || py - ey > y1) continue;
+        const float dya = ty0 + 4.f * by - py, dyb = dya + 3.f;
+        const float c1 = fminf(fmaxf(dyR, dya), dyb), c2 = fminf(fmaxf(-dyR, dya), dyb);
+        const float D1 = AT * (1.f - c1 * c1 * inv_ey2), D2 = AT * (1.f - c2 * c2 * inv_ey2);
+        const bool band = D1 >= 0.f;                                   // (D2 >= 0 says the same: both points lie in the band)
+        const float xr = px + (__builtin_amdgcn_sqrtf(fmaxf(D1, 0.f)) - B * c1) * iA + 1e-3f;
+        const float xl = px - (__builtin_amdgcn_sqrtf(fmaxf(D2, 0.f)) + B * c2) * iA - 1e-3f;
 #pragma unroll
         for (int bx = 0; bx < 4; bx++) {
-            const float x0 = tx0 + 4.f * bx, x1 = x0 + 3.f;
-            if (px + ex < x0 || px - ex > x1) continue;
-            if (rect_hit(r.q0, r.q1.x, r.q1.y, r.q2, RectF{x0, y0, x1, y1})) m |= 1u << (by * 4 + bx);
+            const float x0 = tx0 + 4.f * bx;
+            if (band && xr >= x0 && xl <= x0 + 3.f) m |= 1u << (by * 4 + bx);
         }
     }
     return m;
 }
 
+// One block per unit.  Each wave takes a contiguous quarter of the unit's entries (64 at a time), counts its hits per block,
+// and after ONE barrier writes the survivors' ids behind those of the waves in front of it (ballot ranks: list order kept).
 __global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const SplatRec *rec)
 {
+    constexpr int MAXC = 4;                        // 64-entry chunks per wave: L <= 1024
     __shared__ uint32_t wcnt[4][16];
     __shared__ uint32_t running[16];
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
-    if (tid < 16) running[tid] = 0;
     uint32_t *out = g.mlist + (size_t)16 * u.beg;
     const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (uint32_t c0 = 0; c0 < cn; c0 += BLOCK) {
-        const uint32_t e = c0 + (uint32_t)tid;
-        uint32_t id = 0, mask = 0;
-        if (e < cn) {
-            id = (uint32_t)g.keys[u.beg + e];
-            mask = block_mask(rec[id], tx0, ty0);
+    const uint32_t per = ((cn + 255u) / 256u) * 64u;          // entries per wave, a multiple of 64
+    const uint32_t w0 = (uint32_t)wave * per;
+    uint32_t ids[MAXC], masks[MAXC];
+    uint32_t mycnt = 0;                            // lane b < 16: hits of block b in this wave's entries
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const uint32_t e = w0 + (uint32_t)(c * 64 + lane);
+        ids[c] = 0; masks[c] = 0;
+        if ((uint32_t)(c * 64) < per && e < cn) {
+            ids[c] = (uint32_t)g.keys[u.beg + e];
+            masks[c] = block_mask(rec[ids[c]], tx0, ty0);
         }
 #pragma unroll
         for (int b = 0; b < 16; b++) {
-            const uint64_t bal = __ballot((mask >> b) & 1u);
-            if (lane == b) wcnt[wave][b] = (uint32_t)__builtin_popcountll(bal);
+            const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((masks[c] >> b) & 1u));
+            if (lane == b) mycnt += n;
         }
-        __syncthreads();          // (also orders the initial running[] = 0)
-#pragma unroll
-        for (int b = 0; b < 16; b++) {
-            const uint64_t bal = __ballot((mask >> b) & 1u);
-            if ((mask >> b) & 1u) {
-                uint32_t base = running[b];
-                for (int w = 0; w < wave; w++) base += wcnt[w][b];
-                out[(size_t)b * cn + base + (uint32_t)__builtin_popcountll(bal & lt)] = id;
-            }
-        }
-        __syncthreads();
-        if (tid < 16) running[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-        __syncthreads();
     }
-    if (tid < 16) {
-        const uint32_t c = running[tid];
-        g.mcount[(size_t)u.idx * 16 + tid] = c;
-        // length histograms of the pieces, per launch class and for the backward (non-empty pieces): input of micro_plan
-        const int bk = piece_bucket(c, u.L);
-        atomicAdd(&g.whist[piece_class(u.seg, u.nseg, u.L) * MBUCKETS + bk], 1u);
-        if (c > 0) atomicAdd(&g.whist[PC_BWD * MBUCKETS + bk], 1u);
-    }
-}
-
-// ------------------------------------------------------------------------------------ plan
-// Counting sort of the (unit, block) pieces by list length, heaviest first, one table for the forward launches (classes
-// first | middle early | middle late | last, in this order) and one for the backward: four CONSECUTIVE table entries
-// form a wave, so the four rows of a wave walk lists of (nearly) the same length -- 0.58 wave trips per instance instead
-// of the 0.81 the four blocks of one quadrant give, and waves of equal weight dispatched heaviest first.
-__global__ void __launch_bounds__(WAVE) micro_plan_kernel(BlendGrid g)
-{
-    __shared__ uint32_t base[PC_COUNT][MBUCKETS];
-    __shared__ uint32_t total[PC_COUNT];
-    const int lane = threadIdx.x;
-    if (lane < PC_COUNT) {
-        uint32_t run = 0;
-        for (int k = MBUCKETS - 1; k >= 0; k--) { base[lane][k] = run; run += g.whist[lane * MBUCKETS + k]; }
-        total[lane] = run;
-    }
+    if (lane < 16) wcnt[wave][lane] = mycnt;
     __syncthreads();
-    if (blockIdx.x == 0 && lane < PC_COUNT) g.whist[WH_TOTAL + lane] = total[lane];
-    const uint32_t idx = blockIdx.x * 4u + (uint32_t)(lane >> 4);
-    const int b = lane & 15;
-    const uint32_t nunits = g.unit_first[g.T];
-    if (idx >= nunits || idx >= g.max_units) return;
-    const uint4 r0 = g.unit_tile[2 * (size_t)idx], r1 = g.unit_tile[2 * (size_t)idx + 1];
-    if ((uint64_t)r1.y > g.capacity) return;
-    const uint32_t L = g.scan_out[3];
-    const uint32_t c = g.mcount[(size_t)idx * 16 + b];
-    const int bk = piece_bucket(c, L), cls = piece_class((int)r0.y, (int)r0.z, L);
-    uint32_t off = 0;
-    for (int k = 0; k < cls; k++) off += total[k];
-    const uint32_t desc = idx * 16u + (uint32_t)b;
-    g.wtab_fwd[off + base[cls][bk] + atomicAdd(&g.whist[WH_CURSOR + cls * MBUCKETS + bk], 1u)] = desc;
-    if (c > 0) g.wtab_bwd[base[PC_BWD][bk] + atomicAdd(&g.whist[WH_CURSOR + PC_BWD * MBUCKETS + bk], 1u)] = desc;
+    uint32_t base[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        uint32_t s0 = 0;
+        for (int w = 0; w < wave; w++) s0 += wcnt[w][b];
+        base[b] = s0;
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint64_t bal = __ballot((masks[c] >> b) & 1u);
+            if ((masks[c] >> b) & 1u) out[(size_t)b * cn + base[b] + (uint32_t)__builtin_popcountll(bal & lt)] = ids[c];
+            base[b] += (uint32_t)__builtin_popcountll(bal);
+        }
+    }
+    if (tid < 16) running[tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    if (tid < 16) g.mcount[(size_t)u.idx * 16 + tid] = running[tid];
 }
 
 // ------------------------------------------------------------------------------------ queue
 // Each row keeps 16 entries of its own list in LDS; lane i of row r gathers entry j0 + i of the row's list.
+__device__ __forceinline__ SplatRec zero_rec()
+{
+    SplatRec z;
+    z.q0 = make_float4(0.f, 0.f, 0.f, 0.f); z.q1 = z.q0; z.q2 = z.q0;
+    return z;
+}
 __device__ __forceinline__ void queue_clear(SplatRec *recs)
 {
     const int lane = threadIdx.x & 63;
-    SplatRec z;
-    z.q0 = make_float4(0.f, 0.f, 0.f, 0.f); z.q1 = z.q0; z.q2 = z.q0;
+    const SplatRec z = zero_rec();
     recs[lane] = z;
     if (lane < QSLOTS - WAVE) recs[WAVE + lane] = z;
 }
 
-// ------------------------------------------------------------------------------------ fwd
-// Front-to-back walk of the four rows' lists.  A row is either EXACT (reference skip / stop tests from the true prefix
-// transmittance; its end state is written as image pixels for a single-segment tile, else as the segment's partials) or a
-// PRODUCT (a middle segment's prod(1 - alpha) without termination: the prefix of the segments behind it), chosen per row.
+// ------------------------------------------------------------------------------------ tloc
 template <int NE>
-__device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut &o, const Row &r, SplatRec *recs, bool exact, bool product, int phase)
+__device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase, int q)
+{
+    if (u.nseg == 1 || u.seg == u.nseg - 1) return;
+    if (phase >= 0 && (u.seg < tloc_head(u.L)) != (phase == 0)) return;     // phase -1: every segment in one launch
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    float *dst = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
+    if (phase == 1 && g.tile_dead[u.tile]) { *dst = 0.f; return; }
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
+    const uint32_t maxcnt = max4rows(cnt);
+    queue_clear(recs);
+    float Tl = 1.f;
+    // software-pipelined queue fill: the records of batch k+1 and the ids of batch k+2 are in flight while batch k is walked
+    SplatRec R = zero_rec();
+    uint32_t id2 = 16u + li < cnt ? ml[16u + li] : 0u;
+    if ((uint32_t)li < cnt) R = rec[ml[li]];
+    for (uint32_t j0 = 0; j0 < maxcnt; j0 += 16) {
+        // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
+        if (__all(Tl < T_MIN || !p.inside || j0 >= cnt)) break;
+        wave_sync();
+        if (j0 + li < cnt) recs[row * QROW + li] = R;
+        if (j0 + 16u + li < cnt) R = rec[id2];
+        id2 = j0 + 32u + li < cnt ? ml[j0 + 32u + li] : 0u;
+        wave_sync();
+        const int nt = (int)min(16u, maxcnt - j0);
+        for (int t = 0; t < nt; t += NE) {
+            float al[NE], pw[NE]; bool val[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const SplatRec *s = recs + row * QROW + t + e;
+                const float4 r0 = s->q0, r1 = s->q1;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                val[e] = j0 + t + e < cnt;
+                pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
+                al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+                if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
+        }
+    }
+    *dst = Tl;
+}
+
+// tile_dead[t] = 1 when the product of the first tloc_head(L) segment transmittances is < 1e-4 for every pixel
+__global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
+{
+    const int tile = blockIdx.x;
+    const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
+    const int nhead = tloc_head(g.scan_out[3]);
+    if (nseg <= nhead + 1) return;                 // no phase-1 segment exists (the last one needs no product)
+    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
+    const int tid = threadIdx.x;
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
+    const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
+    float T = 1.f;
+    for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    const int dead = __syncthreads_and(T < T_MIN || !p.inside);
+    if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------ fwd
+template <int NE>
+__device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs, int q)
 {
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const float xf = (float)r.xi, yf = (float)r.yi;
-    float *st = g.seg_state + (size_t)(r.slot0 + (uint32_t)r.seg) * SEG_FLOATS;
-    bool skip = !(exact || product);
-    if (product && phase == 1 && g.tile_dead[r.tile]) { st[SEG_TLOC * TILE_PIX + r.tid] = 0.f; skip = true; }   // products are irrelevant
-    const uint32_t cnt = skip ? 0u : r.cnt;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
     const uint32_t maxcnt = max4rows(cnt);
-    const uint32_t posbase = (uint32_t)r.seg * r.L;
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
 
     float T = 1.f;
-    if (exact && r.seg > 0) {
+    {
         // prefix product of the segments in front, four independent loads per step (same left-to-right order)
-        const float *tl = g.seg_state + (size_t)r.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + r.tid;
+        const float *tl = g.seg_state + (size_t)u.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
         int k = 0;
-        for (; k + 4 <= r.seg; k += 4) {
+        for (; k + 4 <= u.seg; k += 4) {
             const float t0 = tl[(size_t)k * SEG_FLOATS], t1 = tl[(size_t)(k + 1) * SEG_FLOATS];
             const float t2 = tl[(size_t)(k + 2) * SEG_FLOATS], t3 = tl[(size_t)(k + 3) * SEG_FLOATS];
             T = T * t0 * t1 * t2 * t3;
         }
-        for (; k < r.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
+        for (; k < u.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
     }
-    const bool dead_on_entry = T < T_MIN;          // only possible for an exact row with seg > 0
+    const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = skip || !r.inside || dead_on_entry;
+    bool done = !p.inside || dead_on_entry;
     queue_clear(recs);
+    // software-pipelined queue fill: the records of batch k+1 and the ids of batch k+2 are in flight while batch k is walked
+    SplatRec R = zero_rec();
+    uint32_t id2 = 16u + li < cnt ? ml[16u + li] : 0u;
+    if ((uint32_t)li < cnt) R = o.rec[ml[li]];
 
     for (uint32_t j0 = 0; j0 < maxcnt; j0 += 16) {
         if (__all(done || j0 >= cnt)) break;
         wave_sync();
-        if (j0 + li < cnt) recs[row * QROW + li] = o.rec[r.ml[j0 + li]];
+        if (j0 + li < cnt) recs[row * QROW + li] = R;
+        if (j0 + 16u + li < cnt) R = o.rec[id2];
+        id2 = j0 + 32u + li < cnt ? ml[j0 + 32u + li] : 0u;
         wave_sync();
         const int nt = (int)min(16u, maxcnt - j0);
         for (int t = 0; t < nt; t += NE) {
@@ -250,7 +302,7 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
                 const SplatRec *s = recs + row * QROW + t + e;
                 const float4 r0 = s->q0;
                 r1[e] = s->q1; r2[e] = s->q2;
-                const float dx = r0.x - xf, dy = r0.y - yf;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
                 val[e] = j0 + t + e < cnt;
                 pw[e] = pair_power(r0.z, r0.w, r1[e].x, dx, dy);
                 al[e] = fminf(ALPHA_MAX, r1[e].y * __expf(pw[e]));
@@ -259,25 +311,21 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
             for (int e = 0; e < NE; e++) {
                 bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
                 const float testT = T * (1.f - al[e]);
-                if (act && exact && testT < T_MIN) { done = true; act = false; }       // the reference's stop rule
+                if (act && testT < T_MIN) { done = true; act = false; }
                 if (act) {
                     const float w = al[e] * T;
                     C0 += r1[e].z * w; C1 += r1[e].w * w; C2 += r2[e].x * w;
                     Dp += r2[e].y * w;
                     T = testT;
                     last = posbase + j0 + (uint32_t)(t + e) + 1u;
-                    // a product below 1e-4: every later segment starts dead whatever the exact value
-                    if (!exact && T < T_MIN) done = true;
                 }
             }
             if (__all(done || j0 + t + NE >= cnt)) break;
         }
     }
-    if (skip || !r.on) return;
-    if (product) { st[SEG_TLOC * TILE_PIX + r.tid] = T; return; }
-    if (r.nseg == 1) {
-        if (r.inside) {
-            const size_t pid = (size_t)r.yi * g.W + r.xi, HW = (size_t)g.W * g.H;
+    if (u.nseg == 1) {
+        if (p.inside) {
+            const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
             o.final_T[pid] = T;
             o.n_contrib[pid] = last;
             o.out_color[pid] = C0 + T * o.bg[0];
@@ -286,60 +334,37 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
             o.out_invdepth[pid] = Dp;
         }
     } else {
-        st[SEG_C0 * TILE_PIX + r.tid] = C0; st[SEG_C1 * TILE_PIX + r.tid] = C1; st[SEG_C2 * TILE_PIX + r.tid] = C2;
-        st[SEG_D * TILE_PIX + r.tid] = Dp;
-        st[SEG_TEND * TILE_PIX + r.tid] = dead_on_entry ? -1.f : T;
-        st[SEG_LAST * TILE_PIX + r.tid] = __uint_as_float(last);
+        float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        st[SEG_C0 * TILE_PIX + p.tid] = C0; st[SEG_C1 * TILE_PIX + p.tid] = C1; st[SEG_C2 * TILE_PIX + p.tid] = C2;
+        st[SEG_D * TILE_PIX + p.tid] = Dp;
+        st[SEG_TEND * TILE_PIX + p.tid] = dead_on_entry ? -1.f : T;
+        st[SEG_LAST * TILE_PIX + p.tid] = __uint_as_float(last);
         // the first segment's exact walk doubles as its transmittance product (see blend.hip)
-        if (r.seg == 0) st[SEG_TLOC * TILE_PIX + r.tid] = done ? 0.f : T;
+        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + p.tid] = done ? 0.f : T;
     }
 }
 
-// First launch(es): every piece that depends on nothing -- first segments exactly, middle segments as products.
-// phase -1: all of them; phase 0: first + early middle segments; phase 1: the late middle segments (deep scenes: after the
-// tile-dead check).  The class ranges of the forward table are contiguous in exactly this order.
 template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const uint32_t *tot = g.whist + WH_TOTAL;
-    const uint32_t nA = tot[PC_FIRST], nB0 = tot[PC_MID_EARLY], nB1 = tot[PC_MID_LATE];
-    const uint32_t first = phase == 1 ? nA + nB0 : 0u;
-    const uint32_t count = phase == 1 ? nB1 : (phase == 0 ? nA + nB0 : nA + nB0 + nB1);
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count);
-    const bool exact = r.on && r.seg == 0, product = r.on && r.seg > 0;
-    micro_walk<NE>(g, o, r, recs, exact, product, phase);
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;            // the four quadrant waves of a unit are consecutive blocks of one XCD
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    const int q = (int)(bs & 3u);
+    if (u.seg == 0) { if (phase <= 0) micro_fwd_unit<NE>(g, o, u, recs, q); }
+    else micro_tloc_unit<NE>(g, o.rec, u, recs, phase, q);
 }
 
-// Second launch: segments 1.. of the multi-segment tiles, exactly, from the prefix product of the segments in front.
 template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const uint32_t *tot = g.whist + WH_TOTAL;
-    const uint32_t first = tot[PC_FIRST], count = tot[PC_MID_EARLY] + tot[PC_MID_LATE] + tot[PC_LAST];
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count);
-    micro_walk<NE>(g, o, r, recs, r.on, false, -1);
-}
-
-// tile_dead[t] = 1 when the product of the first tloc_head(L) segment transmittances is < 1e-4 for every pixel
-__global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
-{
-    const int tile = blockIdx.x;
-    const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
-    const int nhead = tloc_head(g.scan_out[3]);
-    if (nseg <= nhead + 1) return;                 // no late middle segment exists (the last one needs no product)
-    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
-    const int tid = threadIdx.x;
-    int xi, yi;
-    block_pixel(tile % g.gx, tile / g.gx, tid >> 4, tid & 15, xi, yi);
-    const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
-    float T = 1.f;
-    for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
-    const int dead = __syncthreads_and(T < T_MIN || xi >= g.W || yi >= g.H);
-    if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (u.seg == 0) return;
+    micro_fwd_unit<NE>(g, o, u, recs, (int)(bs & 3u));
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -351,8 +376,7 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
     if (nseg <= 1) return;
     if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
     const int tid = threadIdx.x;
-    int xi, yi;
-    block_pixel(tile % g.gx, tile / g.gx, tid >> 4, tid & 15, xi, yi);
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
     float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
     uint32_t last = 0;
@@ -374,8 +398,8 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
             }
         }
     }
-    if (xi < g.W && yi < g.H) {
-        const size_t pid = (size_t)yi * g.W + xi, HW = (size_t)g.W * g.H;
+    if (p.inside) {
+        const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
         o.final_T[pid] = T;
         o.n_contrib[pid] = last;
         o.out_color[pid] = C0 + T * o.bg[0];
@@ -416,61 +440,69 @@ template <bool INVD, int NE, int FAULT>
 __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     __shared__ SplatRec recs[QSLOTS];
-    __shared__ uint32_t ids[QSLOTS];
-    const uint32_t count = g.whist[WH_TOTAL + PC_BWD];
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_bwd, 0u, count);
+    __shared__ uint32_t ids[2][QSLOTS];                 // ids of the batch being walked / of the batch whose sums await their atomics
+    __shared__ float ystash[16][40];                    // the reduced sums of one batch: [trip][row * 10 + field lane]
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (u.end <= u.beg) return;
+    const int q = (int)(bs & 3u);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const float xf = (float)r.xi, yf = (float)r.yi;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
     const size_t HW = (size_t)g.W * g.H;
-    const size_t pid = (size_t)r.yi * g.W + r.xi;
-    const float Tfinal = r.inside ? a.final_T[pid] : 0.f;
-    const uint32_t last = r.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
+    const size_t pid = (size_t)p.yi * g.W + p.xi;
+    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
+    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
-    if (r.inside) {
+    if (p.inside) {
         dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
         if (INVD) dinvd = a.dL_dinvd[pid];
     }
     const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
-    const uint32_t posbase = (uint32_t)r.seg * r.L;
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
     // entries [0, lrel) of this block's list of this segment were composited by this pixel
-    const uint32_t lrel = last > posbase ? min(last - posbase, r.cnt) : 0u;
+    const uint32_t lrel = last > posbase ? min(last - posbase, cnt) : 0u;
     uint32_t top = lrel;                                    // furthest entry any pixel of the row composited
     top = max(top, (uint32_t)__shfl_xor((int)top, 8)); top = max(top, (uint32_t)__shfl_xor((int)top, 4));
     top = max(top, (uint32_t)__shfl_xor((int)top, 2)); top = max(top, (uint32_t)__shfl_xor((int)top, 1));
     const uint32_t maxtop = max4rows(top);
     if (maxtop == 0) return;
+    // software-pipelined queue fill (see the loop below); batch 0's ids and records start travelling here, behind the
+    // segment-restart loads that follow
+    uint32_t idc = (uint32_t)li < top ? ml[top - 1u - (uint32_t)li] : 0u;               // id of this lane's entry of the current batch
+    uint32_t id2 = 16u + li < top ? ml[top - 1u - (16u + li)] : 0u;                      // ... of the next batch
+    SplatRec R = zero_rec();
+    if ((uint32_t)li < top) R = a.rec[(FAULT == 10 || FAULT == 11) ? (idc & 1023u) : idc];
 
     BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
-    {
-        // restart of the recurrence at the segment boundary: T after this segment's last applied splat and the colour
-        // composited behind it (sum of the live partials of the later segments) divided by that T.  Rows of single-segment
-        // tiles (and rows that are off) keep (Tfinal, 0).
-        const bool multi = r.on && r.nseg > 1 && top > 0;
-        const float te = multi ? g.seg_state[(size_t)(r.slot0 + (uint32_t)r.seg) * SEG_FLOATS + SEG_TEND * TILE_PIX + r.tid] : 0.f;
-        const bool restart = multi && te > 0.f;
-        float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
-        bool stop = !restart;
-        for (int k0 = r.seg + 1; ; k0 += 4) {
-            if (k0 >= r.nseg) stop = true;
-            if (__all(stop)) break;
-            float tk[4], c0[4], c1[4], c2[4], dd[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float *sk = g.seg_state + (size_t)(r.slot0 + (uint32_t)max(0, min(k0 + j, r.nseg - 1))) * SEG_FLOATS;
-                tk[j] = stop ? -1.f : sk[SEG_TEND * TILE_PIX + r.tid]; c0[j] = stop ? 0.f : sk[SEG_C0 * TILE_PIX + r.tid];
-                c1[j] = stop ? 0.f : sk[SEG_C1 * TILE_PIX + r.tid]; c2[j] = stop ? 0.f : sk[SEG_C2 * TILE_PIX + r.tid];
-                dd[j] = (INVD && !stop) ? sk[SEG_D * TILE_PIX + r.tid] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // a pixel that is dead on entry to segment k is dead for every later one: stop at the first
-                if (k0 + j >= r.nseg || tk[j] < 0.f) stop = true;
-                if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
-            }
-        }
-        if (restart) {
+    if (u.nseg > 1) {
+        const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        const float te = st[SEG_TEND * TILE_PIX + p.tid];
+        if (te > 0.f) {
+            // restart of the recurrence at the segment boundary: T after this segment's last applied splat and the colour
+            // composited behind it (sum of the live partials of the later segments) divided by that T
             st8.T = te;
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
+            bool stop = false;
+            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += 4) {
+                float tk[4], c0[4], c1[4], c2[4], dd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float *sk = g.seg_state + (size_t)(u.slot0 + min(k0 + j, u.nseg - 1)) * SEG_FLOATS;
+                    tk[j] = sk[SEG_TEND * TILE_PIX + p.tid]; c0[j] = sk[SEG_C0 * TILE_PIX + p.tid];
+                    c1[j] = sk[SEG_C1 * TILE_PIX + p.tid]; c2[j] = sk[SEG_C2 * TILE_PIX + p.tid];
+                    dd[j] = INVD ? sk[SEG_D * TILE_PIX + p.tid] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k0 + j >= u.nseg || tk[j] < 0.f) stop = true;
+                    if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
+                }
+                if (__all(stop)) break;
+            }
             const float inv = FAULT == 2 ? 0.f : 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
         }
@@ -492,31 +524,50 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     default: afield = GRAD_G; break;       // lane 9
     }
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
+    // slot of the lane's sum in a trip's stash row: the ten field lanes of a row, compacted
+    const int sslot = row * 10 + ((li & 1) ? (li == 1 ? 8 : 9) : (li >> 1));      // (lane 14 -> 7; only written / read when alane)
     float *const abase = a.accum + afield;
     queue_clear(recs);
-    ids[lane] = 0u;
-    if (lane < QSLOTS - WAVE) ids[WAVE + lane] = 0u;
+    ids[0][lane] = 0u; ids[1][lane] = 0u;
+    if (lane < QSLOTS - WAVE) { ids[0][WAVE + lane] = 0u; ids[1][WAVE + lane] = 0u; }
 
-    // back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops)
-    for (uint32_t g0 = 0; g0 < maxtop; g0 += 16) {
-        wave_sync();
-        if (g0 + li < top) {
-            const uint32_t id = r.ml[top - 1u - (g0 + li)];
-            ids[row * QROW + li] = id;
-            recs[row * QROW + li] = a.rec[id];
+    // Back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops).
+    // Pipeline per batch of 16 trips:  [records of batch k -> LDS]  [atomics of batch k-1 from the stash]  [loads of batch
+    // k+1 / ids of batch k+2 issued]  [walk batch k: sums -> stash].  No memory operation is issued inside the walk, and
+    // everything the next batch boundary waits for (vmcnt counts loads and atomics alike on gfx9) was issued a whole walk
+    // earlier: neither the gather latency (two dependent hops) nor the atomics' round trip is exposed.
+    uint32_t prev_trips = 0;                      // bit t: trip t of the previous batch left sums in the stash
+    int buf = 0;
+    auto flush = [&](int b) {
+        while (prev_trips) {
+            const int t = __builtin_ctz(prev_trips);
+            prev_trips &= prev_trips - 1u;
+            if (alane) {
+                const float y = ystash[t][sslot];
+                // a row with no active pixel for this entry summed exact zeros: nothing to add (and its id may be stale)
+                if (FAULT == 9 || FAULT == 11) { if (y == 123.456f) a.accum[0] = y; }            // (timing experiments: no atomics)
+                else if (y != 0.f) unsafeAtomicAdd(abase + (size_t)ids[b][row * QROW + t] * GRAD_STRIDE, y);
+            }
         }
+    };
+    for (uint32_t g0 = 0; g0 < maxtop; g0 += 16, buf ^= 1) {
+        wave_sync();
+        if (g0 + li < top) { ids[buf][row * QROW + li] = idc; recs[row * QROW + li] = R; }
+        flush(buf ^ 1);
+        idc = id2;
+        if (g0 + 16u + li < top) R = a.rec[(FAULT == 10 || FAULT == 11) ? (id2 & 1023u) : id2];
+        id2 = g0 + 32u + li < top ? ml[top - 1u - (g0 + 32u + li)] : 0u;
         wave_sync();
         const int nt = (int)min(16u, maxtop - g0);
         for (int t = 0; t < nt; t += NE) {
-            bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE]; uint32_t sid[NE];
+            bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE];
             bool anyact = false;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                const SplatRec *s = recs + row * QROW + t + e;
-                const float4 r0 = s->q0;
-                r1[e] = s->q1; r2[e] = s->q2;
-                sid[e] = ids[row * QROW + t + e];
-                dx[e] = r0.x - xf; dy[e] = r0.y - yf;
+                const SplatRec *sr = recs + row * QROW + t + e;
+                const float4 r0 = sr->q0;
+                r1[e] = sr->q1; r2[e] = sr->q2;
+                dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
                 const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
                 G[e] = __expf(pw);
                 al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
@@ -531,11 +582,13 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
                 float v[10];
                 bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
                 const float y = row_reduce10(v, b3, b2, b1, b0);
-                // a row with no active pixel for this entry sums exact zeros: nothing to add (and its id may be stale)
-                if (alane && y != 0.f) unsafeAtomicAdd(abase + (size_t)sid[e] * GRAD_STRIDE, y);
+                if (alane) ystash[t + e][sslot] = y;
+                prev_trips |= 1u << (t + e);
             }
         }
     }
+    wave_sync();
+    flush(buf ^ 1);
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -548,11 +601,10 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 2; }
     GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_filter_kernel<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
-    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_plan_kernel<<<(blocks + 3u) / 4u, WAVE, 0, stream>>>(g));
     GMS_KERNEL_CHECK(debug, stream, "micro_filter");
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
-    if (deep) {     // deep scene: first + early middle segments, tile-dead check, then the late middle segments of live tiles
+    if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, micro_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 1));
@@ -577,7 +629,6 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
-                  : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
     }
