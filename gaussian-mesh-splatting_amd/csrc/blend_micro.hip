@@ -35,7 +35,13 @@ constexpr int QSLOTS = 4 * QROW;
 enum { PC_FIRST = 0, PC_MID_EARLY, PC_MID_LATE, PC_LAST, PC_BWD, PC_COUNT };
 constexpr int MBUCKETS = (int)BinningState::MICRO_BUCKETS;
 static_assert(PC_COUNT == (int)BinningState::MICRO_CLASSES, "piece classes");
-constexpr int WH_CURSOR = PC_COUNT * MBUCKETS, WH_TOTAL = 2 * PC_COUNT * MBUCKETS;
+constexpr int MREGIONS = (int)BinningState::MICRO_REGIONS;
+constexpr int WH_KEYS = PC_COUNT * MREGIONS * MBUCKETS;          // counters per histogram: (class, region, bucket)
+constexpr int WH_CURSOR = WH_KEYS, WH_TOTAL = 2 * WH_KEYS;
+// Spatial region of a tile = the XCD whose L2 should hold its splat records: 2x2-tile cells (32 px) dealt to the eight XCDs
+// in a skewed pattern.  A cell's Gaussians are shared with its neighbours only along the ~5 px halo, so an XCD gathers about
+// 1.3 / 8 of the scene's records (~2.4 MB at 300 k Gaussians: inside its 4 MB L2) instead of all of them.
+__device__ __forceinline__ int tile_region(int tile, int gx) { const int tx = tile % gx, ty = tile / gx; return ((tx >> 1) + 3 * (ty >> 1)) & 7; }
 __device__ __forceinline__ int piece_bucket(uint32_t count, uint32_t L) { return (int)min(32u, (count * 32u + L - 1u) / L); }
 __device__ __forceinline__ int piece_class(int seg, int nseg, uint32_t L)
 {
@@ -59,12 +65,36 @@ struct Row {
     const uint32_t *ml;    // the piece's ids
 };
 
+// Which wave of which class of a piece table block `blockIdx.x` walks.  The blocks of XCD x (= blockIdx % 8, how the
+// dispatcher deals them) take the x-th eighth of every class: the table is sorted by (class, region, length), so that eighth
+// is region x's pieces up to the imbalance between regions -- the records a wave gathers are in its own XCD's L2.
+__device__ __forceinline__ bool wave_of_block(const uint32_t *tot, const int *classes, int nclasses, uint32_t &first, uint32_t &count, uint32_t &wave)
+{
+    const uint32_t x = blockIdx.x & 7u;
+    uint32_t w = blockIdx.x >> 3, off = 0;
+    int ci = 0;
+    for (int c = 0; c < PC_COUNT; c++) {
+        const uint32_t n = tot[c];
+        if (ci < nclasses && classes[ci] == c) {
+            ci++;
+            const uint32_t nw = (n + 3u) / 4u, w8 = (nw + 7u) / 8u;
+            if (w < w8) {
+                wave = x * w8 + w; first = off; count = n;
+                return wave < nw;
+            }
+            w -= w8;
+        }
+        if (c < PC_BWD) off += n;          // (the backward table is a table of its own)
+    }
+    return false;
+}
+
 // rows 4 w .. 4 w + 3 of the sorted piece table `tab[first .. first + count)` for wave w
-__device__ __forceinline__ Row load_row(const BlendGrid &g, const uint32_t *tab, uint32_t first, uint32_t count)
+__device__ __forceinline__ Row load_row(const BlendGrid &g, const uint32_t *tab, uint32_t first, uint32_t count, uint32_t wave)
 {
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
     Row r;
-    const uint32_t pi = 4u * blockIdx.x + (uint32_t)row;
+    const uint32_t pi = 4u * wave + (uint32_t)row;
     r.on = pi < count;
     const uint32_t desc = r.on ? tab[first + pi] : 0u;
     r.idx = desc >> 4; r.b = (int)(desc & 15u);
@@ -213,7 +243,7 @@ __global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const 
 // covers 64 units x 16 pieces and counts in LDS first: a global counter sees one atomic per block, not one per piece.
 constexpr int PLAN_THREADS = 1024, PLAN_UNITS = PLAN_THREADS / 16;
 
-__device__ __forceinline__ bool plan_piece(const BlendGrid &g, uint32_t &desc, int &cls, int &bk, uint32_t &c)
+__device__ __forceinline__ bool plan_piece(const BlendGrid &g, uint32_t &desc, int &cls, int &reg, int &bk, uint32_t &c)
 {
     const uint32_t idx = blockIdx.x * PLAN_UNITS + (threadIdx.x >> 4);
     const int b = threadIdx.x & 15;
@@ -223,57 +253,65 @@ __device__ __forceinline__ bool plan_piece(const BlendGrid &g, uint32_t &desc, i
     if ((uint64_t)r1.y > g.capacity) return false;
     const uint32_t L = g.scan_out[3];
     c = g.mcount[(size_t)idx * 16 + b];
-    bk = piece_bucket(c, L); cls = piece_class((int)r0.y, (int)r0.z, L);
+    bk = piece_bucket(c, L); cls = piece_class((int)r0.y, (int)r0.z, L); reg = tile_region((int)r0.x, g.gx);
     desc = idx * 16u + (uint32_t)b;
     return true;
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) micro_plan_hist_kernel(BlendGrid g)
 {
-    __shared__ uint32_t h[PC_COUNT * MBUCKETS];
+    __shared__ uint32_t h[WH_KEYS];
     const int tid = threadIdx.x;
-    if (tid < PC_COUNT * MBUCKETS) h[tid] = 0u;
+    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) h[k] = 0u;
     __syncthreads();
-    uint32_t desc, c; int cls, bk;
-    if (plan_piece(g, desc, cls, bk, c)) {
-        atomicAdd(&h[cls * MBUCKETS + bk], 1u);
-        if (c > 0) atomicAdd(&h[PC_BWD * MBUCKETS + bk], 1u);
+    uint32_t desc, c; int cls, reg, bk;
+    if (plan_piece(g, desc, cls, reg, bk, c)) {
+        atomicAdd(&h[(cls * MREGIONS + reg) * MBUCKETS + bk], 1u);
+        if (c > 0) atomicAdd(&h[(PC_BWD * MREGIONS + reg) * MBUCKETS + bk], 1u);
     }
     __syncthreads();
-    if (tid < PC_COUNT * MBUCKETS && h[tid]) atomicAdd(&g.whist[tid], h[tid]);
+    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS)
+        if (h[k]) atomicAdd(&g.whist[k], h[k]);
 }
 
 __global__ void __launch_bounds__(PLAN_THREADS) micro_plan_scatter_kernel(BlendGrid g)
 {
-    __shared__ uint32_t h[PC_COUNT * MBUCKETS];          // pieces of this block per (class, bucket); then the block's first slot
-    __shared__ uint32_t base[PC_COUNT * MBUCKETS];
+    __shared__ uint32_t h[WH_KEYS];          // pieces of this block per (class, region, bucket); then the block's first slot
+    __shared__ uint32_t base[WH_KEYS];       // first table slot of every key
     __shared__ uint32_t total[PC_COUNT];
     const int tid = threadIdx.x;
-    if (tid < PC_COUNT * MBUCKETS) h[tid] = 0u;
-    if (tid < PC_COUNT) {          // first table slot of every (class, bucket): heaviest bucket first
+    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) { h[k] = 0u; base[k] = g.whist[k]; }
+    __syncthreads();
+    if (tid < PC_COUNT) {          // table order: class | region | heaviest bucket first (one thread per class: 264 counters in LDS)
         uint32_t run = 0;
-        for (int k = MBUCKETS - 1; k >= 0; k--) { base[tid * MBUCKETS + k] = run; run += g.whist[tid * MBUCKETS + k]; }
+        for (int r = 0; r < MREGIONS; r++)
+            for (int k = MBUCKETS - 1; k >= 0; k--) {
+                const int key = (tid * MREGIONS + r) * MBUCKETS + k;
+                const uint32_t n = base[key];
+                base[key] = run; run += n;
+            }
         total[tid] = run;
     }
     __syncthreads();
     if (blockIdx.x == 0 && tid < PC_COUNT) g.whist[WH_TOTAL + tid] = total[tid];
-    uint32_t desc = 0, c = 0, rank = 0, rank_b = 0; int cls = 0, bk = 0;
-    const bool on = plan_piece(g, desc, cls, bk, c);
+    uint32_t desc = 0, c = 0, rank = 0, rank_b = 0; int cls = 0, reg = 0, bk = 0;
+    const bool on = plan_piece(g, desc, cls, reg, bk, c);
+    const int key = (cls * MREGIONS + reg) * MBUCKETS + bk, key_b = (PC_BWD * MREGIONS + reg) * MBUCKETS + bk;
     if (on) {
-        rank = atomicAdd(&h[cls * MBUCKETS + bk], 1u);
-        if (c > 0) rank_b = atomicAdd(&h[PC_BWD * MBUCKETS + bk], 1u);
+        rank = atomicAdd(&h[key], 1u);
+        if (c > 0) rank_b = atomicAdd(&h[key_b], 1u);
     }
     __syncthreads();
-    if (tid < PC_COUNT * MBUCKETS) {
-        const uint32_t n = h[tid];
-        h[tid] = n ? atomicAdd(&g.whist[WH_CURSOR + tid], n) : 0u;
+    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) {
+        const uint32_t n = h[k];
+        h[k] = n ? atomicAdd(&g.whist[WH_CURSOR + k], n) : 0u;
     }
     __syncthreads();
     if (!on) return;
     uint32_t off = 0;
     for (int k = 0; k < cls; k++) off += total[k];
-    g.wtab_fwd[off + base[cls * MBUCKETS + bk] + h[cls * MBUCKETS + bk] + rank] = desc;
-    if (c > 0) g.wtab_bwd[base[PC_BWD * MBUCKETS + bk] + h[PC_BWD * MBUCKETS + bk] + rank_b] = desc;
+    g.wtab_fwd[off + base[key] + h[key] + rank] = desc;
+    if (c > 0) g.wtab_bwd[base[key_b] + h[key_b] + rank_b] = desc;
 }
 
 // ------------------------------------------------------------------------------------ queue
@@ -398,12 +436,10 @@ template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const uint32_t *tot = g.whist + WH_TOTAL;
-    const uint32_t nA = tot[PC_FIRST], nB0 = tot[PC_MID_EARLY], nB1 = tot[PC_MID_LATE];
-    const uint32_t first = phase == 1 ? nA + nB0 : 0u;
-    const uint32_t count = phase == 1 ? nB1 : (phase == 0 ? nA + nB0 : nA + nB0 + nB1);
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count);
+    const int all[3] = {PC_FIRST, PC_MID_EARLY, PC_MID_LATE}, late[1] = {PC_MID_LATE};
+    uint32_t first, count, wave;
+    if (!wave_of_block(g.whist + WH_TOTAL, phase == 1 ? late : all, phase == 1 ? 1 : (phase == 0 ? 2 : 3), first, count, wave)) return;
+    const Row r = load_row(g, g.wtab_fwd, first, count, wave);
     const bool exact = r.on && r.seg == 0, product = r.on && r.seg > 0;
     micro_walk<NE>(g, o, r, recs, exact, product, phase);
 }
@@ -413,10 +449,10 @@ template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const uint32_t *tot = g.whist + WH_TOTAL;
-    const uint32_t first = tot[PC_FIRST], count = tot[PC_MID_EARLY] + tot[PC_MID_LATE] + tot[PC_LAST];
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count);
+    const int later[3] = {PC_MID_EARLY, PC_MID_LATE, PC_LAST};
+    uint32_t first, count, wave;
+    if (!wave_of_block(g.whist + WH_TOTAL, later, 3, first, count, wave)) return;
+    const Row r = load_row(g, g.wtab_fwd, first, count, wave);
     micro_walk<NE>(g, o, r, recs, r.on, false, -1);
 }
 
@@ -514,9 +550,10 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     __shared__ SplatRec recs[QSLOTS];
     __shared__ uint32_t ids[2][QSLOTS];                 // ids of the batch being walked / of the batch whose sums await their atomics
     __shared__ float ystash[16][40];                    // the reduced sums of one batch: [trip][row * 10 + field lane]
-    const uint32_t count = g.whist[WH_TOTAL + PC_BWD];
-    if (4u * blockIdx.x >= count) return;
-    const Row r = load_row(g, g.wtab_bwd, 0u, count);
+    const int bwd_class[1] = {PC_BWD};
+    uint32_t first, count, wave;
+    if (!wave_of_block(g.whist + WH_TOTAL, bwd_class, 1, first, count, wave)) return;
+    const Row r = load_row(g, g.wtab_bwd, 0u, count, wave);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
     const float xf = (float)r.xi, yf = (float)r.yi;
     const size_t HW = (size_t)g.W * g.H;
@@ -681,14 +718,14 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
     if (deep) {     // deep scene: first + early middle segments, tile-dead check, then the late middle segments of live tiles
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 0));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, micro_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, -1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, -1));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_head");
-    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<4u * blocks, WAVE, 0, stream>>>(g, o));
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, micro_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_finalize");
@@ -702,15 +739,15 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
     if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a)));
     } else if (fault_mode() >= 9 && fault_mode() <= 11 && !invd) {      // timing experiments (wrong results): no atomics / L2-resident records
         auto kern = fault_mode() == 9 ? micro_bwd_kernel<false, 2, 9> : fault_mode() == 10 ? micro_bwd_kernel<false, 2, 10> : micro_bwd_kernel<false, 2, 11>;
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_bwd");
     return GMS_OK;

@@ -114,9 +114,9 @@ struct BinningState {
     // segments), the backward table holds the non-empty pieces.  Entry = unit index * 16 + block.
     uint32_t *wtab_fwd;    // [units * 16]
     uint32_t *wtab_bwd;    // [units * 16]
-    uint32_t *whist;       // [2][MICRO_CLASSES][MICRO_BUCKETS] histogram, then cursors; [16] totals per class
-    static constexpr size_t MICRO_CLASSES = 5, MICRO_BUCKETS = 33;
-    static __host__ __device__ size_t whist_words() { return 2 * MICRO_CLASSES * MICRO_BUCKETS + 16; }
+    uint32_t *whist;       // [2][MICRO_CLASSES][MICRO_REGIONS][MICRO_BUCKETS] histogram, then cursors; [16] totals per class
+    static constexpr size_t MICRO_CLASSES = 5, MICRO_REGIONS = 8, MICRO_BUCKETS = 33;
+    static __host__ __device__ size_t whist_words() { return 2 * MICRO_CLASSES * MICRO_REGIONS * MICRO_BUCKETS + 16; }
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
     static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 1024 + T + 2; }
