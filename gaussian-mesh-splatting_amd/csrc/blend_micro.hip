@@ -68,7 +68,7 @@ struct Row {
 // Which wave of which class of a piece table block `blockIdx.x` walks.  The blocks of XCD x (= blockIdx % 8, how the
 // dispatcher deals them) take the x-th eighth of every class: the table is sorted by (class, region, length), so that eighth
 // is region x's pieces up to the imbalance between regions -- the records a wave gathers are in its own XCD's L2.
-__device__ __forceinline__ bool wave_of_block(const uint32_t *tot, const int *classes, int nclasses, uint32_t &first, uint32_t &count, uint32_t &wave)
+__device__ __forceinline__ bool wave_of_block(const BlendGrid &g, const uint32_t *tot, const int *classes, int nclasses, uint32_t &first, uint32_t &count, uint32_t &wave)
 {
     const uint32_t x = blockIdx.x & 7u;
     uint32_t w = blockIdx.x >> 3, off = 0;
@@ -79,7 +79,8 @@ __device__ __forceinline__ bool wave_of_block(const uint32_t *tot, const int *cl
             ci++;
             const uint32_t nw = (n + 3u) / 4u, w8 = (nw + 7u) / 8u;
             if (w < w8) {
-                wave = x * w8 + w; first = off; count = n;
+                wave = (g.dbg & 0x10000u) ? x * w8 + w : w * 8u + x;      // regions on: XCD x walks the x-th eighth; off: interleaved
+                first = off; count = n;
                 return wave < nw;
             }
             w -= w8;
@@ -253,7 +254,7 @@ __device__ __forceinline__ bool plan_piece(const BlendGrid &g, uint32_t &desc, i
     if ((uint64_t)r1.y > g.capacity) return false;
     const uint32_t L = g.scan_out[3];
     c = g.mcount[(size_t)idx * 16 + b];
-    bk = piece_bucket(c, L); cls = piece_class((int)r0.y, (int)r0.z, L); reg = tile_region((int)r0.x, g.gx);
+    bk = piece_bucket(c, L); cls = piece_class((int)r0.y, (int)r0.z, L); reg = (g.dbg & 0x10000u) ? tile_region((int)r0.x, g.gx) : 0;
     desc = idx * 16u + (uint32_t)b;
     return true;
 }
@@ -438,7 +439,7 @@ __global__ void __launch_bounds__(WAVE) micro_head_kernel(BlendGrid g, BlendFwdO
     __shared__ SplatRec recs[QSLOTS];
     const int all[3] = {PC_FIRST, PC_MID_EARLY, PC_MID_LATE}, late[1] = {PC_MID_LATE};
     uint32_t first, count, wave;
-    if (!wave_of_block(g.whist + WH_TOTAL, phase == 1 ? late : all, phase == 1 ? 1 : (phase == 0 ? 2 : 3), first, count, wave)) return;
+    if (!wave_of_block(g, g.whist + WH_TOTAL, phase == 1 ? late : all, phase == 1 ? 1 : (phase == 0 ? 2 : 3), first, count, wave)) return;
     const Row r = load_row(g, g.wtab_fwd, first, count, wave);
     const bool exact = r.on && r.seg == 0, product = r.on && r.seg > 0;
     micro_walk<NE>(g, o, r, recs, exact, product, phase);
@@ -451,7 +452,7 @@ __global__ void __launch_bounds__(WAVE) micro_fwd_kernel(BlendGrid g, BlendFwdOu
     __shared__ SplatRec recs[QSLOTS];
     const int later[3] = {PC_MID_EARLY, PC_MID_LATE, PC_LAST};
     uint32_t first, count, wave;
-    if (!wave_of_block(g.whist + WH_TOTAL, later, 3, first, count, wave)) return;
+    if (!wave_of_block(g, g.whist + WH_TOTAL, later, 3, first, count, wave)) return;
     const Row r = load_row(g, g.wtab_fwd, first, count, wave);
     micro_walk<NE>(g, o, r, recs, r.on, false, -1);
 }
@@ -552,7 +553,7 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     __shared__ float ystash[16][40];                    // the reduced sums of one batch: [trip][row * 10 + field lane]
     const int bwd_class[1] = {PC_BWD};
     uint32_t first, count, wave;
-    if (!wave_of_block(g.whist + WH_TOTAL, bwd_class, 1, first, count, wave)) return;
+    if (!wave_of_block(g, g.whist + WH_TOTAL, bwd_class, 1, first, count, wave)) return;
     const Row r = load_row(g, g.wtab_bwd, 0u, count, wave);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
     const float xf = (float)r.xi, yf = (float)r.yi;
@@ -654,6 +655,10 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
                 const float y = ystash[t][sslot];
                 // a row with no active pixel for this entry summed exact zeros: nothing to add (and its id may be stale)
                 if (FAULT == 9 || FAULT == 11) { if (y == 123.456f) a.accum[0] = y; }            // (timing experiments: no atomics)
+                else if (FAULT == 12) {      // timing experiment: every XCD adds into cache lines no other XCD touches
+                    const uint32_t id = ids[b][row * QROW + t];
+                    if (y != 0.f) unsafeAtomicAdd(abase + (size_t)(((id >> 4) << 4) | ((blockIdx.x & 7u) << 1) | (id & 1u)) * GRAD_STRIDE, y);
+                }
                 else if (y != 0.f) unsafeAtomicAdd(abase + (size_t)ids[b][row * QROW + t] * GRAD_STRIDE, y);
             }
         }
@@ -700,8 +705,17 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
 }
 
 // ------------------------------------------------------------------------------------ host
-int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+static uint32_t micro_flags()
 {
+    static int f = -1;
+    if (f < 0) { const char *e = getenv("GMS_MICRO_REGIONS"); f = (e && atoi(e) != 0) ? 0x10000 : 0; }
+    return (uint32_t)f;
+}
+
+int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+{
+    BlendGrid g = g_in;
+    g.dbg |= micro_flags();
     static int deep_env = -2;
     if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
     const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;
@@ -732,16 +746,19 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     return GMS_OK;
 }
 
-int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    BlendGrid g = g_in;
+    g.dbg |= micro_flags();
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
     if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a)));
-    } else if (fault_mode() >= 9 && fault_mode() <= 11 && !invd) {      // timing experiments (wrong results): no atomics / L2-resident records
-        auto kern = fault_mode() == 9 ? micro_bwd_kernel<false, 2, 9> : fault_mode() == 10 ? micro_bwd_kernel<false, 2, 10> : micro_bwd_kernel<false, 2, 11>;
+    } else if (fault_mode() >= 9 && fault_mode() <= 12 && !invd) {      // timing experiments (wrong results): no atomics / L2-resident records / XCD-private atomics
+        auto kern = fault_mode() == 9 ? micro_bwd_kernel<false, 2, 9> : fault_mode() == 10 ? micro_bwd_kernel<false, 2, 10>
+                  : fault_mode() == 11 ? micro_bwd_kernel<false, 2, 11> : micro_bwd_kernel<false, 2, 12>;
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
