@@ -31,87 +31,23 @@ namespace gms {
 constexpr int QROW = 17;          // LDS queue slots per row (16 used): 17 x 12 dwords staggers the four rows over the banks
 constexpr int QSLOTS = 4 * QROW;
 
-// Piece classes (which launches walk a (unit, block) piece) and the length buckets of the counting sort
-enum { PC_FIRST = 0, PC_MID_EARLY, PC_MID_LATE, PC_LAST, PC_BWD, PC_COUNT };
-constexpr int MBUCKETS = (int)BinningState::MICRO_BUCKETS;
-static_assert(PC_COUNT == (int)BinningState::MICRO_CLASSES, "piece classes");
-constexpr int MREGIONS = (int)BinningState::MICRO_REGIONS;
-constexpr int WH_KEYS = PC_COUNT * MREGIONS * MBUCKETS;          // counters per histogram: (class, region, bucket)
-constexpr int WH_CURSOR = WH_KEYS, WH_TOTAL = 2 * WH_KEYS;
-// Spatial region of a tile = the XCD whose L2 should hold its splat records: 2x2-tile cells (32 px) dealt to the eight XCDs
-// in a skewed pattern.  A cell's Gaussians are shared with its neighbours only along the ~5 px halo, so an XCD gathers about
-// 1.3 / 8 of the scene's records (~2.4 MB at 300 k Gaussians: inside its 4 MB L2) instead of all of them.
-__device__ __forceinline__ int tile_region(int tile, int gx) { const int tx = tile % gx, ty = tile / gx; return ((tx >> 1) + 3 * (ty >> 1)) & 7; }
-__device__ __forceinline__ int piece_bucket(uint32_t count, uint32_t L) { return (int)min(32u, (count * 32u + L - 1u) / L); }
-__device__ __forceinline__ int piece_class(int seg, int nseg, uint32_t L)
-{
-    if (seg == 0) return PC_FIRST;
-    if (seg == nseg - 1) return PC_LAST;
-    return seg < tloc_head(L) ? PC_MID_EARLY : PC_MID_LATE;
-}
-
-// pixel `li` of 4x4 block `b` of a tile; index of the pixel in the per-(unit, pixel) segment state = b * 16 + li
-__device__ __forceinline__ void block_pixel(int tx, int ty, int b, int li, int &xi, int &yi)
-{
-    xi = tx * TILE + (b & 3) * 4 + (li & 3);
-    yi = ty * TILE + (b >> 2) * 4 + (li >> 2);
-}
-
-// One row (16 lanes) of a wave = one (unit, block) piece; all fields are uniform across the row's lanes.
-struct Row {
-    bool on;               // the row has a piece
-    int b, tile, seg, nseg, xi, yi, tid; bool inside;
-    uint32_t idx, slot0, beg, cn, cnt, L;
-    const uint32_t *ml;    // the piece's ids
+struct MPix {
+    int xi, yi, tid, b; bool inside; float xf, yf;
 };
 
-// Which wave of which class of a piece table block `blockIdx.x` walks.  The blocks of XCD x (= blockIdx % 8, how the
-// dispatcher deals them) take the x-th eighth of every class: the table is sorted by (class, region, length), so that eighth
-// is region x's pieces up to the imbalance between regions -- the records a wave gathers are in its own XCD's L2.
-__device__ __forceinline__ bool wave_of_block(const BlendGrid &g, const uint32_t *tot, const int *classes, int nclasses, uint32_t &first, uint32_t &count, uint32_t &wave)
+// wave q of a unit = the tile's 8x8 quadrant q; row r of the wave = block r of the quadrant; lane i of the row = pixel i
+__device__ __forceinline__ MPix micro_pixel(const BlendGrid &g, int tx, int ty, int q, int lane)
 {
-    const uint32_t x = blockIdx.x & 7u;
-    uint32_t w = blockIdx.x >> 3, off = 0;
-    int ci = 0;
-    for (int c = 0; c < PC_COUNT; c++) {
-        const uint32_t n = tot[c];
-        if (ci < nclasses && classes[ci] == c) {
-            ci++;
-            const uint32_t nw = (n + 3u) / 4u, w8 = (nw + 7u) / 8u;
-            if (w < w8) {
-                wave = (g.dbg & 0x10000u) ? x * w8 + w : w * 8u + x;      // regions on: XCD x walks the x-th eighth; off: interleaved
-                first = off; count = n;
-                return wave < nw;
-            }
-            w -= w8;
-        }
-        if (c < PC_BWD) off += n;          // (the backward table is a table of its own)
-    }
-    return false;
-}
-
-// rows 4 w .. 4 w + 3 of the sorted piece table `tab[first .. first + count)` for wave w
-__device__ __forceinline__ Row load_row(const BlendGrid &g, const uint32_t *tab, uint32_t first, uint32_t count, uint32_t wave)
-{
-    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    Row r;
-    const uint32_t pi = 4u * wave + (uint32_t)row;
-    r.on = pi < count;
-    const uint32_t desc = r.on ? tab[first + pi] : 0u;
-    r.idx = desc >> 4; r.b = (int)(desc & 15u);
-    const uint4 r0 = g.unit_tile[2 * (size_t)r.idx], r1 = g.unit_tile[2 * (size_t)r.idx + 1];
-    r.tile = (int)r0.x; r.seg = (int)r0.y; r.nseg = (int)r0.z; r.slot0 = r0.w;
-    r.L = g.scan_out[3];
-    r.beg = r1.x + (uint32_t)r.seg * r.L;
-    const uint32_t end = min(r1.y, r.beg + r.L);
-    r.cn = end > r.beg ? end - r.beg : 0u;
-    if ((uint64_t)r1.y > g.capacity) r.on = false;          // overflowed optimistic launch: the host re-runs
-    r.cnt = r.on ? g.mcount[(size_t)r.idx * 16 + r.b] : 0u;
-    r.ml = g.mlist + (size_t)16 * r.beg + (size_t)r.b * r.cn;
-    block_pixel(r.tile % g.gx, r.tile / g.gx, r.b, li, r.xi, r.yi);
-    r.inside = r.on && r.xi < g.W && r.yi < g.H;
-    r.tid = r.b * 16 + li;
-    return r;
+    const int row = lane >> 4, li = lane & 15;
+    const int bx = (q & 1) * 2 + (row & 1), by = (q >> 1) * 2 + (row >> 1);
+    MPix p;
+    p.b = by * 4 + bx;
+    p.xi = tx * TILE + bx * 4 + (li & 3);
+    p.yi = ty * TILE + by * 4 + (li >> 2);
+    p.inside = p.xi < g.W && p.yi < g.H;
+    p.xf = (float)p.xi; p.yf = (float)p.yi;
+    p.tid = q * WAVE + lane;          // index of the pixel in the per-(unit, pixel) segment state
+    return p;
 }
 
 __device__ __forceinline__ uint32_t max4rows(uint32_t v)          // v is row-uniform
@@ -235,146 +171,110 @@ __global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const 
     if (tid < 16) g.mcount[(size_t)u.idx * 16 + tid] = running[tid];
 }
 
-// ------------------------------------------------------------------------------------ plan
-// Counting sort of the (unit, block) pieces by list length, heaviest first, one table for the forward launches (classes
-// first | middle early | middle late | last, in this order) and one for the backward (non-empty pieces): four CONSECUTIVE
-// table entries form a wave, so the four rows of a wave walk lists of (nearly) the same length -- 0.58 wave trips per
-// instance instead of the 0.81 the four blocks of one quadrant give -- and waves of equal weight are dispatched heaviest
-// first (no long tail behind a few heavy quadrants).  Two small launches: histogram, scatter.  Each block of 1024 threads
-// covers 64 units x 16 pieces and counts in LDS first: a global counter sees one atomic per block, not one per piece.
-constexpr int PLAN_THREADS = 1024, PLAN_UNITS = PLAN_THREADS / 16;
-
-__device__ __forceinline__ bool plan_piece(const BlendGrid &g, uint32_t &desc, int &cls, int &reg, int &bk, uint32_t &c)
-{
-    const uint32_t idx = blockIdx.x * PLAN_UNITS + (threadIdx.x >> 4);
-    const int b = threadIdx.x & 15;
-    const uint32_t nunits = g.unit_first[g.T];
-    if (idx >= nunits || idx >= g.max_units) return false;
-    const uint4 r0 = g.unit_tile[2 * (size_t)idx], r1 = g.unit_tile[2 * (size_t)idx + 1];
-    if ((uint64_t)r1.y > g.capacity) return false;
-    const uint32_t L = g.scan_out[3];
-    c = g.mcount[(size_t)idx * 16 + b];
-    bk = piece_bucket(c, L); cls = piece_class((int)r0.y, (int)r0.z, L); reg = (g.dbg & 0x10000u) ? tile_region((int)r0.x, g.gx) : 0;
-    desc = idx * 16u + (uint32_t)b;
-    return true;
-}
-
-__global__ void __launch_bounds__(PLAN_THREADS) micro_plan_hist_kernel(BlendGrid g)
-{
-    __shared__ uint32_t h[WH_KEYS];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) h[k] = 0u;
-    __syncthreads();
-    uint32_t desc, c; int cls, reg, bk;
-    if (plan_piece(g, desc, cls, reg, bk, c)) {
-        atomicAdd(&h[(cls * MREGIONS + reg) * MBUCKETS + bk], 1u);
-        if (c > 0) atomicAdd(&h[(PC_BWD * MREGIONS + reg) * MBUCKETS + bk], 1u);
-    }
-    __syncthreads();
-    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS)
-        if (h[k]) atomicAdd(&g.whist[k], h[k]);
-}
-
-__global__ void __launch_bounds__(PLAN_THREADS) micro_plan_scatter_kernel(BlendGrid g)
-{
-    __shared__ uint32_t h[WH_KEYS];          // pieces of this block per (class, region, bucket); then the block's first slot
-    __shared__ uint32_t base[WH_KEYS];       // first table slot of every key
-    __shared__ uint32_t total[PC_COUNT];
-    const int tid = threadIdx.x;
-    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) { h[k] = 0u; base[k] = g.whist[k]; }
-    __syncthreads();
-    if (tid < PC_COUNT) {          // table order: class | region | heaviest bucket first (one thread per class: 264 counters in LDS)
-        uint32_t run = 0;
-        for (int r = 0; r < MREGIONS; r++)
-            for (int k = MBUCKETS - 1; k >= 0; k--) {
-                const int key = (tid * MREGIONS + r) * MBUCKETS + k;
-                const uint32_t n = base[key];
-                base[key] = run; run += n;
-            }
-        total[tid] = run;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && tid < PC_COUNT) g.whist[WH_TOTAL + tid] = total[tid];
-    uint32_t desc = 0, c = 0, rank = 0, rank_b = 0; int cls = 0, reg = 0, bk = 0;
-    const bool on = plan_piece(g, desc, cls, reg, bk, c);
-    const int key = (cls * MREGIONS + reg) * MBUCKETS + bk, key_b = (PC_BWD * MREGIONS + reg) * MBUCKETS + bk;
-    if (on) {
-        rank = atomicAdd(&h[key], 1u);
-        if (c > 0) rank_b = atomicAdd(&h[key_b], 1u);
-    }
-    __syncthreads();
-    for (int k = tid; k < WH_KEYS; k += PLAN_THREADS) {
-        const uint32_t n = h[k];
-        h[k] = n ? atomicAdd(&g.whist[WH_CURSOR + k], n) : 0u;
-    }
-    __syncthreads();
-    if (!on) return;
-    uint32_t off = 0;
-    for (int k = 0; k < cls; k++) off += total[k];
-    g.wtab_fwd[off + base[key] + h[key] + rank] = desc;
-    if (c > 0) g.wtab_bwd[base[key_b] + h[key_b] + rank_b] = desc;
-}
-
 // ------------------------------------------------------------------------------------ queue
 // Each row keeps 16 entries of its own list in LDS; lane i of row r gathers entry j0 + i of the row's list.
-__device__ __forceinline__ SplatRec zero_rec()
-{
-    SplatRec z;
-    z.q0 = make_float4(0.f, 0.f, 0.f, 0.f); z.q1 = z.q0; z.q2 = z.q0;
-    return z;
-}
 __device__ __forceinline__ void queue_clear(SplatRec *recs)
 {
     const int lane = threadIdx.x & 63;
-    const SplatRec z = zero_rec();
+    SplatRec z;
+    z.q0 = make_float4(0.f, 0.f, 0.f, 0.f); z.q1 = z.q0; z.q2 = z.q0;
     recs[lane] = z;
     if (lane < QSLOTS - WAVE) recs[WAVE + lane] = z;
 }
 
-// ------------------------------------------------------------------------------------ fwd
-// Front-to-back walk of the four rows' lists.  A row is either EXACT (reference skip / stop tests from the true prefix
-// transmittance; its end state is written as image pixels for a single-segment tile, else as the segment's partials) or a
-// PRODUCT (a middle segment's prod(1 - alpha) without termination: the prefix of the segments behind it), chosen per row.
+// ------------------------------------------------------------------------------------ tloc
 template <int NE>
-__device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut &o, const Row &r, SplatRec *recs, bool exact, bool product, int phase)
+__device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase, int q)
+{
+    if (u.nseg == 1 || u.seg == u.nseg - 1) return;
+    if (phase >= 0 && (u.seg < tloc_head(u.L)) != (phase == 0)) return;     // phase -1: every segment in one launch
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    float *dst = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
+    if (phase == 1 && g.tile_dead[u.tile]) { *dst = 0.f; return; }
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
+    const uint32_t maxcnt = max4rows(cnt);
+    queue_clear(recs);
+    float Tl = 1.f;
+    for (uint32_t j0 = 0; j0 < maxcnt; j0 += 16) {
+        // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
+        if (__all(Tl < T_MIN || !p.inside || j0 >= cnt)) break;
+        wave_sync();
+        if (j0 + li < cnt) recs[row * QROW + li] = rec[ml[j0 + li]];
+        wave_sync();
+        const int nt = (int)min(16u, maxcnt - j0);
+        for (int t = 0; t < nt; t += NE) {
+            float al[NE], pw[NE]; bool val[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                const SplatRec *s = recs + row * QROW + t + e;
+                const float4 r0 = s->q0, r1 = s->q1;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+                val[e] = j0 + t + e < cnt;
+                pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
+                al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+                if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
+        }
+    }
+    *dst = Tl;
+}
+
+// tile_dead[t] = 1 when the product of the first tloc_head(L) segment transmittances is < 1e-4 for every pixel
+__global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
+{
+    const int tile = blockIdx.x;
+    const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
+    const int nhead = tloc_head(g.scan_out[3]);
+    if (nseg <= nhead + 1) return;                 // no phase-1 segment exists (the last one needs no product)
+    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
+    const int tid = threadIdx.x;
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
+    const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
+    float T = 1.f;
+    for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
+    const int dead = __syncthreads_and(T < T_MIN || !p.inside);
+    if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
+}
+
+// ------------------------------------------------------------------------------------ fwd
+template <int NE>
+__device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs, int q)
 {
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const float xf = (float)r.xi, yf = (float)r.yi;
-    float *st = g.seg_state + (size_t)(r.slot0 + (uint32_t)r.seg) * SEG_FLOATS;
-    bool skip = !(exact || product);
-    if (product && phase == 1 && g.tile_dead[r.tile]) { st[SEG_TLOC * TILE_PIX + r.tid] = 0.f; skip = true; }   // products are irrelevant
-    const uint32_t cnt = skip ? 0u : r.cnt;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
     const uint32_t maxcnt = max4rows(cnt);
-    const uint32_t posbase = (uint32_t)r.seg * r.L;
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
 
     float T = 1.f;
-    if (exact && r.seg > 0) {
+    {
         // prefix product of the segments in front, four independent loads per step (same left-to-right order)
-        const float *tl = g.seg_state + (size_t)r.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + r.tid;
+        const float *tl = g.seg_state + (size_t)u.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
         int k = 0;
-        for (; k + 4 <= r.seg; k += 4) {
+        for (; k + 4 <= u.seg; k += 4) {
             const float t0 = tl[(size_t)k * SEG_FLOATS], t1 = tl[(size_t)(k + 1) * SEG_FLOATS];
             const float t2 = tl[(size_t)(k + 2) * SEG_FLOATS], t3 = tl[(size_t)(k + 3) * SEG_FLOATS];
             T = T * t0 * t1 * t2 * t3;
         }
-        for (; k < r.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
+        for (; k < u.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
     }
-    const bool dead_on_entry = T < T_MIN;          // only possible for an exact row with seg > 0
+    const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = skip || !r.inside || dead_on_entry;
+    bool done = !p.inside || dead_on_entry;
     queue_clear(recs);
-    // software-pipelined queue fill: the records of batch k+1 and the ids of batch k+2 are in flight while batch k is walked
-    SplatRec R = zero_rec();
-    uint32_t id2 = 16u + li < cnt ? r.ml[16u + li] : 0u;
-    if ((uint32_t)li < cnt) R = o.rec[r.ml[li]];
 
     for (uint32_t j0 = 0; j0 < maxcnt; j0 += 16) {
         if (__all(done || j0 >= cnt)) break;
         wave_sync();
-        if (j0 + li < cnt) recs[row * QROW + li] = R;
-        if (j0 + 16u + li < cnt) R = o.rec[id2];
-        id2 = j0 + 32u + li < cnt ? r.ml[j0 + 32u + li] : 0u;
+        if (j0 + li < cnt) recs[row * QROW + li] = o.rec[ml[j0 + li]];
         wave_sync();
         const int nt = (int)min(16u, maxcnt - j0);
         for (int t = 0; t < nt; t += NE) {
@@ -385,7 +285,7 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
                 const SplatRec *s = recs + row * QROW + t + e;
                 const float4 r0 = s->q0;
                 r1[e] = s->q1; r2[e] = s->q2;
-                const float dx = r0.x - xf, dy = r0.y - yf;
+                const float dx = r0.x - p.xf, dy = r0.y - p.yf;
                 val[e] = j0 + t + e < cnt;
                 pw[e] = pair_power(r0.z, r0.w, r1[e].x, dx, dy);
                 al[e] = fminf(ALPHA_MAX, r1[e].y * __expf(pw[e]));
@@ -394,25 +294,21 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
             for (int e = 0; e < NE; e++) {
                 bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
                 const float testT = T * (1.f - al[e]);
-                if (act && exact && testT < T_MIN) { done = true; act = false; }       // the reference's stop rule
+                if (act && testT < T_MIN) { done = true; act = false; }
                 if (act) {
                     const float w = al[e] * T;
                     C0 += r1[e].z * w; C1 += r1[e].w * w; C2 += r2[e].x * w;
                     Dp += r2[e].y * w;
                     T = testT;
                     last = posbase + j0 + (uint32_t)(t + e) + 1u;
-                    // a product below 1e-4: every later segment starts dead whatever the exact value
-                    if (!exact && T < T_MIN) done = true;
                 }
             }
             if (__all(done || j0 + t + NE >= cnt)) break;
         }
     }
-    if (skip || !r.on) return;
-    if (product) { st[SEG_TLOC * TILE_PIX + r.tid] = T; return; }
-    if (r.nseg == 1) {
-        if (r.inside) {
-            const size_t pid = (size_t)r.yi * g.W + r.xi, HW = (size_t)g.W * g.H;
+    if (u.nseg == 1) {
+        if (p.inside) {
+            const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
             o.final_T[pid] = T;
             o.n_contrib[pid] = last;
             o.out_color[pid] = C0 + T * o.bg[0];
@@ -421,58 +317,37 @@ __device__ __forceinline__ void micro_walk(const BlendGrid &g, const BlendFwdOut
             o.out_invdepth[pid] = Dp;
         }
     } else {
-        st[SEG_C0 * TILE_PIX + r.tid] = C0; st[SEG_C1 * TILE_PIX + r.tid] = C1; st[SEG_C2 * TILE_PIX + r.tid] = C2;
-        st[SEG_D * TILE_PIX + r.tid] = Dp;
-        st[SEG_TEND * TILE_PIX + r.tid] = dead_on_entry ? -1.f : T;
-        st[SEG_LAST * TILE_PIX + r.tid] = __uint_as_float(last);
+        float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        st[SEG_C0 * TILE_PIX + p.tid] = C0; st[SEG_C1 * TILE_PIX + p.tid] = C1; st[SEG_C2 * TILE_PIX + p.tid] = C2;
+        st[SEG_D * TILE_PIX + p.tid] = Dp;
+        st[SEG_TEND * TILE_PIX + p.tid] = dead_on_entry ? -1.f : T;
+        st[SEG_LAST * TILE_PIX + p.tid] = __uint_as_float(last);
         // the first segment's exact walk doubles as its transmittance product (see blend.hip)
-        if (r.seg == 0) st[SEG_TLOC * TILE_PIX + r.tid] = done ? 0.f : T;
+        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + p.tid] = done ? 0.f : T;
     }
 }
 
-// First launch(es): every piece that depends on nothing -- first segments exactly, middle segments as products.
-// phase -1: all of them; phase 0: first + early middle segments; phase 1: the late middle segments (deep scenes: after the
-// tile-dead check).  The class ranges of the forward table are contiguous in exactly this order.
 template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const int all[3] = {PC_FIRST, PC_MID_EARLY, PC_MID_LATE}, late[1] = {PC_MID_LATE};
-    uint32_t first, count, wave;
-    if (!wave_of_block(g, g.whist + WH_TOTAL, phase == 1 ? late : all, phase == 1 ? 1 : (phase == 0 ? 2 : 3), first, count, wave)) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count, wave);
-    const bool exact = r.on && r.seg == 0, product = r.on && r.seg > 0;
-    micro_walk<NE>(g, o, r, recs, exact, product, phase);
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;            // the four quadrant waves of a unit are consecutive blocks of one XCD
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    const int q = (int)(bs & 3u);
+    if (u.seg == 0) { if (phase <= 0) micro_fwd_unit<NE>(g, o, u, recs, q); }
+    else micro_tloc_unit<NE>(g, o.rec, u, recs, phase, q);
 }
 
-// Second launch: segments 1.. of the multi-segment tiles, exactly, from the prefix product of the segments in front.
 template <int NE>
 __global__ void __launch_bounds__(WAVE) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
     __shared__ SplatRec recs[QSLOTS];
-    const int later[3] = {PC_MID_EARLY, PC_MID_LATE, PC_LAST};
-    uint32_t first, count, wave;
-    if (!wave_of_block(g, g.whist + WH_TOTAL, later, 3, first, count, wave)) return;
-    const Row r = load_row(g, g.wtab_fwd, first, count, wave);
-    micro_walk<NE>(g, o, r, recs, r.on, false, -1);
-}
-
-// tile_dead[t] = 1 when the product of the first tloc_head(L) segment transmittances is < 1e-4 for every pixel
-__global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
-{
-    const int tile = blockIdx.x;
-    const int nseg = (int)(g.unit_first[tile + 1] - g.unit_first[tile]);
-    const int nhead = tloc_head(g.scan_out[3]);
-    if (nseg <= nhead + 1) return;                 // no late middle segment exists (the last one needs no product)
-    if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
-    const int tid = threadIdx.x;
-    int xi, yi;
-    block_pixel(tile % g.gx, tile / g.gx, tid >> 4, tid & 15, xi, yi);
-    const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
-    float T = 1.f;
-    for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
-    const int dead = __syncthreads_and(T < T_MIN || xi >= g.W || yi >= g.H);
-    if (tid == 0) g.tile_dead[tile] = dead ? 1u : 0u;
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (u.seg == 0) return;
+    micro_fwd_unit<NE>(g, o, u, recs, (int)(bs & 3u));
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -484,8 +359,7 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
     if (nseg <= 1) return;
     if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
     const int tid = threadIdx.x;
-    int xi, yi;
-    block_pixel(tile % g.gx, tile / g.gx, tid >> 4, tid & 15, xi, yi);
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
     float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
     uint32_t last = 0;
@@ -507,8 +381,8 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
             }
         }
     }
-    if (xi < g.W && yi < g.H) {
-        const size_t pid = (size_t)yi * g.W + xi, HW = (size_t)g.W * g.H;
+    if (p.inside) {
+        const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
         o.final_T[pid] = T;
         o.n_contrib[pid] = last;
         o.out_color[pid] = C0 + T * o.bg[0];
@@ -549,69 +423,62 @@ template <bool INVD, int NE, int FAULT>
 __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     __shared__ SplatRec recs[QSLOTS];
-    __shared__ uint32_t ids[2][QSLOTS];                 // ids of the batch being walked / of the batch whose sums await their atomics
-    __shared__ float ystash[16][40];                    // the reduced sums of one batch: [trip][row * 10 + field lane]
-    const int bwd_class[1] = {PC_BWD};
-    uint32_t first, count, wave;
-    if (!wave_of_block(g, g.whist + WH_TOTAL, bwd_class, 1, first, count, wave)) return;
-    const Row r = load_row(g, g.wtab_bwd, 0u, count, wave);
+    __shared__ uint32_t ids[QSLOTS];
+    Unit u;
+    const uint32_t bs = blockIdx.x >> 3;
+    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (u.end <= u.beg) return;
+    const int q = (int)(bs & 3u);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const float xf = (float)r.xi, yf = (float)r.yi;
+    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
     const size_t HW = (size_t)g.W * g.H;
-    const size_t pid = (size_t)r.yi * g.W + r.xi;
-    const float Tfinal = r.inside ? a.final_T[pid] : 0.f;
-    const uint32_t last = r.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
+    const size_t pid = (size_t)p.yi * g.W + p.xi;
+    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
+    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
     float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
-    if (r.inside) {
+    if (p.inside) {
         dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
         if (INVD) dinvd = a.dL_dinvd[pid];
     }
     const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
-    const uint32_t posbase = (uint32_t)r.seg * r.L;
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
+    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
     // entries [0, lrel) of this block's list of this segment were composited by this pixel
-    const uint32_t lrel = last > posbase ? min(last - posbase, r.cnt) : 0u;
+    const uint32_t lrel = last > posbase ? min(last - posbase, cnt) : 0u;
     uint32_t top = lrel;                                    // furthest entry any pixel of the row composited
     top = max(top, (uint32_t)__shfl_xor((int)top, 8)); top = max(top, (uint32_t)__shfl_xor((int)top, 4));
     top = max(top, (uint32_t)__shfl_xor((int)top, 2)); top = max(top, (uint32_t)__shfl_xor((int)top, 1));
     const uint32_t maxtop = max4rows(top);
     if (maxtop == 0) return;
-    // software-pipelined queue fill (see the loop below); batch 0's ids and records start travelling here, behind the
-    // segment-restart loads that follow
-    uint32_t idc = (uint32_t)li < top ? r.ml[top - 1u - (uint32_t)li] : 0u;             // id of this lane's entry of the current batch
-    uint32_t id2 = 16u + li < top ? r.ml[top - 1u - (16u + li)] : 0u;                    // ... of the next batch
-    SplatRec R = zero_rec();
-    if ((uint32_t)li < top) R = a.rec[(FAULT == 10 || FAULT == 11) ? (idc & 1023u) : idc];
 
     BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
-    {
-        // restart of the recurrence at the segment boundary: T after this segment's last applied splat and the colour
-        // composited behind it (sum of the live partials of the later segments) divided by that T.  Rows of single-segment
-        // tiles (and rows that are off) keep (Tfinal, 0).
-        const bool multi = r.on && r.nseg > 1 && top > 0;
-        const float te = multi ? g.seg_state[(size_t)(r.slot0 + (uint32_t)r.seg) * SEG_FLOATS + SEG_TEND * TILE_PIX + r.tid] : 0.f;
-        const bool restart = multi && te > 0.f;
-        float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
-        bool stop = !restart;
-        for (int k0 = r.seg + 1; ; k0 += 4) {
-            if (k0 >= r.nseg) stop = true;
-            if (__all(stop)) break;
-            float tk[4], c0[4], c1[4], c2[4], dd[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float *sk = g.seg_state + (size_t)(r.slot0 + (uint32_t)max(0, min(k0 + j, r.nseg - 1))) * SEG_FLOATS;
-                tk[j] = stop ? -1.f : sk[SEG_TEND * TILE_PIX + r.tid]; c0[j] = stop ? 0.f : sk[SEG_C0 * TILE_PIX + r.tid];
-                c1[j] = stop ? 0.f : sk[SEG_C1 * TILE_PIX + r.tid]; c2[j] = stop ? 0.f : sk[SEG_C2 * TILE_PIX + r.tid];
-                dd[j] = (INVD && !stop) ? sk[SEG_D * TILE_PIX + r.tid] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // a pixel that is dead on entry to segment k is dead for every later one: stop at the first
-                if (k0 + j >= r.nseg || tk[j] < 0.f) stop = true;
-                if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
-            }
-        }
-        if (restart) {
+    if (u.nseg > 1) {
+        const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        const float te = st[SEG_TEND * TILE_PIX + p.tid];
+        if (te > 0.f) {
+            // restart of the recurrence at the segment boundary: T after this segment's last applied splat and the colour
+            // composited behind it (sum of the live partials of the later segments) divided by that T
             st8.T = te;
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
+            bool stop = false;
+            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += 4) {
+                float tk[4], c0[4], c1[4], c2[4], dd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float *sk = g.seg_state + (size_t)(u.slot0 + min(k0 + j, u.nseg - 1)) * SEG_FLOATS;
+                    tk[j] = sk[SEG_TEND * TILE_PIX + p.tid]; c0[j] = sk[SEG_C0 * TILE_PIX + p.tid];
+                    c1[j] = sk[SEG_C1 * TILE_PIX + p.tid]; c2[j] = sk[SEG_C2 * TILE_PIX + p.tid];
+                    dd[j] = INVD ? sk[SEG_D * TILE_PIX + p.tid] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k0 + j >= u.nseg || tk[j] < 0.f) stop = true;
+                    if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
+                }
+                if (__all(stop)) break;
+            }
             const float inv = FAULT == 2 ? 0.f : 1.f / te;
             st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
         }
@@ -633,43 +500,19 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     default: afield = GRAD_G; break;       // lane 9
     }
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
-    // slot of the lane's sum in a trip's stash row: the ten field lanes of a row, compacted
-    const int sslot = row * 10 + ((li & 1) ? (li == 1 ? 8 : 9) : (li >> 1));      // (lane 14 -> 7; only written / read when alane)
     float *const abase = a.accum + afield;
     queue_clear(recs);
-    ids[0][lane] = 0u; ids[1][lane] = 0u;
-    if (lane < QSLOTS - WAVE) { ids[0][WAVE + lane] = 0u; ids[1][WAVE + lane] = 0u; }
+    ids[lane] = 0u;
+    if (lane < QSLOTS - WAVE) ids[WAVE + lane] = 0u;
 
-    // Back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops).
-    // Pipeline per batch of 16 trips:  [records of batch k -> LDS]  [atomics of batch k-1 from the stash]  [loads of batch
-    // k+1 / ids of batch k+2 issued]  [walk batch k: sums -> stash].  No memory operation is issued inside the walk, and
-    // everything the next batch boundary waits for (vmcnt counts loads and atomics alike on gfx9) was issued a whole walk
-    // earlier: neither the gather latency (two dependent hops) nor the atomics' round trip is exposed.
-    uint32_t prev_trips = 0;                      // bit t: trip t of the previous batch left sums in the stash
-    int buf = 0;
-    auto flush = [&](int b) {
-        while (prev_trips) {
-            const int t = __builtin_ctz(prev_trips);
-            prev_trips &= prev_trips - 1u;
-            if (alane) {
-                const float y = ystash[t][sslot];
-                // a row with no active pixel for this entry summed exact zeros: nothing to add (and its id may be stale)
-                if (FAULT == 9 || FAULT == 11) { if (y == 123.456f) a.accum[0] = y; }            // (timing experiments: no atomics)
-                else if (FAULT == 12) {      // timing experiment: every XCD adds into cache lines no other XCD touches
-                    const uint32_t id = ids[b][row * QROW + t];
-                    if (y != 0.f) unsafeAtomicAdd(abase + (size_t)(((id >> 4) << 4) | ((blockIdx.x & 7u) << 1) | (id & 1u)) * GRAD_STRIDE, y);
-                }
-                else if (y != 0.f) unsafeAtomicAdd(abase + (size_t)ids[b][row * QROW + t] * GRAD_STRIDE, y);
-            }
-        }
-    };
-    for (uint32_t g0 = 0; g0 < maxtop; g0 += 16, buf ^= 1) {
+    // back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops)
+    for (uint32_t g0 = 0; g0 < maxtop; g0 += 16) {
         wave_sync();
-        if (g0 + li < top) { ids[buf][row * QROW + li] = idc; recs[row * QROW + li] = R; }
-        flush(buf ^ 1);
-        idc = id2;
-        if (g0 + 16u + li < top) R = a.rec[(FAULT == 10 || FAULT == 11) ? (id2 & 1023u) : id2];
-        id2 = g0 + 32u + li < top ? r.ml[top - 1u - (g0 + 32u + li)] : 0u;
+        if (g0 + li < top) {
+            const uint32_t id = ml[top - 1u - (g0 + li)];
+            ids[row * QROW + li] = id;
+            recs[row * QROW + li] = a.rec[id];
+        }
         wave_sync();
         const int nt = (int)min(16u, maxtop - g0);
         for (int t = 0; t < nt; t += NE) {
@@ -677,10 +520,10 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
             bool anyact = false;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                const SplatRec *sr = recs + row * QROW + t + e;
-                const float4 r0 = sr->q0;
-                r1[e] = sr->q1; r2[e] = sr->q2;
-                dx[e] = r0.x - xf; dy[e] = r0.y - yf;
+                const SplatRec *s = recs + row * QROW + t + e;
+                const float4 r0 = s->q0;
+                r1[e] = s->q1; r2[e] = s->q2;
+                dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
                 const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
                 G[e] = __expf(pw);
                 al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
@@ -695,27 +538,17 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
                 float v[10];
                 bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
                 const float y = row_reduce10(v, b3, b2, b1, b0);
-                if (alane) ystash[t + e][sslot] = y;
-                prev_trips |= 1u << (t + e);
+                // a row with no active pixel for this entry sums exact zeros: nothing to add (and its id may be stale)
+                if (FAULT == 9) { if (y == 123.456f) a.accum[0] = y; }                  // (timing experiment: no atomics)
+                else if (alane && y != 0.f) unsafeAtomicAdd(abase + (size_t)ids[row * QROW + t + e] * GRAD_STRIDE, y);
             }
         }
     }
-    wave_sync();
-    flush(buf ^ 1);
 }
 
 // ------------------------------------------------------------------------------------ host
-static uint32_t micro_flags()
+int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    static int f = -1;
-    if (f < 0) { const char *e = getenv("GMS_MICRO_REGIONS"); f = (e && atoi(e) != 0) ? 0x10000 : 0; }
-    return (uint32_t)f;
-}
-
-int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
-{
-    BlendGrid g = g_in;
-    g.dbg |= micro_flags();
     static int deep_env = -2;
     if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
     const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;
@@ -725,46 +558,38 @@ int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
     const uint32_t Lh = seg_len_min();             // micro mode: one segment length for every frame
     auto filter = Lh <= 256u ? micro_filter_kernel<1> : (Lh <= 512u ? micro_filter_kernel<2> : micro_filter_kernel<4>);
     GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, filter<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
-    const unsigned pblocks = (blocks + PLAN_UNITS - 1u) / PLAN_UNITS;
-    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_plan_hist_kernel<<<pblocks, PLAN_THREADS, 0, stream>>>(g));
-    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_plan_scatter_kernel<<<pblocks, PLAN_THREADS, 0, stream>>>(g));
     GMS_KERNEL_CHECK(debug, stream, "micro_filter");
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
-    if (deep) {     // deep scene: first + early middle segments, tile-dead check, then the late middle segments of live tiles
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, 0));
+    if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, micro_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, 1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o, -1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, -1));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_head");
-    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, o));
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<4u * blocks, WAVE, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, micro_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_finalize");
     return GMS_OK;
 }
 
-int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    BlendGrid g = g_in;
-    g.dbg |= micro_flags();
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
     if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a)));
-    } else if (fault_mode() >= 9 && fault_mode() <= 12 && !invd) {      // timing experiments (wrong results): no atomics / L2-resident records / XCD-private atomics
-        auto kern = fault_mode() == 9 ? micro_bwd_kernel<false, 2, 9> : fault_mode() == 10 ? micro_bwd_kernel<false, 2, 10>
-                  : fault_mode() == 11 ? micro_bwd_kernel<false, 2, 11> : micro_bwd_kernel<false, 2, 12>;
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+    } else if (fault_mode() == 9 && !invd) {      // timing experiment (wrong results): no atomics
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
-                  : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks + 64u, WAVE, 0, stream>>>(g, a));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_bwd");
     return GMS_OK;
