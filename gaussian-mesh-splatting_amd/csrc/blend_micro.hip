@@ -35,18 +35,16 @@ struct MPix {
     int xi, yi, tid, b; bool inside; float xf, yf;
 };
 
-// wave q of a unit = the tile's 8x8 quadrant q; row r of the wave = block r of the quadrant; lane i of the row = pixel i
-__device__ __forceinline__ MPix micro_pixel(const BlendGrid &g, int tx, int ty, int q, int lane)
+// pixel `li` of 4x4 block `b` of a tile; index of the pixel in the per-(unit, pixel) segment state = b * 16 + li
+__device__ __forceinline__ MPix micro_pixel(const BlendGrid &g, int tx, int ty, int b, int li)
 {
-    const int row = lane >> 4, li = lane & 15;
-    const int bx = (q & 1) * 2 + (row & 1), by = (q >> 1) * 2 + (row >> 1);
     MPix p;
-    p.b = by * 4 + bx;
-    p.xi = tx * TILE + bx * 4 + (li & 3);
-    p.yi = ty * TILE + by * 4 + (li >> 2);
+    p.b = b;
+    p.xi = tx * TILE + (b & 3) * 4 + (li & 3);
+    p.yi = ty * TILE + (b >> 2) * 4 + (li >> 2);
     p.inside = p.xi < g.W && p.yi < g.H;
     p.xf = (float)p.xi; p.yf = (float)p.yi;
-    p.tid = q * WAVE + lane;          // index of the pixel in the per-(unit, pixel) segment state
+    p.tid = b * 16 + li;
     return p;
 }
 
@@ -55,6 +53,33 @@ __device__ __forceinline__ uint32_t max4rows(uint32_t v)          // v is row-un
     const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
     const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
     return max(max(a, b), max(c, d));
+}
+
+// What the four waves of a unit's block share: the Gaussian ids of the unit's entries (a block's list holds entry indices,
+// one byte each) and the unit's sixteen blocks ordered by list length, longest first -- wave q takes blocks order[4q .. 4q+3],
+// so the four rows of a wave walk lists of similar length (0.6 wave trips per instance instead of the 0.81 of a fixed
+// quadrant) and the block's longest wave is known to be wave 0.
+constexpr int LMAX = 256;          // micro mode: segment length <= 256 (entry index in a byte)
+struct UnitShared {
+    uint32_t uid[LMAX];
+    uint32_t order[16], ocnt[16];
+};
+__device__ __forceinline__ void unit_setup(const BlendGrid &g, const Unit &u, UnitShared &S)
+{
+    const int tid = threadIdx.x;
+    const uint32_t cn = u.end - u.beg;
+    if ((uint32_t)tid < cn) S.uid[tid] = (uint32_t)g.keys[u.beg + tid];
+    if (tid < 16) {
+        const uint32_t c = g.mcount[(size_t)u.idx * 16 + tid];
+        uint32_t rank = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0++) {
+            const uint32_t cs = (uint32_t)__shfl((int)c, s0);
+            rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
+        }
+        S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------ filter
@@ -128,7 +153,7 @@ __global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const 
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
-    uint32_t *out = g.mlist + (size_t)16 * u.beg;
+    uint8_t *out = reinterpret_cast<uint8_t *>(g.mlist) + (size_t)16 * u.beg;        // entry indices within the unit, one byte each
     const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
     const uint64_t lt = (1ull << lane) - 1ull;
     const uint32_t per = ((cn + 255u) / 256u) * 64u;          // entries per wave, a multiple of 64
@@ -163,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const 
 #pragma unroll
         for (int b = 0; b < 16; b++) {
             const uint64_t bal = __ballot((masks[c] >> b) & 1u);
-            if ((masks[c] >> b) & 1u) out[(size_t)b * cn + base[b] + (uint32_t)__builtin_popcountll(bal & lt)] = ids[c];
+            if ((masks[c] >> b) & 1u) out[(size_t)b * cn + base[b] + (uint32_t)__builtin_popcountll(bal & lt)] = (uint8_t)(w0 + (uint32_t)(c * 64 + lane));
             base[b] += (uint32_t)__builtin_popcountll(bal);
         }
     }
@@ -184,17 +209,15 @@ __device__ __forceinline__ void queue_clear(SplatRec *recs)
 
 // ------------------------------------------------------------------------------------ tloc
 template <int NE>
-__device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, SplatRec *recs, int phase, int q)
+__device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const SplatRec *rec, const Unit &u, const UnitShared &S, SplatRec *recs, int phase, int q)
 {
-    if (u.nseg == 1 || u.seg == u.nseg - 1) return;
-    if (phase >= 0 && (u.seg < tloc_head(u.L)) != (phase == 0)) return;     // phase -1: every segment in one launch
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
     float *dst = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
     if (phase == 1 && g.tile_dead[u.tile]) { *dst = 0.f; return; }
     const uint32_t cn = u.end - u.beg;
-    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
-    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *ml = reinterpret_cast<const uint8_t *>(g.mlist) + (size_t)16 * u.beg + (size_t)p.b * cn;
     const uint32_t maxcnt = max4rows(cnt);
     queue_clear(recs);
     float Tl = 1.f;
@@ -202,7 +225,7 @@ __device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const SplatR
         // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
         if (__all(Tl < T_MIN || !p.inside || j0 >= cnt)) break;
         wave_sync();
-        if (j0 + li < cnt) recs[row * QROW + li] = rec[ml[j0 + li]];
+        if (j0 + li < cnt) recs[row * QROW + li] = rec[S.uid[ml[j0 + li]]];
         wave_sync();
         const int nt = (int)min(16u, maxcnt - j0);
         for (int t = 0; t < nt; t += NE) {
@@ -233,7 +256,7 @@ __global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
     if (nseg <= nhead + 1) return;                 // no phase-1 segment exists (the last one needs no product)
     if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
     const int tid = threadIdx.x;
-    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 4, tid & 15);
     const float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float T = 1.f;
     for (int k = 0; k < nhead; k++) T *= st0[(size_t)k * SEG_FLOATS + SEG_TLOC * TILE_PIX + tid];
@@ -243,13 +266,13 @@ __global__ void __launch_bounds__(BLOCK) micro_tloc_check_kernel(BlendGrid g)
 
 // ------------------------------------------------------------------------------------ fwd
 template <int NE>
-__device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, SplatRec *recs, int q)
+__device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, const UnitShared &S, SplatRec *recs, int q)
 {
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
     const uint32_t cn = u.end - u.beg;
-    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
-    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *ml = reinterpret_cast<const uint8_t *>(g.mlist) + (size_t)16 * u.beg + (size_t)p.b * cn;
     const uint32_t maxcnt = max4rows(cnt);
     const uint32_t posbase = (uint32_t)u.seg * u.L;
 
@@ -274,7 +297,7 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
     for (uint32_t j0 = 0; j0 < maxcnt; j0 += 16) {
         if (__all(done || j0 >= cnt)) break;
         wave_sync();
-        if (j0 + li < cnt) recs[row * QROW + li] = o.rec[ml[j0 + li]];
+        if (j0 + li < cnt) recs[row * QROW + li] = o.rec[S.uid[ml[j0 + li]]];
         wave_sync();
         const int nt = (int)min(16u, maxcnt - j0);
         for (int t = 0; t < nt; t += NE) {
@@ -327,27 +350,37 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
     }
 }
 
+// First launch: every unit that depends on nothing -- the exact walk of each tile's FIRST segment (single-segment tiles are
+// finished by it) and, for the middle segments of multi-segment tiles, the transmittance products.  One block = one unit.
 template <int NE>
-__global__ void __launch_bounds__(WAVE) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
+__global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
-    __shared__ SplatRec recs[QSLOTS];
+    __shared__ SplatRec recs[4][QSLOTS];
+    __shared__ UnitShared S;
     Unit u;
-    const uint32_t bs = blockIdx.x >> 3;            // the four quadrant waves of a unit are consecutive blocks of one XCD
-    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
-    const int q = (int)(bs & 3u);
-    if (u.seg == 0) { if (phase <= 0) micro_fwd_unit<NE>(g, o, u, recs, q); }
-    else micro_tloc_unit<NE>(g, o.rec, u, recs, phase, q);
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
+    // (block-uniform decisions first: a unit with nothing to do in this launch leaves before the setup barrier)
+    const bool walk = u.seg == 0 ? phase <= 0
+                                 : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
+    if (!walk) return;
+    unit_setup(g, u, S);
+    const int q = (int)(threadIdx.x >> 6);
+    if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
+    else micro_tloc_unit<NE>(g, o.rec, u, S, recs[q], phase, q);
 }
 
+// Second launch: segments 1.. of the multi-segment tiles, from the prefix product of the segments in front.
 template <int NE>
-__global__ void __launch_bounds__(WAVE) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
+__global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
-    __shared__ SplatRec recs[QSLOTS];
+    __shared__ SplatRec recs[4][QSLOTS];
+    __shared__ UnitShared S;
     Unit u;
-    const uint32_t bs = blockIdx.x >> 3;
-    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
-    micro_fwd_unit<NE>(g, o, u, recs, (int)(bs & 3u));
+    unit_setup(g, u, S);
+    const int q = (int)(threadIdx.x >> 6);
+    micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
 }
 
 // ------------------------------------------------------------------------------------ finalize
@@ -359,7 +392,7 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
     if (nseg <= 1) return;
     if ((uint64_t)g.tile_offset[tile + 1] > g.capacity) return;
     const int tid = threadIdx.x;
-    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 6, tid & 63);
+    const MPix p = micro_pixel(g, tile % g.gx, tile / g.gx, tid >> 4, tid & 15);
     float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
     uint32_t last = 0;
@@ -419,18 +452,27 @@ __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, 
     return (b0 ? x1 : x0) + dpp_mov<0xB1>(b0 ? x0 : x1);
 }
 
+// One block = one unit.  The ten sums of every (row, splat) pair go into an LDS table indexed by the splat's entry in the unit
+// (ds_add_f32: 16.6 M LDS adds per frame on the headline scene); when the four waves are done the table is flushed with ONE
+// set of global atomics per (unit, entry): a splat that lies in several 4x4 blocks of the tile costs ten global atomics, not
+// ten per block (5.3 M instead of 16.6 M, and far fewer waves hammering the same gradient record at the same time).
 template <bool INVD, int NE, int FAULT>
-__global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
+__global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    __shared__ SplatRec recs[QSLOTS];
-    __shared__ uint32_t ids[QSLOTS];
+    __shared__ SplatRec recs_all[4][QSLOTS];
+    __shared__ uint32_t eid_all[4][QSLOTS];            // entry index (within the unit) of every queue slot
+    __shared__ float table[LMAX * 10];
+    __shared__ UnitShared S;
     Unit u;
-    const uint32_t bs = blockIdx.x >> 3;
-    if (!load_unit_at(g, u, bs >> 2, blockIdx.x & 7u)) return;
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
-    const int q = (int)(bs & 3u);
+    for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table[k] = 0.f;
+    unit_setup(g, u, S);                                // (its barrier also orders the table clear)
+    const int q = (int)(threadIdx.x >> 6);
+    SplatRec *recs = recs_all[q];
+    uint32_t *eid = eid_all[q];
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    const MPix p = micro_pixel(g, u.tx, u.ty, q, lane);
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
     const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
     const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
@@ -443,16 +485,16 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
     const uint32_t posbase = (uint32_t)u.seg * u.L;
     const uint32_t cn = u.end - u.beg;
-    const uint32_t cnt = g.mcount[(size_t)u.idx * 16 + p.b];
-    const uint32_t *ml = g.mlist + (size_t)16 * u.beg + (size_t)p.b * cn;
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *ml = reinterpret_cast<const uint8_t *>(g.mlist) + (size_t)16 * u.beg + (size_t)p.b * cn;
     // entries [0, lrel) of this block's list of this segment were composited by this pixel
     const uint32_t lrel = last > posbase ? min(last - posbase, cnt) : 0u;
     uint32_t top = lrel;                                    // furthest entry any pixel of the row composited
     top = max(top, (uint32_t)__shfl_xor((int)top, 8)); top = max(top, (uint32_t)__shfl_xor((int)top, 4));
     top = max(top, (uint32_t)__shfl_xor((int)top, 2)); top = max(top, (uint32_t)__shfl_xor((int)top, 1));
     const uint32_t maxtop = max4rows(top);
-    if (maxtop == 0) return;
 
+    if (maxtop > 0) {          // (wave-uniform; a wave with nothing to walk goes straight to the flush barrier)
     BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
     if (u.nseg > 1) {
         const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
@@ -484,7 +526,7 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
         }
     }
 
-    // lane -> field of the Gaussian's 64-byte gradient record it adds to (the layout row_reduce10 leaves)
+    // lane -> field of the 64-byte gradient record (the layout row_reduce10 leaves)
     const bool b3 = (li & 8) != 0, b2 = (li & 4) != 0, b1 = (li & 2) != 0, b0 = (li & 1) != 0;
     int afield;
     switch (li) {
@@ -500,29 +542,29 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
     default: afield = GRAD_G; break;       // lane 9
     }
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
-    float *const abase = a.accum + afield;
     queue_clear(recs);
-    ids[lane] = 0u;
-    if (lane < QSLOTS - WAVE) ids[WAVE + lane] = 0u;
+    eid[lane] = 0u;
+    if (lane < QSLOTS - WAVE) eid[WAVE + lane] = 0u;
 
     // back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops)
     for (uint32_t g0 = 0; g0 < maxtop; g0 += 16) {
         wave_sync();
         if (g0 + li < top) {
-            const uint32_t id = ml[top - 1u - (g0 + li)];
-            ids[row * QROW + li] = id;
-            recs[row * QROW + li] = a.rec[id];
+            const uint32_t e = ml[top - 1u - (g0 + li)];
+            eid[row * QROW + li] = e;
+            recs[row * QROW + li] = a.rec[S.uid[e]];
         }
         wave_sync();
         const int nt = (int)min(16u, maxtop - g0);
         for (int t = 0; t < nt; t += NE) {
-            bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE];
+            bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE]; uint32_t se[NE];
             bool anyact = false;
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                const SplatRec *s = recs + row * QROW + t + e;
-                const float4 r0 = s->q0;
-                r1[e] = s->q1; r2[e] = s->q2;
+                const SplatRec *sr = recs + row * QROW + t + e;
+                const float4 r0 = sr->q0;
+                r1[e] = sr->q1; r2[e] = sr->q2;
+                se[e] = eid[row * QROW + t + e];
                 dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
                 const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
                 G[e] = __expf(pw);
@@ -538,9 +580,21 @@ __global__ void __launch_bounds__(WAVE) micro_bwd_kernel(BlendGrid g, BlendBwdAr
                 float v[10];
                 bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
                 const float y = row_reduce10(v, b3, b2, b1, b0);
-                // a row with no active pixel for this entry sums exact zeros: nothing to add (and its id may be stale)
-                if (FAULT == 9) { if (y == 123.456f) a.accum[0] = y; }                  // (timing experiment: no atomics)
-                else if (alane && y != 0.f) unsafeAtomicAdd(abase + (size_t)ids[row * QROW + t + e] * GRAD_STRIDE, y);
+                // a row with no active pixel for this entry sums exact zeros: nothing to add (and its slot may be stale)
+                if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
+            }
+        }
+    }
+    }
+    __syncthreads();
+    // flush: sixteen entries per step, ten lanes per entry on the ten fields of its 64-byte record (one cache line)
+    {
+        const int f = threadIdx.x & 15;
+        for (uint32_t e = threadIdx.x >> 4; e < cn; e += BLOCK / 16) {
+            if (f < 10) {
+                const float y = table[e * 10u + (uint32_t)f];
+                if (FAULT == 9) { if (y == 123.456f) a.accum[0] = y; }                  // (timing experiment: no global atomics)
+                else if (y != 0.f) unsafeAtomicAdd(a.accum + (size_t)S.uid[e] * GRAD_STRIDE + f, y);
             }
         }
     }
@@ -562,14 +616,14 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 0));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, micro_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, 1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 1));
     } else {
-        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<4u * blocks, WAVE, 0, stream>>>(g, o, -1));
+        GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, -1));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_head");
-    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<4u * blocks, WAVE, 0, stream>>>(g, o));
+    GMS_LAUNCH(GMS_K_BLEND_FWD, stream, fwd2<<<blocks, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_fwd");
     GMS_LAUNCH(GMS_K_BLEND_FINALIZE, stream, micro_finalize_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g, o));
     GMS_KERNEL_CHECK(debug, stream, "micro_finalize");
@@ -583,13 +637,13 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
     if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else if (fault_mode() == 9 && !invd) {      // timing experiment (wrong results): no atomics
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<4u * blocks, WAVE, 0, stream>>>(g, a));
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_bwd");
     return GMS_OK;

@@ -999,7 +999,7 @@ uint32_t seg_len_forced()
     if (L < 0) {
         uint32_t v = 0;
         if (const char *e = getenv("GMS_SEG_LEN")) { v = (uint32_t)atoi(e); if (v < 64) v = 64; v = (v + 63u) / 64u * 64u; }
-        if (micro_mode()) { if (v == 0) v = SEG_LEN_MICRO; if (v > 1024u) v = 1024u; }      // one L for every frame
+        if (micro_mode()) { if (v == 0) v = SEG_LEN_MICRO; if (v > 256u) v = 256u; }      // one L for every frame; entry indices are bytes
         L = v;
     }
     return (uint32_t)L;

@@ -3,15 +3,15 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 export GMS_MICRO=1
 export GMS_SEG_LEN=256
-timeout 600 python -m pytest tests/test_gpu_raster.py -q -x 2>&1 | tail -3 > gpurun_out/r03_pytest_micro8_a.log
-tail -2 gpurun_out/r03_pytest_micro8_a.log
+timeout 600 python -m pytest tests/test_gpu_raster.py tests/test_gpu_negative_controls.py -q -x 2>&1 | tail -3 > gpurun_out/r03_pytest_micro9_a.log
+tail -2 gpurun_out/r03_pytest_micro9_a.log
 for F in 0 9; do
-  GMS_FAULT=$F timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_micro8_F$F.log 2> gpurun_out/r03_bench_micro8_F$F.err
+  GMS_FAULT=$F timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_micro9_F$F.log 2> gpurun_out/r03_bench_micro9_F$F.err
 done
-GMS_TRIP=4 GMS_TRIP_BWD=1 timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_micro8_t41.log 2>&1
+GMS_TRIP=4 GMS_TRIP_BWD=1 timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r03_bench_micro9_t41.log 2>&1
 python - <<'P'
 import json,glob
-for f in sorted(glob.glob("gpurun_out/r03_bench_micro8_*.log")):
+for f in sorted(glob.glob("gpurun_out/r03_bench_micro9_*.log")):
     try:
         d=json.loads([l for l in open(f) if l.startswith("{")][-1])
         print(f, d["value"], {k:v["avg_us"] for k,v in d["kernels"].items() if k.startswith(("blend","micro"))})
