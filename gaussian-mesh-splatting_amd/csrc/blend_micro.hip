@@ -77,6 +77,10 @@ __device__ __forceinline__ void unit_setup(const BlendGrid &g, const Unit &u, Un
             const uint32_t cs = (uint32_t)__shfl((int)c, s0);
             rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
         }
+        if (g.dbg & 0x20000u) {          // experiment: fixed quadrant grouping (wave q = the tile's quadrant q) instead of sorted
+            const int qd = ((tid >> 3) << 1) | ((tid >> 1) & 1), rr = (((tid >> 2) & 1) << 1) | (tid & 1);
+            rank = (uint32_t)(qd * 4 + rr);
+        }
         S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
     }
     __syncthreads();
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
                                  : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
     if (!walk) return;
     unit_setup(g, u, S);
-    const int q = (int)(threadIdx.x >> 6);
+    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
     else micro_tloc_unit<NE>(g, o.rec, u, S, recs[q], phase, q);
 }
@@ -379,7 +383,7 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
     unit_setup(g, u, S);
-    const int q = (int)(threadIdx.x >> 6);
+    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
     micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
 }
 
@@ -468,7 +472,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     if (u.end <= u.beg) return;
     for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table[k] = 0.f;
     unit_setup(g, u, S);                                // (its barrier also orders the table clear)
-    const int q = (int)(threadIdx.x >> 6);
+    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
     SplatRec *recs = recs_all[q];
     uint32_t *eid = eid_all[q];
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
@@ -601,8 +605,20 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 }
 
 // ------------------------------------------------------------------------------------ host
-int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+static uint32_t micro_flags()
 {
+    static int f = -1;
+    if (f < 0) {
+        const char *e = getenv("GMS_MICRO_ORDER"); f = (e && e[0] == 'q') ? 0x20000 : 0;
+        if (const char *r = getenv("GMS_MICRO_NOROT")) if (atoi(r)) f |= 0x40000;
+    }
+    return (uint32_t)f;
+}
+
+int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+{
+    BlendGrid g = g_in;
+    g.dbg |= micro_flags();
     static int deep_env = -2;
     if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
     const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;
@@ -630,8 +646,10 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     return GMS_OK;
 }
 
-int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    BlendGrid g = g_in;
+    g.dbg |= micro_flags();
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
@@ -642,6 +660,7 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
+                  : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     }
