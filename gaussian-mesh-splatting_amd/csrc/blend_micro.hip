@@ -4,23 +4,35 @@
 // scene).  A wave that owns an 8x8 quadrant and walks the quadrant's culled list one splat at a time (blend.hip) has 12 of
 // its 64 lanes busy and pays a 64-lane reduction per splat.  Here the unit of work is a 4x4 pixel BLOCK with its own
 // pre-filtered list: a wave carries four blocks, one per 16-lane row, each row walking ITS OWN list, so one trip of the
-// wave advances four (block, splat) pairs: 0.68 trips per instance instead of 1.19, 39 % of the lanes busy instead of 19 %,
+// wave advances four (block, splat) pairs (0.6 trips per instance instead of 1.19, 39 % of the lanes busy instead of 19 %)
 // and the ten gradient sums of a splat are reduced inside a 16-lane row with row-local DPP only (29 VALU for four splats
-// instead of 26 for one).
+// instead of 26 for one).  Measured on the headline scene (round 3, MI355X): backward 194 -> 142 us, forward compositing
+// 140 -> 113 us + 27 us for the filter.
 //
-//   micro_filter   one block per work unit (tile, segment of <= L <= 1024 list entries): gathers the unit's splat records
-//                  once, tests each against the tile's sixteen 4x4 blocks (bounding box of the alpha >= 1/255 ellipse, then
-//                  the exact ellipse-vs-rectangle test: it can only drop pairs every pixel of the block would skip) and
-//                  writes, per block, the ids of the survivors in list order (ballot ranks, no atomics).  The cull is paid
-//                  once per frame instead of once per pass (products, forward walk, backward walk).
+//   micro_filter   one block per work unit (tile, segment of <= L <= 256 list entries): gathers the unit's splat records
+//                  once, finds for each which of the tile's sixteen 4x4 blocks its {alpha >= 1/255} ellipse touches (exact
+//                  ellipse-vs-band intervals, conservative: it can only drop pairs every pixel of the block would skip) and
+//                  writes, per block, the survivors' entry indices (one byte each) in list order -- ballot ranks, no
+//                  atomics.  The cull is paid once per frame instead of once per pass (products, forward walk, backward walk).
 //   micro_head / micro_fwd / micro_finalize / micro_bwd
 //                  the segment-parallel scheme of blend.hip unchanged -- first segments walked exactly, transmittance
 //                  products of the middle segments, exact walk of segments 1.. from the prefix product, partial sums in
-//                  order, backward restarted at segment boundaries -- on (unit, quadrant) waves whose four rows are the
-//                  quadrant's four blocks.  No cull, no ballot loop: a row's queue holds only entries that hit its block.
+//                  order, backward restarted at segment boundaries -- with one 256-thread block per unit: the unit's
+//                  sixteen blocks are ordered by list length and dealt four to a wave (rows of similar length), the unit's
+//                  Gaussian ids sit in LDS, each row keeps a 16-entry queue of records there.  No cull, no ballot loop: a
+//                  row's queue holds only entries that hit its block.
+//   backward sums  go to an LDS table indexed by the splat's entry in the unit (ds_add_f32) and leave the block as ONE set of
+//                  global atomics per (unit, entry): 5.3 M global float atomics per frame instead of the 16.6 M a per-(block,
+//                  splat) atomic would issue (at ~120 G float atomics/s the L2 sustains, those alone would take 140 us).
 //
 // Positions.  n_contrib holds, per pixel, seg * L + (index in the block's list of that segment) + 1 of the last splat
 // applied: monotone along the block's concatenated lists, which is all the backward needs.
+//
+// Measured and not kept (same scene; git history holds the code): independent rows -- (unit, block) pieces counting-sorted
+// by length over the whole frame, four consecutive pieces per wave (0.58 trips per instance, 94 us of backward without its
+// atomics) -- loses the unit-level LDS table (16.6 M global atomics: 144 us) and needs two planning launches; a region key
+// in that sort for XCD-local gathers (slower: imbalance between XCDs); software-pipelined queue fills and deferred atomics
+// (no gain: the gather latency is already covered by the resident waves); fixed-quadrant rows instead of sorted ones (+6 us).
 #include <stdlib.h>
 
 #include "gms_common.h"
@@ -76,10 +88,6 @@ __device__ __forceinline__ void unit_setup(const BlendGrid &g, const Unit &u, Un
         for (int s0 = 0; s0 < 16; s0++) {
             const uint32_t cs = (uint32_t)__shfl((int)c, s0);
             rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
-        }
-        if (g.dbg & 0x20000u) {          // experiment: fixed quadrant grouping (wave q = the tile's quadrant q) instead of sorted
-            const int qd = ((tid >> 3) << 1) | ((tid >> 1) & 1), rr = (((tid >> 2) & 1) << 1) | (tid & 1);
-            rank = (uint32_t)(qd * 4 + rr);
         }
         S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
     }
@@ -368,7 +376,7 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
                                  : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
     if (!walk) return;
     unit_setup(g, u, S);
-    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
     else micro_tloc_unit<NE>(g, o.rec, u, S, recs[q], phase, q);
 }
@@ -383,7 +391,7 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
     unit_setup(g, u, S);
-    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
 }
 
@@ -472,7 +480,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     if (u.end <= u.beg) return;
     for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table[k] = 0.f;
     unit_setup(g, u, S);                                // (its barrier also orders the table clear)
-    const int q = (int)(((threadIdx.x >> 6) + (g.dbg & 0x40000u ? 0u : (blockIdx.x >> 3))) & 3u);      // rotate the sorted groups over the block's waves (= SIMDs): wave 0 must not always be the heaviest
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     SplatRec *recs = recs_all[q];
     uint32_t *eid = eid_all[q];
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
@@ -605,29 +613,15 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 }
 
 // ------------------------------------------------------------------------------------ host
-static uint32_t micro_flags()
+int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    static int f = -1;
-    if (f < 0) {
-        const char *e = getenv("GMS_MICRO_ORDER"); f = (e && e[0] == 'q') ? 0x20000 : 0;
-        if (const char *r = getenv("GMS_MICRO_NOROT")) if (atoi(r)) f |= 0x40000;
-    }
-    return (uint32_t)f;
-}
-
-int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
-{
-    BlendGrid g = g_in;
-    g.dbg |= micro_flags();
     static int deep_env = -2;
     if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
     const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 2; }
-    const uint32_t Lh = seg_len_min();             // micro mode: one segment length for every frame
-    auto filter = Lh <= 256u ? micro_filter_kernel<1> : (Lh <= 512u ? micro_filter_kernel<2> : micro_filter_kernel<4>);
-    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, filter<<<blocks, BLOCK, 0, stream>>>(g, o.rec));
+    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_filter_kernel<1><<<blocks, BLOCK, 0, stream>>>(g, o.rec));      // L <= 256: one 64-entry chunk per wave
     GMS_KERNEL_CHECK(debug, stream, "micro_filter");
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
@@ -646,10 +640,8 @@ int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32
     return GMS_OK;
 }
 
-int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
-    BlendGrid g = g_in;
-    g.dbg |= micro_flags();
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }

@@ -26,10 +26,8 @@ struct BlendGrid {
     uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)
     uint32_t unit_run;             // consecutive units dealt to one XCD (power of two <= 64)
     unsigned long long *dbg_buf;   // GMS_DBG&16: per block {start, end} wall clock (100 MHz), else NULL
-    uint32_t *mlist;               // micro mode: [16 capacity] ids per (unit, 4x4 block), see BinningState
+    uint32_t *mlist;               // micro mode: [16 capacity] bytes: entry indices per (unit, 4x4 block), see BinningState
     uint32_t *mcount;              // micro mode: [units][16]
-    uint32_t *wtab_fwd, *wtab_bwd; // micro mode: (unit, block) pieces grouped by list length, see BinningState
-    uint32_t *whist;               // micro mode: piece histogram / cursors / class totals
 };
 
 struct BlendFwdOut {
@@ -70,7 +68,7 @@ inline uint32_t max_slots(uint64_t instances, uint32_t L) { return 2u * (uint32_
 
 // ---- device-side helpers shared by the blend kernel files -------------------------------------------------------
 #ifndef GMS_MICRO_DEFAULT
-#define GMS_MICRO_DEFAULT 0
+#define GMS_MICRO_DEFAULT 1
 #endif
 #ifndef GMS_QUEUE
 #define GMS_QUEUE 256

@@ -103,20 +103,12 @@ struct BinningState {
     float *seg_state;      // [2N/L + 2][7][256]
     uint2 *deep_tab;       // [N/1024 + T + 2] (tile, run): every 1024-key sort run / merge chunk of every tile with >= 2 keys
     uint32_t *multi_tab;   // [N/1024 + 2] tiles with more than one run (they need merging)
-    // micro-tile compositing (blend_micro.hip): per (unit, 4x4 pixel block) the Gaussian ids of the unit's entries whose
-    // {alpha >= 1/255} ellipse touches the block, in list (depth) order.  Block b of the unit whose entries are
-    // [beg, beg + cn) starts at mlist[16 beg + b cn]: worst-case capacity (every entry in every block) at a fixed address,
-    // no scan; only the lines actually written (~2.3 ids per entry on mesh scenes) ever move.
-    uint32_t *mlist;       // [16 N]
-    uint32_t *mcount;      // [units][16] ids per (unit, block)
-    // (unit, block) pieces grouped four to a wave by list length (counting sort into MICRO_BUCKETS length classes, heaviest
-    // first): the forward table keeps the launch classes apart (first segments | middle segments, early | middle, late | last
-    // segments), the backward table holds the non-empty pieces.  Entry = unit index * 16 + block.
-    uint32_t *wtab_fwd;    // [units * 16]
-    uint32_t *wtab_bwd;    // [units * 16]
-    uint32_t *whist;       // [2][MICRO_CLASSES][MICRO_REGIONS][MICRO_BUCKETS] histogram, then cursors; [16] totals per class
-    static constexpr size_t MICRO_CLASSES = 5, MICRO_REGIONS = 8, MICRO_BUCKETS = 33;
-    static __host__ __device__ size_t whist_words() { return 2 * MICRO_CLASSES * MICRO_REGIONS * MICRO_BUCKETS + 16; }
+    // micro-tile compositing (blend_micro.hip): per (unit, 4x4 pixel block) the unit's entries whose {alpha >= 1/255} ellipse
+    // touches the block, in list (depth) order, as entry indices within the unit (one byte each: L <= 256).  Block b of the
+    // unit whose entries are [beg, beg + cn) starts at byte 16 beg + b cn: worst-case capacity (every entry in every block) at
+    // a fixed address, no scan; only the lines actually written (~2.3 bytes per entry on mesh scenes) ever move.
+    uint32_t *mlist;       // [16 N] bytes
+    uint32_t *mcount;      // [units][16] entries per (unit, block)
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
     static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 1024 + T + 2; }
@@ -125,7 +117,7 @@ struct BinningState {
     {
         return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 32, 256) +
                align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256) + align_up(n_multi(N) * 4, 256) +
-               (micro ? align_up((N > 0 ? N : 1) * 64, 256) + 3 * align_up(n_units(N, T, L) * 64, 256) + align_up(whist_words() * 4, 256) : 0);
+               (micro ? align_up((N > 0 ? N : 1) * 16, 256) + align_up(n_units(N, T, L) * 64, 256) : 0);
     }
     static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
     {
@@ -136,11 +128,8 @@ struct BinningState {
         b.seg_state = (float *)p;    p += align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
         b.deep_tab = (uint2 *)p;     p += align_up(n_deep(N, T) * 8, 256);
         b.multi_tab = (uint32_t *)p; p += align_up(n_multi(N) * 4, 256);
-        b.mlist = (uint32_t *)p;     p += align_up((N > 0 ? N : 1) * 64, 256);       // (this and the rest: present only in micro mode)
-        b.mcount = (uint32_t *)p;    p += align_up(n_units(N, T, L) * 64, 256);
-        b.wtab_fwd = (uint32_t *)p;  p += align_up(n_units(N, T, L) * 64, 256);
-        b.wtab_bwd = (uint32_t *)p;  p += align_up(n_units(N, T, L) * 64, 256);
-        b.whist = (uint32_t *)p;
+        b.mlist = (uint32_t *)p;     p += align_up((N > 0 ? N : 1) * 16, 256);       // (this and the next: present only in micro mode)
+        b.mcount = (uint32_t *)p;
         return b;
     }
 };

@@ -519,8 +519,6 @@ struct FillUnitsArgs {
     int T, sort_np;
     const uint32_t *scan_out;      // [3] = this frame's segment length
     uint32_t max_units, max_deep, max_multi;
-    uint32_t *whist;               // micro mode: piece histogram + cursors + totals, cleared here for the frame (else NULL)
-    uint32_t whist_words;
 };
 
 __device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
@@ -567,8 +565,6 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
     if (blockIdx.x >= emit_blocks) {
         // (first spare block: this frame's counts go to the host from here when the scan left that to us)
         if (blockIdx.x == emit_blocks && threadIdx.x == 0 && host_slot) publish_counts(host_slot, seq, scan_out[0], scan_out[1], scan_out[2]);
-        if (blockIdx.x == emit_blocks && fu.whist)
-            for (uint32_t k = threadIdx.x; k < fu.whist_words; k += BLOCK) fu.whist[k] = 0u;
         fill_units(fu, (int)(blockIdx.x - emit_blocks));
         return;
     }
@@ -1180,7 +1176,6 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         fu.unit_tile = bin.unit_tile; fu.deep_tab = bin.deep_tab; fu.multi_tab = bin.multi_tab;
         fu.max_multi = (uint32_t)BinningState::n_multi((size_t)capacity); fu.T = T; fu.sort_np = sort_np; fu.scan_out = img.scan_out; fu.max_units = mu;
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
-        fu.whist = micro_mode() ? bin.whist : nullptr; fu.whist_words = (uint32_t)BinningState::whist_words();
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                                        img.tile_cursor, bin.keys, capacity, pblocks, fu,
@@ -1204,7 +1199,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
-        g.mlist = bin.mlist; g.mcount = bin.mcount; g.wtab_fwd = bin.wtab_fwd; g.wtab_bwd = bin.wtab_bwd; g.whist = bin.whist;
+        g.mlist = bin.mlist; g.mcount = bin.mcount;
         if (micro_mode()) return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
         return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);
     };

@@ -315,15 +315,20 @@ def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
         assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, (frame, rep)
 
 
-@pytest.mark.parametrize("env", [{"GMS_SEG_LEN": "64"}, {"GMS_SEG_LEN": "256"}, {"GMS_SEG_LEN": "512", "GMS_DEEP": "1"},
-                                 {"GMS_TRIP": "2", "GMS_TRIP_BWD": "2"}, {"GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4"},
-                                 {"GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4", "GMS_SEG_LEN": "256", "GMS_DEEP": "1"},
-                                 {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}, {"GMS_BINDING": "ctypes"},
-                                 {"GMS_BINDING": "ctypes", "GMS_SYNC_BINNING": "1"}])
+@pytest.mark.parametrize("env", [
+    # micro-tile compositing (the default, blend_micro.hip): segment lengths, forced two-phase products, entries per trip
+    {"GMS_SEG_LEN": "64"}, {"GMS_SEG_LEN": "128", "GMS_DEEP": "1"}, {"GMS_SEG_LEN": "192"}, {"GMS_TRIP": "4", "GMS_TRIP_BWD": "1"},
+    {"GMS_TRIP": "1", "GMS_TRIP_BWD": "4"}, {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}, {"GMS_BINDING": "ctypes"},
+    {"GMS_BINDING": "ctypes", "GMS_SYNC_BINNING": "1"},
+    # the quadrant-wave kernels of blend.hip (GMS_MICRO=0) with their own knobs
+    {"GMS_MICRO": "0"}, {"GMS_MICRO": "0", "GMS_SEG_LEN": "64"}, {"GMS_MICRO": "0", "GMS_SEG_LEN": "256"},
+    {"GMS_MICRO": "0", "GMS_SEG_LEN": "512", "GMS_DEEP": "1"}, {"GMS_MICRO": "0", "GMS_TRIP": "2", "GMS_TRIP_BWD": "2"},
+    {"GMS_MICRO": "0", "GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4"},
+    {"GMS_MICRO": "0", "GMS_FWD_WPB": "4", "GMS_BWD_WPB": "4", "GMS_SEG_LEN": "256", "GMS_DEEP": "1"}])
 def test_tuning_knobs_do_not_change_results(env):
     """The knobs of INTEGRATION.md section 6 are read once per process: run the parity check in a child process per
-    setting (segment lengths other than the default, forced two-phase products, 2-entry trips, the four-waves-per-block
-    layout, no XCD run interleave, synchronous binning)."""
+    setting (both compositing implementations; segment lengths other than the default, forced two-phase products, entries
+    per trip, the four-waves-per-block layout of the quadrant kernels, no XCD run interleave, synchronous binning)."""
     import os
     import subprocess
     import sys
