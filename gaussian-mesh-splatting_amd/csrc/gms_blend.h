@@ -59,7 +59,8 @@ constexpr uint32_t SEG_LEN_SHALLOW = 128, SEG_LEN_DEEP = 256, SEG_DEEP_PER_TILE 
 // Micro-tile compositing (blend_micro.hip; GMS_MICRO=0 selects the quadrant-wave kernels of blend.hip): one segment length
 // for every frame (GMS_SEG_LEN, default SEG_LEN_MICRO, at most 256: a block's list holds entry indices within the unit, one byte each).
 constexpr uint32_t SEG_LEN_MICRO = 256;
-bool micro_mode();
+bool micro_mode();                                  // the micro-tile path may be taken (GMS_MICRO unset or 1)
+bool use_micro(uint64_t capacity, int T);           // ... and is, for a frame whose binning capacity is `capacity`
 uint32_t seg_len_forced();     // GMS_SEG_LEN, or 0
 uint32_t seg_len_min();        // the forced L, or SEG_LEN_SHALLOW: what BinningState is sized and carved with
 uint32_t unit_run();

@@ -519,7 +519,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         b.has_invd = A->dL_dout_invdepth != nullptr;
         uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
         if (A->num_units > 0 && (uint64_t)A->num_units < mu) mu = (uint32_t)A->num_units;      // exact count from the forward
-        int32_t rc = micro_mode() ? launch_micro_backward(g, b, mu, A->debug != 0, stream) : launch_blend_backward(g, b, mu, A->debug != 0, stream);
+        int32_t rc = use_micro(cap, T) ? launch_micro_backward(g, b, mu, A->debug != 0, stream) : launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
         if (fault_mode() == 1)      // negative control: sum(q dx^2) of every 1000th Gaussian off by 2e-3
             fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->grad_accum, P, GRAD_STRIDE, GRAD_CA, 1000, 1.002f);

@@ -118,11 +118,15 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
     }
 }
 
-template <int SHDEG, bool SPLIT>
+// MODE 0: everything in one launch.  MODE 1 / 2: the same kernel cut in two for the two-stream forward -- 1 = geometry (what
+// the binning needs: projection, conic, radius, extents, tile counts; 8 KB of LDS instead of 53), 2 = SH -> RGB (57 MB of
+// coefficient reads that only the compositing needs: runs on a second stream beside scan / emit / sort / filter).  The two
+// write disjoint bytes of the 48-byte record.
+template <int SHDEG, bool SPLIT, int MODE = 0>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH];
+    __shared__ __attribute__((aligned(16))) float sh_lds[MODE == 1 ? 2 * TT_SLOTS : 4 * WAVE * SH_PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < a.P;
@@ -140,7 +144,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     if (SHDEG >= 0) {
         const int g0 = blockIdx.x * BLOCK + wave * WAVE;
         const int rows = min(WAVE, a.P - g0);
-        if (!SPLIT) {
+        if (MODE == 1) {
+        } else if (!SPLIT) {
             const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
 #pragma unroll
             for (int j = 0; j < NQ; j++) {
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
                 }
             }
         }
-        if (valid) {
+        if (valid && MODE != 2) {
             op_in = a.opac[i];
             if (!a.cov3Dp) {
                 s_in[0] = a.scales[3 * (size_t)i]; s_in[1] = a.scales[3 * (size_t)i + 1]; s_in[2] = a.scales[3 * (size_t)i + 2];
@@ -185,10 +190,10 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     if (valid) {
         px = a.means3D[3 * (size_t)i]; py = a.means3D[3 * (size_t)i + 1]; pz = a.means3D[3 * (size_t)i + 2];
-        view_transform(a.view, px, py, pz, vx, vy, vz);
-        vis = vz > NEAR_Z;
+        if (MODE == 2) vis = a.radii[i] > 0;                          // (decided by the geometry launch)
+        else { view_transform(a.view, px, py, pz, vx, vy, vz); vis = vz > NEAR_Z; }
     }
-    if (vis) {
+    if (vis && MODE != 2) {
         const float *Mx = a.proj;
         float hx = dot3p(Mx[0], px, Mx[4], py, Mx[8], pz, Mx[12]);
         float hy = dot3p(Mx[1], px, Mx[5], py, Mx[9], pz, Mx[13]);
@@ -232,7 +237,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     // ---- colour
     float rgb[3] = {0, 0, 0};
     unsigned clampbits = 0;
-    if (SHDEG >= 0) {
+    if (MODE == 1) {
+    } else if (SHDEG >= 0) {
         float *wl = sh_lds + wave * (WAVE * SH_PITCH);
         if (!SPLIT) {
 #pragma unroll
@@ -310,9 +316,31 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         rgb[0] = a.colors[3 * (size_t)i]; rgb[1] = a.colors[3 * (size_t)i + 1]; rgb[2] = a.colors[3 * (size_t)i + 2];
     }
 
+    if (MODE == 2) {          // colour launch: the three colour words of the record and the clamp bits, nothing else
+        if (vis) {
+            float *rw = reinterpret_cast<float *>(a.geom.rec + i);
+            *reinterpret_cast<float2 *>(rw + 6) = make_float2(rgb[0], rgb[1]);
+            rw[8] = rgb[2];
+            a.geom.clamped[i] = (uint8_t)clampbits;
+        }
+        return;
+    }
     if (valid && !vis) a.radii[i] = 0;
     if (valid && a.visible) a.visible[i] = vis ? 1 : 0;
-    if (vis) {
+    if (vis && MODE == 1) {   // geometry launch: everything but the colour words
+        float tau = __logf(255.f * opp);
+        float ex, ey;
+        if (tau < -1e-3f) { ex = -1e30f; ey = -1e30f; }
+        else { ex = sqrtf(2.f * a_d * (tau + 1e-3f)); ey = sqrtf(2.f * c_d * (tau + 1e-3f)); }
+        float *rw = reinterpret_cast<float *>(a.geom.rec + i);
+        *reinterpret_cast<float4 *>(rw) = make_float4(pix, piy, cA, cB);
+        *reinterpret_cast<float2 *>(rw + 4) = make_float2(cC, opp);
+        rw[9] = 1.f / vz;
+        *reinterpret_cast<float2 *>(rw + 10) = make_float2(ex, ey);
+        a.geom.depth[i] = vz;
+        a.radii[i] = (int)rad;
+    }
+    if (vis && MODE == 0) {
         // half extents of the bounding box of {alpha >= 1/255}: |dx| <= sqrt(2 * cov_xx * ln(255 op)).
         // ln is inflated by 1e-3 so float rounding can never cull a pair the per-pixel test would keep.
         float tau = __logf(255.f * opp);
@@ -982,12 +1010,18 @@ static uint32_t deepest_tile(const int32_t *slot)
     return (uint32_t)(__atomic_load_n(reinterpret_cast<const unsigned long long *>(slot) + 1, __ATOMIC_RELAXED) & 0xffffffffull);
 }
 
-bool micro_mode()
+// GMS_MICRO: 1 = micro-tile compositing always, 0 = the quadrant-wave kernels always, unset = per frame: micro-tile for
+// shallow scenes (at most 512 list entries per tile on average: mesh surfaces, translucent splats), quadrant waves for deep
+// opaque ones (FLAME heads with 100 splats per face: most of a tile's list is never composited, and the two-phase
+// products of blend.hip stop at the visible depth while the filter would still test every entry).
+int micro_setting()
 {
-    static int m = -1;
-    if (m < 0) { const char *e = getenv("GMS_MICRO"); m = e ? (atoi(e) != 0 ? 1 : 0) : GMS_MICRO_DEFAULT; }
-    return m == 1;
+    static int m = -2;
+    if (m == -2) { const char *e = getenv("GMS_MICRO"); m = e ? (atoi(e) != 0 ? 1 : 0) : (GMS_MICRO_DEFAULT ? -1 : 0); }
+    return m;
 }
+bool micro_mode() { return micro_setting() != 0; }          // the micro-tile path may be taken: buffers carry its lists
+bool use_micro(uint64_t capacity, int T) { const int m = micro_setting(); return m == 1 || (m < 0 && capacity <= 512ull * (uint64_t)T); }
 
 uint32_t seg_len_forced()
 {
@@ -1127,19 +1161,51 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         set_error("split SH storage (shs_rest) needs M == 16 and 16-byte aligned pointers");
         return GMS_ERR_INVALID_ARGUMENT;
     }
-#define GMS_PRE(DEG, SP) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<DEG, SP><<<pblocks, BLOCK, 0, stream>>>(pa)))
+    // Two-stream forward (GMS_SH_STREAM=1 enables; measured on the headline scene: no gain, 2 158 against 2 173 it/s, so off by default): the SH -> RGB half of the preprocess runs on a library-owned second stream
+    // beside tile scan / emit / sort / filter, which leave most of the chip idle and need only the geometry half; the
+    // compositing waits for it (fork / join with two events).  The 57 MB of coefficient reads leave the critical path.
+    static int sh_stream_env = -1;
+    if (sh_stream_env < 0) { const char *e = getenv("GMS_SH_STREAM"); sh_stream_env = e ? (atoi(e) != 0) : 0; }
+    struct Aux { int device; hipStream_t s; hipEvent_t fork, join; };
+    static thread_local std::vector<Aux> t_aux;
+    Aux *aux = nullptr;
+    const bool two_stream = sh_stream_env && sh_fast && A->D > 0;
+    if (two_stream) {
+        for (auto &x : t_aux) if (x.device == device) aux = &x;
+        if (!aux) {
+            Aux x{device, nullptr, nullptr, nullptr};
+            GMS_HIP_CHECK(hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking));
+            GMS_HIP_CHECK(hipEventCreateWithFlags(&x.fork, hipEventDisableTiming));
+            GMS_HIP_CHECK(hipEventCreateWithFlags(&x.join, hipEventDisableTiming));
+            t_aux.push_back(x); aux = &t_aux.back();
+        }
+    }
+#define GMS_PRE_M(DEG, SP, MODE, STR) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, STR, (preprocess_fwd_kernel<DEG, SP, MODE><<<pblocks, BLOCK, 0, STR>>>(pa)))
+#define GMS_PRE(DEG, SP)                                                              \
+    do {                                                                              \
+        if (aux) {                                                                    \
+            GMS_PRE_M(DEG, SP, 1, stream);                                            \
+            GMS_HIP_CHECK(hipEventRecord(aux->fork, stream));                         \
+            GMS_HIP_CHECK(hipStreamWaitEvent(aux->s, aux->fork, 0));                  \
+            GMS_PRE_M(DEG, SP, 2, aux->s);                                            \
+            GMS_HIP_CHECK(hipEventRecord(aux->join, aux->s));                         \
+        } else {                                                                      \
+            GMS_PRE_M(DEG, SP, 0, stream);                                            \
+        }                                                                             \
+    } while (0)
     switch ((sh_fast ? A->D : -1) * 2 + (split ? 1 : 0)) {
-    case 0: GMS_PRE(0, false); break;
-    case 1: GMS_PRE(0, true); break;
+    case 0: GMS_PRE_M(0, false, 0, stream); break;
+    case 1: GMS_PRE_M(0, true, 0, stream); break;
     case 2: GMS_PRE(1, false); break;
     case 3: GMS_PRE(1, true); break;
     case 4: GMS_PRE(2, false); break;
     case 5: GMS_PRE(2, true); break;
     case 6: GMS_PRE(3, false); break;
     case 7: GMS_PRE(3, true); break;
-    default: GMS_PRE(-1, false); break;
+    default: GMS_PRE_M(-1, false, 0, stream); break;
     }
 #undef GMS_PRE
+#undef GMS_PRE_M
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len_min();         // sizes and carving; the frame's own L is chosen by the scan (scan_out[3])
     int32_t *slot = pinned_slot();
@@ -1200,7 +1266,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
         g.mlist = bin.mlist; g.mcount = bin.mcount;
-        if (micro_mode()) return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
+        if (aux) GMS_HIP_CHECK(hipStreamWaitEvent(stream, aux->join, 0));      // the colours (second stream) before the compositing
+        if (use_micro(capacity, T)) return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
         return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);
     };
 

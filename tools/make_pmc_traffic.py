@@ -11,12 +11,16 @@ stats_path = sys.argv[4] if len(sys.argv) > 4 else None
 dst = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 t = json.load(open(src))
 names = {"preprocess_fwd": ["preprocess_fwd"], "tile_scan": ["tile_scan"], "emit_instances": ["emit_instances"],
-         "tile_sort": ["tile_presort", "tile_merge"], "blend_head": ["blend_head"], "blend_fwd": ["blend_fwd"],
-         "blend_finalize": ["blend_finalize"], "blend_bwd": ["blend_bwd"], "preprocess_bwd": ["preprocess_bwd"],
+         "tile_sort": ["tile_presort", "tile_merge"], "blend_head": ["micro_head", "blend_head"], "blend_fwd": ["micro_fwd", "blend_fwd"],
+         "blend_finalize": ["micro_finalize", "blend_finalize"], "blend_bwd": ["micro_bwd", "blend_bwd"], "micro_filter": ["micro_filter"],
+         "preprocess_bwd": ["preprocess_bwd"],
          "mesh_fwd": ["mesh_fwd"], "mesh_bwd_splat": ["mesh_bwd_splat"], "mesh_bwd_face": ["mesh_bwd_face_thread", "mesh_bwd_face_wave", "mesh_bwd_fused"]}
 out = {}
 for k, srcs in names.items():
-    vals = [t[s]["hbm_bytes_corrected"] for s in srcs if s in t]
+    present = [s for s in srcs if s in t]
+    if k != "tile_sort":
+        present = present[:1]                    # (the first name that ran: micro_* kernels or the quadrant kernels)
+    vals = [t[s]["hbm_bytes_corrected"] for s in present]
     if vals:
         out[k] = int(sum(vals) / len(vals))      # per launch (tile_sort = mean of its two launches)
 # SQ counters (wave-instruction counts, mean per dispatch) for the VALU roofline of the compositing kernels
@@ -33,7 +37,7 @@ if stats_path and os.path.exists(stats_path):
         if k in sqo:
             sqo[k]["active_pairs"] = round(pairs)
             if sqo[k].get("SQ_INSTS_VALU"):
-                sqo[k]["active_lane_frac"] = round(st["blocks"]["8x8"]["active_lane_frac_exact"], 3)
+                sqo[k]["active_lane_frac"] = round(st["blocks"]["4x4"]["active_lane_frac_exact"], 3)      # micro-tile rows
 out["_sq"] = sqo
 # the build the counters belong to: bench.py withholds them from any other build (same hash function as bench.py)
 import hashlib
