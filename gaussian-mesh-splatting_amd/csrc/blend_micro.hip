@@ -76,24 +76,6 @@ struct UnitShared {
     uint32_t uid[LMAX];
     uint32_t order[16], ocnt[16];
 };
-__device__ __forceinline__ void unit_setup(const BlendGrid &g, const Unit &u, UnitShared &S)
-{
-    const int tid = threadIdx.x;
-    const uint32_t cn = u.end - u.beg;
-    if ((uint32_t)tid < cn) S.uid[tid] = (uint32_t)g.keys[u.beg + tid];
-    if (tid < 16) {
-        const uint32_t c = g.mcount[(size_t)u.idx * 16 + tid];
-        uint32_t rank = 0;
-#pragma unroll
-        for (int s0 = 0; s0 < 16; s0++) {
-            const uint32_t cs = (uint32_t)__shfl((int)c, s0);
-            rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
-        }
-        S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------ filter
 // Which of the tile's sixteen 4x4 blocks can see the splat with alpha >= 1/255 (bit by * 4 + bx).  Conservative: it may keep
 // a (splat, block) pair no pixel of the block accepts, never the reverse.
@@ -154,58 +136,57 @@ __device__ __forceinline__ uint32_t block_mask(const SplatRec &r, float tx0, flo
     return m;
 }
 
-// One block per unit.  Each wave takes a contiguous quarter of the unit's entries (64 at a time), counts its hits per block,
-// and after ONE barrier writes the survivors' ids behind those of the waves in front of it (ballot ranks: list order kept).
-template <int MAXC>                               // 64-entry chunks per wave: L <= 256 MAXC
-__global__ void __launch_bounds__(BLOCK) micro_filter_kernel(BlendGrid g, const SplatRec *rec)
+// What every unit block does first.  FILTER = this launch is the first to touch the unit: each thread takes one entry,
+// gathers its splat record, finds the 4x4 blocks it can reach (block_mask) and the survivors' entry indices are written per
+// block in list order -- ballot ranks inside a wave, wave bases after ONE barrier, no atomics -- to the unit's byte lists in
+// global memory, where the later launches (second forward launch, backward) find them.  Otherwise the counts are read back.
+// Either way: the unit's Gaussian ids into LDS and its sixteen blocks ordered by list length.
+// (The cull is paid once per frame -- not once per pass -- and costs no launch of its own: the filter used to be a kernel,
+// 25 us on the headline scene for work that takes a block about a microsecond.)
+template <bool FILTER>
+__device__ __forceinline__ void unit_setup(const BlendGrid &g, const Unit &u, UnitShared &S, const SplatRec *rec)
 {
     __shared__ uint32_t wcnt[4][16];
-    __shared__ uint32_t running[16];
-    Unit u;
-    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
-    uint8_t *out = reinterpret_cast<uint8_t *>(g.mlist) + (size_t)16 * u.beg;        // entry indices within the unit, one byte each
-    const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
-    const uint64_t lt = (1ull << lane) - 1ull;
-    const uint32_t per = ((cn + 255u) / 256u) * 64u;          // entries per wave, a multiple of 64
-    const uint32_t w0 = (uint32_t)wave * per;
-    uint32_t ids[MAXC], masks[MAXC];
-    uint32_t mycnt = 0;                            // lane b < 16: hits of block b in this wave's entries
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-        const uint32_t e = w0 + (uint32_t)(c * 64 + lane);
-        ids[c] = 0; masks[c] = 0;
-        if ((uint32_t)(c * 64) < per && e < cn) {
-            ids[c] = (uint32_t)g.keys[u.beg + e];
-            masks[c] = block_mask(rec[ids[c]], tx0, ty0);
-        }
+    uint32_t id = 0, mask = 0;
+    if ((uint32_t)tid < cn) { id = (uint32_t)g.keys[u.beg + tid]; S.uid[tid] = id; }
+    if (FILTER) {
+        if ((uint32_t)tid < cn) mask = block_mask(rec[id], (float)(u.tx * TILE), (float)(u.ty * TILE));
+        uint32_t mycnt = 0;                        // lane b < 16: hits of block b among this wave's 64 entries
 #pragma unroll
         for (int b = 0; b < 16; b++) {
-            const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((masks[c] >> b) & 1u));
-            if (lane == b) mycnt += n;
+            const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((mask >> b) & 1u));
+            if (lane == b) mycnt = n;
+        }
+        if (lane < 16) wcnt[wave][lane] = mycnt;
+        __syncthreads();
+        uint8_t *out = reinterpret_cast<uint8_t *>(g.mlist) + (size_t)16 * u.beg;    // entry indices within the unit, one byte each
+        const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const uint64_t bal = __ballot((mask >> b) & 1u);
+            if ((mask >> b) & 1u) {
+                uint32_t base = 0;
+                for (int w = 0; w < wave; w++) base += wcnt[w][b];
+                out[(size_t)b * cn + base + (uint32_t)__builtin_popcountll(bal & lt)] = (uint8_t)tid;
+            }
         }
     }
-    if (lane < 16) wcnt[wave][lane] = mycnt;
+    if (tid < 16) {
+        uint32_t c;
+        if (FILTER) { c = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid]; g.mcount[(size_t)u.idx * 16 + tid] = c; }
+        else c = g.mcount[(size_t)u.idx * 16 + tid];
+        uint32_t rank = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0++) {
+            const uint32_t cs = (uint32_t)__shfl((int)c, s0);
+            rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
+        }
+        S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
+    }
+    __threadfence_block();          // the lists just written are read back by this block's other waves
     __syncthreads();
-    uint32_t base[16];
-#pragma unroll
-    for (int b = 0; b < 16; b++) {
-        uint32_t s0 = 0;
-        for (int w = 0; w < wave; w++) s0 += wcnt[w][b];
-        base[b] = s0;
-    }
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-#pragma unroll
-        for (int b = 0; b < 16; b++) {
-            const uint64_t bal = __ballot((masks[c] >> b) & 1u);
-            if ((masks[c] >> b) & 1u) out[(size_t)b * cn + base[b] + (uint32_t)__builtin_popcountll(bal & lt)] = (uint8_t)(w0 + (uint32_t)(c * 64 + lane));
-            base[b] += (uint32_t)__builtin_popcountll(bal);
-        }
-    }
-    if (tid < 16) running[tid] = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
-    if (tid < 16) g.mcount[(size_t)u.idx * 16 + tid] = running[tid];
 }
 
 // ------------------------------------------------------------------------------------ queue
@@ -375,7 +356,12 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
     const bool walk = u.seg == 0 ? phase <= 0
                                  : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
     if (!walk) return;
-    unit_setup(g, u, S);
+    if (u.seg > 0 && phase == 1 && g.tile_dead[u.tile]) {          // products of a dead tile: nothing to walk, empty lists on record
+        if (threadIdx.x < 16) g.mcount[(size_t)u.idx * 16 + threadIdx.x] = 0u;
+        g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + threadIdx.x] = 0.f;
+        return;
+    }
+    unit_setup<true>(g, u, S, o.rec);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
     else micro_tloc_unit<NE>(g, o.rec, u, S, recs[q], phase, q);
@@ -390,7 +376,8 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
-    unit_setup(g, u, S);
+    if (u.seg == u.nseg - 1) unit_setup<true>(g, u, S, o.rec);          // last segments are first touched here
+    else unit_setup<false>(g, u, S, o.rec);                                // middle segments: filtered by the first launch
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     micro_fwd_unit<NE>(g, o, u, S, recs[q], q);
 }
@@ -479,7 +466,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
     for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table[k] = 0.f;
-    unit_setup(g, u, S);                                // (its barrier also orders the table clear)
+    unit_setup<false>(g, u, S, a.rec);                  // (its barrier also orders the table clear)
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     SplatRec *recs = recs_all[q];
     uint32_t *eid = eid_all[q];
@@ -621,8 +608,6 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 2; }
-    GMS_LAUNCH(GMS_K_MICRO_FILTER, stream, micro_filter_kernel<1><<<blocks, BLOCK, 0, stream>>>(g, o.rec));      // L <= 256: one 64-entry chunk per wave
-    GMS_KERNEL_CHECK(debug, stream, "micro_filter");
     auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
     auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
