@@ -7,13 +7,14 @@
 // wave advances four (block, splat) pairs (0.6 trips per instance instead of 1.19, 39 % of the lanes busy instead of 19 %)
 // and the ten gradient sums of a splat are reduced inside a 16-lane row with row-local DPP only (29 VALU for four splats
 // instead of 26 for one).  Measured on the headline scene (round 3, MI355X): backward 194 -> 142 us, forward compositing
-// 140 -> 113 us + 27 us for the filter.
+// (head + fwd + finalize) 140 -> 121 us including the filter.
 //
-//   micro_filter   one block per work unit (tile, segment of <= L <= 256 list entries): gathers the unit's splat records
-//                  once, finds for each which of the tile's sixteen 4x4 blocks its {alpha >= 1/255} ellipse touches (exact
-//                  ellipse-vs-band intervals, conservative: it can only drop pairs every pixel of the block would skip) and
-//                  writes, per block, the survivors' entry indices (one byte each) in list order -- ballot ranks, no
-//                  atomics.  The cull is paid once per frame instead of once per pass (products, forward walk, backward walk).
+//   filter         (unit_setup<true>, inside the first launch that touches a unit -- it used to be a kernel of its own, 25 us
+//                  for a microsecond of work per block): each thread takes one entry of the unit (tile, segment of <= L <= 256
+//                  list entries), gathers its splat record, finds which of the tile's sixteen 4x4 blocks its {alpha >= 1/255}
+//                  ellipse touches (exact ellipse-vs-band intervals, conservative: it can only drop pairs every pixel of
+//                  the block would skip) and the survivors' entry indices (one byte each) are written per block in list
+//                  order -- ballot ranks, no atomics.  The cull is paid once per frame, not once per pass.
 //   micro_head / micro_fwd / micro_finalize / micro_bwd
 //                  the segment-parallel scheme of blend.hip unchanged -- first segments walked exactly, transmittance
 //                  products of the middle segments, exact walk of segments 1.. from the prefix product, partial sums in
@@ -32,7 +33,10 @@
 // by length over the whole frame, four consecutive pieces per wave (0.58 trips per instance, 94 us of backward without its
 // atomics) -- loses the unit-level LDS table (16.6 M global atomics: 144 us) and needs two planning launches; a region key
 // in that sort for XCD-local gathers (slower: imbalance between XCDs); software-pipelined queue fills and deferred atomics
-// (no gain: the gather latency is already covered by the resident waves); fixed-quadrant rows instead of sorted ones (+6 us).
+// (no gain: the gather latency is already covered by the resident waves); fixed-quadrant rows instead of sorted ones (+6 us);
+// part of the ten sums by global atomics and part through the LDS table (+4 us); every non-first segment composited locally
+// from T = 1 and walked again only where a pixel can stop inside it (no gain: on the headline scene most later segments
+// hold a stopping pixel).
 #include <stdlib.h>
 
 #include "gms_common.h"
