@@ -771,6 +771,121 @@ __global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_
     for (int i = tid; i < cn; i += 256) d[i] = s[i];
 }
 
+// ---- register-resident presort ------------------------------------------------------------------------------------
+// The same all-ascending bitonic network (mirror step + half-cleaners: every step pairs element i with i ^ M) on a run of
+// <= 1024 keys, but with the keys in REGISTERS: thread t of 256 holds keys 4t .. 4t+3.  A step whose mask only touches bits
+// 0-1 is a compare-exchange between the thread's own registers; bits 2-7 select the partner LANE (lane ^ (M >> 2)): DPP row
+// operations for the lane masks 1, 2, 3, 4, 7, 8, 15 (full rate, no LDS), ds_bpermute for those that cross a 16-lane row; only
+// the four steps with bits 8-9 (k = 512 mirror, k = 1024 mirror, strides 512 and 256) go through LDS.  The LDS version pays an
+// LDS round trip and a barrier or wave sync for each of its 55 steps (a lone 1024-key block takes ~25 us: pure latency, and
+// the launch is a single round of blocks); this one pays four.
+template <int CTRL>
+__device__ __forceinline__ uint64_t dpp64(uint64_t v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+template <int ML>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v)
+{
+    if (ML == 1) return dpp64<0xB1>(v);            // quad_perm [1,0,3,2]
+    if (ML == 2) return dpp64<0x4E>(v);            // quad_perm [2,3,0,1]
+    if (ML == 3) return dpp64<0x1B>(v);            // quad_perm [3,2,1,0]
+    if (ML == 4) return dpp64<0x1B>(dpp64<0x141>(v));      // 7 - i within the half row, then the quad reversed: i ^ 4
+    if (ML == 7) return dpp64<0x141>(v);           // row_half_mirror
+    if (ML == 8) return dpp64<0x128>(v);           // row_ror:8
+    if (ML == 15) return dpp64<0x140>(v);          // row_mirror
+    const int lo = __shfl_xor((int)(uint32_t)v, ML), hi = __shfl_xor((int)(uint32_t)(v >> 32), ML);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+// one step of the network: element i = 4 t + r is paired with i ^ M; the element whose bit TOP(M) is clear keeps the minimum
+template <int M>
+__device__ __forceinline__ void sort_step(uint64_t (&k)[4], int t, uint64_t *lds)
+{
+    constexpr int MR = M & 3, ML = (M >> 2) & 63, MW = M >> 8;
+    constexpr int TOP = M >= 512 ? 512 : M >= 256 ? 256 : M >= 128 ? 128 : M >= 64 ? 64 : M >= 32 ? 32 : M >= 16 ? 16 : M >= 8 ? 8 : M >= 4 ? 4 : M >= 2 ? 2 : 1;
+    if (ML == 0 && MW == 0) {          // both elements in this thread
+        if (MR == 1) { ce(k[0], k[1]); ce(k[2], k[3]); }
+        else if (MR == 2) { ce(k[0], k[2]); ce(k[1], k[3]); }
+        else { ce(k[0], k[3]); ce(k[1], k[2]); }
+        return;
+    }
+    uint64_t p[4];
+    if (MW != 0) {                     // partner in another wave: through LDS
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) lds[4 * t + r] = k[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[r] = lds[(4 * t + r) ^ M];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) p[r] = lane_xor64<ML>(k[r ^ MR]);
+    }
+    const bool keep_min = ((4 * t) & TOP) == 0;          // (TOP >= 4 here: the same for the thread's four elements)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool less = p[r] < k[r];
+        k[r] = (less == keep_min) ? p[r] : k[r];
+    }
+}
+template <int J>
+__device__ __forceinline__ void sort_half_cleaners(uint64_t (&k)[4], int t, uint64_t *lds)
+{
+    if constexpr (J >= 1) {
+        sort_step<J>(k, t, lds);
+        sort_half_cleaners<J / 2>(k, t, lds);
+    }
+}
+template <int K>
+__device__ __forceinline__ void sort_level(uint64_t (&k)[4], int t, uint64_t *lds)
+{
+    sort_step<K - 1>(k, t, lds);               // mirror: i with i ^ (K - 1)
+    sort_half_cleaners<K / 4>(k, t, lds);      // strides K/4 ... 1
+}
+
+__global__ void __launch_bounds__(256) tile_presort_reg_kernel(const uint32_t *tile_offset, const uint32_t *run_total, const uint2 *run_tab,
+                                                               uint32_t max_runs, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
+                                                               int passes_launched)
+{
+    __shared__ uint64_t s[SORT_RUN];
+    const int tid = threadIdx.x;
+    if (blockIdx.x >= run_total[0] || blockIdx.x >= max_runs) return;      // one block per (tile, run) of the run table
+    const uint2 tr = run_tab[blockIdx.x];
+    const uint64_t beg = tile_offset[tr.x], end64 = tile_offset[tr.x + 1];
+    if (end64 > capacity) return;                 // overflowed launch: results are discarded by the host
+    const long n = (long)(end64 - beg);
+    int q;
+    const int cls = sort_class((uint64_t)n, passes_launched, q);
+    if (cls == SORT_FALLBACK) return;
+    uint64_t *dst_base = (cls == SORT_MERGEPATH && (q & 1)) ? tmp : keys;
+    const long c0 = (long)tr.y * SORT_RUN;
+    const int cn = (int)min((long)SORT_RUN, n - c0);
+    const uint64_t *g = keys + beg + c0;
+    uint64_t *d = dst_base + beg + c0;
+    if (cn <= 1) { if (cn == 1 && tid == 0) d[0] = g[0]; return; }
+    int m = 2;
+    while (m < cn) m <<= 1;
+    uint64_t k[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) k[r] = 4 * tid + r < cn ? g[4 * tid + r] : ~0ull;      // virtual +inf padding
+    sort_level<2>(k, tid, s);
+    sort_level<4>(k, tid, s);
+    if (m >= 8) sort_level<8>(k, tid, s);
+    if (m >= 16) sort_level<16>(k, tid, s);
+    if (m >= 32) sort_level<32>(k, tid, s);
+    if (m >= 64) sort_level<64>(k, tid, s);
+    if (m >= 128) sort_level<128>(k, tid, s);
+    if (m >= 256) sort_level<256>(k, tid, s);
+    if (m >= 512) sort_level<512>(k, tid, s);
+    if (m >= 1024) sort_level<1024>(k, tid, s);
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (4 * tid + r < cn) d[4 * tid + r] = k[r];
+}
+
 // number of elements taken from A among the first o outputs of merge(A, B) (keys are unique)
 template <typename PA, typename PB>
 __device__ __forceinline__ int co_rank(int o, PA A, int la, PB B, int lb)
@@ -1253,8 +1368,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         const uint32_t max_multi = (uint32_t)BinningState::n_multi((size_t)capacity);
         const uint32_t *run_total = img.class_first + NCLASS * ((size_t)T + 1) + T;
         const uint32_t *multi_total = img.class_first + (NCLASS + 1) * ((size_t)T + 1) + T;
-        GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
-                                                                                             sort_tmp, capacity, sort_np));
+        static int presort_lds = -1;        // GMS_PRESORT=lds: the LDS bitonic presort instead of the register-resident one
+        if (presort_lds < 0) { const char *e = getenv("GMS_PRESORT"); presort_lds = (e && e[0] == 'l') ? 1 : 0; }
+        if (presort_lds)
+            GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
+                                                                                                 sort_tmp, capacity, sort_np));
+        else
+            GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_reg_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
+                                                                                                     sort_tmp, capacity, sort_np));
         for (int pass = 0; pass < sort_np; pass++)
             GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
                                                                                                    sort_tmp, capacity, sort_np, pass));
