@@ -1,0 +1,17 @@
+# Round-3 evidence run (GPU box): full GPU suite, headline bench, secondary lines, rocprofv3 + PMC passes.
+set -x
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+T=${1:-r03v2}
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_pytest_gpu.log
+tail -3 gpurun_out/${T}_pytest_gpu.log
+python bench.py --steps 200 --warmup 20 > gpurun_out/${T}_bench_full.json.log 2> gpurun_out/${T}_bench_full.err
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --loss l1_ssim --optimizer fused_adam > gpurun_out/${T}_bench_full_iteration.json.log 2>&1
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload c4_ficus_like > gpurun_out/${T}_bench_c4_single_gpu.json.log 2>&1
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_1m --profile-steps 10 > gpurun_out/${T}_bench_c5_1m.json.log 2>&1
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_1m --mode animate > gpurun_out/${T}_bench_c5_1m_animate.json.log 2>&1
+GMS_BENCH_FORCE_DDP=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload c4_ficus_like --profile-steps 0 > gpurun_out/${T}_bench_one_rank_rccl.json.log 2>&1
+python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --profile-steps 0 > gpurun_out/${T}_bench_gpus2_shared.json.log 2>&1
+bash tools/collect_profiles.sh $T > gpurun_out/${T}_collect.log 2>&1
+grep -h -o '"value": [0-9.]*' gpurun_out/${T}_bench_*.json.log
+grep -E "^(micro|blend|tile_|preprocess|emit|mesh)" gpurun_out/${T}_rocprofv3_summary.txt | head -14 | cut -c1-130
