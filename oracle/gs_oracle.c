@@ -86,9 +86,17 @@ static const real SH_C3[7] = {(real)-0.5900435899266435, (real)2.890611442640554
  * evaluation orders can differ by 1e-4 in `power` -- enough to flip the 1/255 test.  A fixed order removes that. */
 static inline real pair_power(real A, real B, real C, real dx, real dy)
 {
+#ifdef ORACLE_UPSTREAM_ORDER
+    /* The published formula evaluated as written, left to right, every operation rounded on its own (no FMA):
+     *     power = -0.5f * (con_o.x * d.x * d.x + con_o.z * d.y * d.y) - con_o.y * d.x * d.y;
+     * A fourth build of the checker (libgs_oracle_f32up): tests/test_oracle_raster.py compares it with the default build to
+     * bound what sharing ONE evaluation order between the checker and the kernels could hide. */
+    return (real)-0.5 * (A * dx * dx + C * dy * dy) - B * dx * dy;
+#else
     const real a = A * dx, c = C * dy, b = B * dx;
     const real s = R_FMA(a, dx, c * dy);
     return R_FMA((real)-0.5, s, -(b * dy));
+#endif
 }
 
 typedef struct {

@@ -26,11 +26,11 @@ def build(force: bool = False) -> None:
     """Compile the C oracle (both precisions) with gcc."""
     out = os.path.join(_HERE, "_build")
     need = force or not all(
-        os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc")
+        os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc", "f32up")
     )
     src = os.path.join(_HERE, "gs_oracle.c")
     if not need:
-        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc"))
+        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc", "f32up"))
         need = os.path.getmtime(src) > newest
     if need:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
