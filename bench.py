@@ -183,10 +183,11 @@ def parse_args(argv=None):
                     help="how the large (SH) gradient is reduced on several GPUs: ring = one all_reduce (RCCL's choice of algorithm), "
                          "direct = two all-to-all phases over all xGMI links at once (games_hip.ddp.DirectAllReduce); auto times both "
                          "on gradient-sized buffers before the timed region and takes the faster one (both times are reported)")
-    ap.add_argument("--sh-exchange", default="auto", choices=["auto", "dense", "factor"],
+    ap.add_argument("--sh-exchange", default="auto", choices=["auto", "dense", "factor", "packed"],
                     help="several ranks: how the SH gradient (54 of the 64 MB) crosses ranks.  dense: inside the gradient all-reduce; "
-                         "factor: all-gather of the per-view [P,3] colour-gradient factors + local expansion (gms_sh_grad_expand); "
-                         "auto = factor when there is more than one rank")
+                         "factor: all-gather of the per-view [P,3] colour-gradient factors + local expansion (gms_sh_grad_expand) next to an "
+                         "all-reduce of the remaining 6.6 MB; packed: ONE all-gather of [small gradients | factors], summed locally; "
+                         "auto = a short timed run of the step with each, the fastest wins (all three times are reported)")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -267,7 +268,7 @@ def main():
 
     from diff_gaussian_rasterization import _lib, keep_buffers, last_stats
     from games_hip import synthetic as syn
-    from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce, ShFactorExchange
+    from games_hip.ddp import DirectAllReduce, OverlappedGradAllReduce, PackedGradExchange, ShFactorExchange
     from games_hip.render import PipelineParams, render
 
     workload = args.workload or ("c2_hotdog_like" if world == 1 else "c4_ficus_like")
@@ -292,8 +293,8 @@ def main():
         torch.cuda.synchronize(device)
 
     # ---- several ranks: which collective for the large gradient (timed on gradient-sized buffers, outside the timed region)
-    sh_factor = distributed and (args.sh_exchange == "factor" or (args.sh_exchange == "auto" and (world > 1 or force_ddp)))
-    sh_factor_default = sh_factor
+    sh_factor = distributed and (args.sh_exchange in ("factor", "packed") or (args.sh_exchange == "auto" and (world > 1 or force_ddp)))
+    sh_mode_default = ("packed" if args.sh_exchange == "packed" else "factor") if sh_factor else "dense"
     algo, allreduce_times = "ring", {}
     if distributed:
         # (factorised SH exchange: the feature tensors take no part in the all-reduce)
@@ -343,8 +344,9 @@ def main():
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
         del big, flat
 
-    def make_step(vps, reduce_grads, sh_factor=None):
-        sh_factor = sh_factor_default if sh_factor is None else sh_factor
+    def make_step(vps, reduce_grads, sh_mode=None):
+        sh_mode = sh_mode_default if sh_mode is None else sh_mode
+        sh_factor = sh_mode == "factor"
         """One step = K0 forward (once: the parameters are the same for all its views) + vps x (render fwd + bwd) on this rank's
         views + [reduce_grads] ONE gradient all-reduce.  Rank r renders cameras (r*vps + v) % 8 (config 4: 8 views)."""
         cams = [all_cams[(rank * vps + v) % 8] for v in range(vps)]
@@ -352,10 +354,13 @@ def main():
         # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
         inv_norm = 1.0 / (3.0 * size * size * vps * world)
         neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
-        reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed) else None
+        packed = PackedGradExchange(params, model._features_dc, model._features_rest, world, force=force_ddp) if (reduce_grads and distributed and sh_mode == "packed") else None
+        reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed and packed is None) else None
         exchange = ShFactorExchange(model._features_dc, model._features_rest, world, force=force_ddp) if (reducer is not None and sh_factor) else None
 
         def step():
+            if packed is not None:
+                packed.enable()
             if exchange is not None:
                 exchange.enable()
             model.update_alpha()
@@ -377,6 +382,9 @@ def main():
             if exchange is not None:
                 exchange.finish(model.get_xyz, model.active_sh_degree)
                 exchange.disable()
+            if packed is not None:
+                packed.finish(model.get_xyz, model.active_sh_degree)      # the step's ONE collective
+                packed.disable()
             if args.optimizer != "none":
                 model.optimizer.step()
                 model.optimizer.zero_grad(set_to_none=True)
@@ -429,13 +437,14 @@ def main():
     sh_exchange_ms = {}
     if distributed and args.sh_exchange == "auto":
         # like the all-reduce algorithm: measured, not assumed -- a short run of the step with each exchange, the same on every rank
-        for mode in (False, True):
-            s_try, r_try = make_step(vps, True, sh_factor=mode)
+        for mode in ("dense", "factor", "packed"):
+            s_try, r_try = make_step(vps, True, sh_mode=mode)
             el_try = timed(s_try, 30, 10)
-            sh_exchange_ms["factor" if mode else "dense"] = round(1000 * el_try / 30, 4)
+            sh_exchange_ms[mode] = round(1000 * el_try / 30, 4)
             if r_try is not None:
                 r_try.remove()
-        sh_factor_default = sh_factor = sh_exchange_ms["factor"] < sh_exchange_ms["dense"]
+        sh_mode_default = min(sh_exchange_ms, key=sh_exchange_ms.get)
+        sh_factor = sh_mode_default != "dense"
     step, reducer = make_step(vps, True)
     # untimed pre-warm (~0.3 s of steps before the W warm-up steps): allocator pools, capacity / unit hints and the GPU's
     # clocks reach their steady state; two back-to-back runs on one box otherwise differ by 6 % (first run slower)
@@ -479,20 +488,23 @@ def main():
             el_am = timed(s_am, max(1, args.steps // 2), 2)
             extra["amortised"] = {"views_per_rank_per_step": 4, "value": round(world * 4 * max(1, args.steps // 2) / el_am, 2),
                                   "ms_per_step": round(1000 * el_am / max(1, args.steps // 2), 4)}
-            r_am.remove()
+            if r_am is not None:
+                r_am.remove()
         # (c) the collectives alone on gradient-sized buffers (one large + one flat bucket, as the reducer issues them)
         extra["allreduce_ms"] = allreduce_times.get(algo)
         extra["allreduce_algorithms_ms"] = allreduce_times
         extra["allreduce_algorithm"] = algo
         extra["allreduce_bytes"] = allreduce_bytes
-        extra["sh_exchange"] = ("factor: all-gather of [P+1,3] colour-gradient factors + gms_sh_grad_expand" if sh_factor
-                                else "dense: the SH gradient travels inside the all-reduce")
+        extra["sh_exchange"] = {"factor": "factor: all-gather of [P+1,3] colour-gradient factors + gms_sh_grad_expand, all-reduce of the rest",
+                                "packed": "packed: ONE all-gather of [small gradients | colour-gradient factors], summed and expanded locally",
+                                "dense": "dense: the SH gradient travels inside the all-reduce"}[sh_mode_default]
         extra["sh_exchange_ms_per_step"] = sh_exchange_ms or None
         gather_bytes = 4 * 3 * (int(model.get_xyz.shape[0]) + 1) * vps * world if sh_factor else 0
         if sh_factor:
             extra["sh_factor_gather_bytes"] = gather_bytes
         dense_numel = sum(p.numel() for p in params if not (sh_factor and (p is model._features_dc or p is model._features_rest)))
-        extra["exchange_bytes"] = 4 * dense_numel + gather_bytes      # per rank per step: all-reduced gradient + gathered factors
+        # per rank per step: all-reduced gradient + gathered factors (packed: everything gathered, W x the small gradients)
+        extra["exchange_bytes"] = (4 * dense_numel * world + gather_bytes) if sh_mode_default == "packed" else (4 * dense_numel + gather_bytes)
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)

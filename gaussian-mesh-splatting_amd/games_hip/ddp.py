@@ -256,3 +256,63 @@ class ShFactorExchange:
             p.grad = g if p.grad is None else p.grad.add_(g)
         self._gathered, self._work, self._local = None, None, None
 
+
+
+class PackedGradExchange:
+    """The whole gradient exchange of a view-parallel step as ONE collective.
+
+    Every rank all-gathers one packed buffer  [ its small gradients | the [P+1,3] SH factors of its views ]  and then forms,
+    locally and in rank order, (a) the sum of the W small-gradient slices and (b) the SH gradient from the W x views factors
+    (`gms_sh_grad_expand`).  Compared with `OverlappedGradAllReduce` + `ShFactorExchange` (one all-reduce + one all-gather):
+    one RCCL launch and one stream hand-over per step instead of two, results bit-identical on every rank (fixed summation
+    order), at the price of receiving W x 6.6 MB of small gradients instead of all-reducing 6.6 MB (at 8 GPUs and 300 k
+    Gaussians 82 MB in, against 36 MB).  Which of the three wins is measured, not assumed: `bench.py --sh-exchange auto`.
+
+    `ops` = (set_mode, take, expand) as for `ShFactorExchange`."""
+
+    def __init__(self, params: Iterable[torch.Tensor], features_dc: torch.Tensor, features_rest: torch.Tensor, world: int, group=None,
+                 force: bool = False, ops=None):
+        if ops is None:
+            import diff_gaussian_rasterization as dgr
+            ops = (dgr.set_sh_factor_mode, dgr.take_sh_factors, dgr.sh_grad_expand)
+        self._set_mode, self._take, self._expand = ops
+        self.f_dc, self.f_rest = features_dc, features_rest
+        self.small = [p for p in params if p is not features_dc and p is not features_rest]
+        self.world, self.group = int(world), group
+        self._comm = (self.world > 1 or force) and dist.is_initialized()
+
+    def enable(self) -> "PackedGradExchange":
+        self._set_mode(True)
+        return self
+
+    def disable(self) -> None:
+        self._set_mode(False)
+
+    def finish(self, means3D: torch.Tensor, sh_degree: int) -> None:
+        facs = self._take()
+        if not facs:
+            raise RuntimeError("PackedGradExchange.finish(): no SH factor was queued -- was backward() run on the SH path with the mode on?")
+        local = facs[0].unsqueeze(0) if len(facs) == 1 else torch.stack(facs)          # [v, P+1, 3]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.small]
+        send = torch.cat([g.reshape(-1) for g in grads] + [local.reshape(-1)])
+        n, nf = send.numel(), local.numel()
+        W = self.world if self._comm else 1
+        if self._comm:
+            gathered = torch.empty(W * n, dtype=send.dtype, device=send.device)
+            dist.all_gather_into_tensor(gathered, send, group=self.group)
+        else:
+            gathered = send
+        G = gathered.view(W, n)
+        flat = G[:, :n - nf].sum(dim=0) if W > 1 else G[0, :n - nf]
+        off = 0
+        for p, g in zip(self.small, grads):
+            p.grad = flat[off:off + g.numel()].view(g.shape)
+            off += g.numel()
+        factors = G[:, n - nf:].reshape((W * local.shape[0],) + tuple(local.shape[1:])).contiguous()     # (rank, view) order
+        P = means3D.shape[0]
+        dc = torch.empty((P, 1, 3), dtype=torch.float32, device=means3D.device)
+        rest = torch.empty((P, self.f_rest.shape[1], 3), dtype=torch.float32, device=means3D.device)
+        self._expand(factors, means3D.detach(), int(sh_degree), dc, rest, False)
+        for p, g in ((self.f_dc, dc), (self.f_rest, rest)):
+            g = g.view(p.shape).to(p.dtype)
+            p.grad = g if p.grad is None else p.grad.add_(g)

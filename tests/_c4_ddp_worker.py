@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo")
     from games_hip import synthetic as syn
-    from games_hip.ddp import OverlappedGradAllReduce, ShFactorExchange
+    from games_hip.ddp import OverlappedGradAllReduce, PackedGradExchange, ShFactorExchange
     from games_hip.model import HipGaussianMultiMeshModel
     from games_hip.render import PipelineParams, render
     scenes = syn.multi_mesh_scenes(workload, state="trained")
@@ -30,14 +30,17 @@ def main():
     bg = torch.ones(3, device=dev)
     gcs = torch.load(os.path.join(os.path.dirname(out_path), "upstream.pt"))       # [world][3,H,W]: the serial run uses the same
     results = {}
-    for variant in ("ring", "direct", "direct_ag", "factor"):
+    for variant in ("ring", "direct", "direct_ag", "factor", "packed"):
         sh_factor = variant == "factor"
-        algo = "ring" if sh_factor else variant
-        reducer = OverlappedGradAllReduce(params, world, average=False, algorithm=algo, big_numel=1 << 16)
+        algo = "ring" if variant in ("factor", "packed") else variant
+        packed = PackedGradExchange(params, model._features_dc, model._features_rest, world) if variant == "packed" else None
+        reducer = OverlappedGradAllReduce(params, world if packed is None else 1, average=False, algorithm=algo, big_numel=1 << 16)
         exchange = ShFactorExchange(model._features_dc, model._features_rest, world) if sh_factor else None
         try:
             for p in params:
                 p.grad = None
+            if packed is not None:
+                packed.enable()
             if exchange is not None:
                 exchange.enable()
             model.update_alpha(); model.prepare_scaling_rot()
@@ -49,12 +52,17 @@ def main():
             if exchange is not None:
                 exchange.finish(model.get_xyz, model.active_sh_degree)
                 exchange.disable()
+            if packed is not None:
+                packed.finish(model.get_xyz, model.active_sh_degree)
+                packed.disable()
             torch.cuda.synchronize()
             results[variant] = [p.grad.detach().cpu().clone() for p in params]
         except Exception as e:  # noqa: BLE001 -- a collective this backend cannot run on CUDA tensors is reported, not hidden
             results[variant] = f"failed: {e!r}"
             if exchange is not None:
                 exchange.disable()
+            if packed is not None:
+                packed.disable()
         finally:
             reducer.remove()
         ok = torch.tensor([0.0 if isinstance(results[variant], str) else 1.0])

@@ -246,3 +246,60 @@ def test_sh_factor_exchange_world2_equals_the_sum_of_dense_gradients():
         assert mode is False
         assert float((got - dense).abs().max()) <= 2e-6 * scale, rank
     assert torch.equal(res[0][1], res[1][1])                        # same views, same order: bit-identical on every rank
+
+
+def _packed_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from games_hip.ddp import PackedGradExchange
+        from oracle import sh_expand_ref
+        mine = [_sh_view(rank)]                                    # one view per rank
+        sc = mine[0][0]
+        queue = [m[2] for m in mine]
+
+        def expand(factors, means3D, deg, dc, rest, accumulate):
+            full = sh_expand_ref.expand(factors, means3D, deg, 16)
+            dc.copy_(full[:, :1]); rest.copy_(full[:, 1:])
+
+        P = sc.means3D.shape[0]
+        f_dc = torch.zeros(P, 1, 3, requires_grad=True)
+        f_rest = torch.zeros(P, 15, 3, requires_grad=True)
+        small = [torch.zeros(s_, requires_grad=True) for s_ in ((P, 1), (7, 3), (P, 3, 3))]
+        local = [torch.randn(p.shape, generator=torch.Generator().manual_seed(900 + 10 * rank + k)) for k, p in enumerate(small)]
+        for p, g in zip(small, local):
+            p.grad = g.clone()
+        ex = PackedGradExchange(small + [f_dc, f_rest], f_dc, f_rest, world, ops=(lambda on: None, lambda: [queue.pop(0) for _ in range(len(queue))], expand))
+        ex.enable()
+        ex.finish(sc.means3D, 3)
+        ex.disable()
+        q.put((rank, [l.numpy().copy() for l in local], [p.grad.numpy().copy() for p in small],
+               torch.cat([f_dc.grad, f_rest.grad], dim=1).numpy().copy(), mine[0][1].numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_single_collective_exchange_world2():
+    """ONE all-gather of [small gradients | SH factors]: the small gradients come out as the sum over ranks, the SH gradient as
+    the sum of the views' dense gradients, bit-identical on both ranks."""
+    import numpy as np
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    for k in range(3):
+        total = res[0][1][k] + res[1][1][k]
+        for r in res:
+            np.testing.assert_allclose(r[2][k], total, rtol=1e-6, atol=1e-7)
+        assert np.array_equal(res[0][2][k], res[1][2][k])
+    dense = res[0][4] + res[1][4]
+    for r in res:
+        assert np.abs(r[3] - dense).max() <= 2e-6 * np.abs(dense).max()
+    assert np.array_equal(res[0][3], res[1][3])

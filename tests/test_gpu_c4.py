@@ -6,7 +6,7 @@ the GPU with REAL gradients:
     gradient criterion -- reference: games/multi_mesh_splatting/scene/gaussian_multi_mesh_model.py:99-199;
   * SURVEY.md 8(e) "Semantics caveat": two ranks (sharing cuda:0 over gloo on this 1-GPU box), rank r renders view r; after the
     exchange every parameter gradient equals the SUM of the two single-view gradients computed serially in one process -- for
-    the ring, direct and direct+all-gather all-reduce and for the factorised SH exchange."""
+    the ring, direct and direct+all-gather all-reduce, for the factorised SH exchange and for the packed single-collective exchange."""
 import os
 import socket
 import subprocess
@@ -126,4 +126,4 @@ def test_config4_exchanged_gradients_equal_the_sum_of_the_single_view_gradients(
             # relative (floor: 1 % of the scale) on EVERY entry
             rel = np.abs(a - b) / (np.abs(b) + 1e-2 * scale + 1e-30)
             assert np.quantile(np.abs(a - b), 0.999) <= 1e-5 * scale + 1e-30 and rel.max() <= 1e-3, (workload, variant, k, float(rel.max()))
-    assert "ring" in ran and "factor" in ran, res.keys()
+    assert "ring" in ran and "factor" in ran and "packed" in ran, res.keys()
