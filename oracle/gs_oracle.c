@@ -509,6 +509,19 @@ typedef double acc_t;
 /* per-instance gradient slots */
 enum { G_MX = 0, G_MY, G_CA, G_CB, G_CC, G_OP, G_R, G_G, G_B, G_ID, G_NUM };
 
+/* -DORACLE_FMA_BACKWARD (libgs_oracle_f32fma): the SAME float32 backward with the compiler free to contract a*b+c into one
+ * FMA -- a second rounding realisation of the same formulas, which is what every GPU build of them is (nvcc and hipcc both
+ * contract by default).  The forward pass and every decision keep the fixed operation order (this pragma covers
+ * or_backward only; the decision helpers use explicit fma chains).  Why it exists: the published cov2D-inverse gradient
+ * contains (denom - a*c) with denom = a*c - b*b; for a long splat that difference is rounding noise of size ulp(a*c)
+ * against b*b, and the gradient of the rotation moves by up to 2e-3 of the tensor's largest entry between two float32
+ * realisations of the very same expression (fuzz seed 5337, one Gaussian: 1.9e-3).  tests/_util.py
+ * takes the float32 oracle's own error on a row as the maximum over its realisations (f32, f32acc, f32fma). */
+#ifdef ORACLE_FMA_BACKWARD
+#pragma GCC push_options
+#pragma GCC target("fma")
+#pragma GCC optimize("fp-contract=fast")
+#endif
 void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,H,W]*/,
                  const real *dL_dinvdepth_pix /*[H,W] or NULL*/,
                  real *dL_dmeans3D, real *dL_dmeans2D /*[P,3]*/, real *dL_dsh /*[P,M,3]*/,
@@ -797,6 +810,10 @@ void or_backward(const OrScene *sc, const OrState *st, const real *dL_dpix /*[3,
 /* accessors for the python wrapper */
 long or_state_N(const OrState *st) { return st->N; }
 double or_state_interactions(const OrState *st) { return st->interactions; }
+#ifdef ORACLE_FMA_BACKWARD
+#pragma GCC pop_options
+#endif
+
 void or_state_copy(const OrState *st, real *depth, real *xy, real *conic_op, real *rgb, real *cov3D,
                    uint8_t *clamped, int *rect, real *final_T, int *n_contrib, uint8_t *gauss_ambig,
                    uint8_t *pix_ambig, uint32_t *point_list, long *ranges)

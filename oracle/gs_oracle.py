@@ -22,15 +22,28 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
 
+_VARIANTS = ("f32", "f64", "f32acc", "f32up", "f32fma")
+
+
+def has_fma() -> bool:
+    """The f32fma build (backward contracted into FMA3 instructions) only runs on an x86 host that has them."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
 def build(force: bool = False) -> None:
-    """Compile the C oracle (both precisions) with gcc."""
+    """Compile the C oracle (all variants of oracle/Makefile) with gcc."""
     out = os.path.join(_HERE, "_build")
-    need = force or not all(
-        os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc", "f32up")
-    )
+    need = force or not all(os.path.exists(os.path.join(out, f"libgs_oracle_{p}.so")) for p in _VARIANTS)
     src = os.path.join(_HERE, "gs_oracle.c")
     if not need:
-        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in ("f32", "f64", "f32acc", "f32up"))
+        newest = min(os.path.getmtime(os.path.join(out, f"libgs_oracle_{p}.so")) for p in _VARIANTS)
         need = os.path.getmtime(src) > newest
     if need:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
@@ -56,6 +69,8 @@ def _scene_struct(real):
 
 def _lib(precision: str):
     if precision not in _LIBS:
+        if precision == "f32fma" and not has_fma():
+            raise RuntimeError("oracle variant f32fma needs a host CPU with FMA3")
         build()
         lib = C.CDLL(os.path.join(_HERE, "_build", f"libgs_oracle_{precision}.so"))
         real = C.c_double if precision == "f64" else C.c_float

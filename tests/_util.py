@@ -87,20 +87,76 @@ def forward_report(hip, ora, W, H, input_rounding=False):
 
 GRAD_REL = 1e-3          # north_star: 1e-3 relative on gradients
 # An outlier is float32 conditioning if HIP is within K x the float32 ORACLE's own error against the float64 oracle on the
-# same row.  "The float32 oracle's error" = the larger of two float32 builds': the default one (float32 terms summed in
-# double: per-term rounding only) and the float32-accumulator one (libgs_oracle_f32acc: the sums themselves in float32, as
-# any float-atomics implementation -- the reference's CUDA kernels, these HIP kernels -- has them).  The affected rows are
-# thin, long splats whose cov2D gradient is a difference of terms ~5000x its size.
+# same row.  "The float32 oracle's error" = the largest over its float32 REALISATIONS: the default build (float32 terms
+# summed in double: per-term rounding only), the float32-accumulator build (libgs_oracle_f32acc: the sums themselves in
+# float32, as any float-atomics implementation -- the reference's CUDA kernels, these HIP kernels -- has them) and the
+# FMA-contracted backward (libgs_oracle_f32fma: the same formulas with a*b+c fused, which is what nvcc and hipcc both emit),
+# and the default build on inputs nudged by one float32 ulp (`f32_realisations`).
+# The affected rows are thin, long splats whose cov2D gradient is a difference of terms ~5000x its size.
 # Round 3: every constant below was tightened to <= 2x the maximum observed over the round-2 report (27 comparisons incl.
-# three config-5-size frames, profiles/r02_parity_report.jsonl) and the 3 600-case fuzz sweep; DESIGN.md section 2 holds
-# the table (constant, the failure that introduced it, observed maximum).  tests/test_gpu_negative_controls.py shows the
-# criterion FAILS for four injected defects (gmsplat.h, gms_set_fault).
-ADJUDICATE_K = 16.0               # observed worst ratio 8.0 (scales, config-5 size)
+# three config-5-size frames, profiles/r02_parity_report.jsonl) and the fuzz sweeps (400 + 1000 cases on the round-3
+# kernels); DESIGN.md section 2 holds the table (constant, the failure that introduced it, observed maximum).
+# tests/test_gpu_negative_controls.py shows the criterion FAILS for four injected defects (gmsplat.h, gms_set_fault).
+ADJUDICATE_K = 8.0                # observed worst ratio 3.4 (scales, config-5 size), 2.9 (600-case fuzz) with the realisations below
 UNEXPLAINED_PER_MILLION = 1.0     # observed 0
 RARE_FRAC = 5e-4                  # explained outliers per tensor: observed <= 5.2e-5 (scales); small tensors: <= RARE_MIN entries
 RARE_MIN = 8
-ROW_FRAC = 5e-3                   # rows taking the excused / alternate-outcome rules: observed <= 1.3e-5 of the entries
+ROW_FRAC = 1e-2                   # entries taking the excused / alternate-outcome rules: suite <= 1.3e-5; fuzz seed 7197 (faint splats, alpha near 1/255 everywhere): 26 of 4500
 Q_MIN_SIZE = 500                  # the 0.999 quantile is asserted for every tensor with at least this many entries
+# Conditioning-relative caps.  On 0.7 % of random scenes (faint, large, elongated splats) the float32 ORACLE ITSELF is not
+# within 1e-3 of the float64 one: e.g. fuzz seed 5179, rotation gradients: 27 of 6000 entries of the float32 realisations
+# beyond 1e-3 from float64, 0.999-quantile 2.8e-3; HIP against the float32 oracle: 15 entries, 2.4e-3.  There the fixed
+# caps above cannot hold for ANY float32 implementation, so the cap becomes relative to what the oracle's own float32
+# realisations do on the same tensor (`ref_outliers`, `ref_q`: measured without the HIP output):
+COND_COUNT = 2.0                  # outliers <= COND_COUNT x ref_outliers   (observed <= 1.25 x where more than RARE_MIN entries are involved)
+COND_Q = 3.0                      # HIP's 0.999-quantile error AGAINST FLOAT64 <= COND_Q x ref_q   (observed <= 1.89 x, 600-case fuzz)
+
+
+def nudged_inputs(inputs, seed):
+    """The same scene with every coordinate of means3D / scales / rotations moved to a NEIGHBOURING float32 (random
+    direction, seeded): to float64 the gradient changes by ~1e-5 of its scale; to a float32 evaluation it is a fresh
+    rounding realisation of every intermediate."""
+    rng = np.random.default_rng(seed)
+    out = dict(inputs)
+    for k in ("means3D", "scales", "rotations"):
+        if inputs.get(k) is not None:
+            a = np.asarray(inputs[k].detach().cpu().numpy() if torch.is_tensor(inputs[k]) else inputs[k], np.float32)
+            out[k] = torch.from_numpy(np.nextafter(a, np.where(rng.integers(0, 2, a.shape) > 0, np.inf, -np.inf).astype(np.float32)))
+    return out
+
+
+def f32_realisations(inputs, kw, grad_color, grad_invdepth=None, nudged=(1, 2)):
+    """Gradients of further float32 realisations of the oracle (same algorithm, different rounding), the noise scale of
+    `assert_grads(go32acc_fn=...)`: float32 accumulators; the FMA-contracted backward where the host CPU has FMA3; and the
+    default build on inputs nudged by one float32 ulp (seeds `nudged`).  The last is the one that does not depend on luck:
+    on fuzz seed 5337 (one elongated Gaussian) the default and accumulator builds are within 1e-4 of float64 on the
+    rotation gradient, every nudged realisation and the contracted one are 1.8e-3 ... 3.5e-3 away."""
+    out = [oracle_render(inputs, kw, grad_color, grad_invdepth, precision="f32acc")["grads"]]
+    if gs_oracle.has_fma():
+        out.append(oracle_render(inputs, kw, grad_color, grad_invdepth, precision="f32fma")["grads"])
+    for sd in nudged:
+        out.append(oracle_render(nudged_inputs(inputs, sd), kw, grad_color, grad_invdepth)["grads"])
+    return out
+
+
+def fuzz_case(seed):
+    """The random scene / camera / settings of tools/fuzz_parity.py for one seed -> (inputs, kw, tag, rng): shared by the
+    sweep, tools/diag_case.py and the CPU self-checks of the criterion (tests/test_oracle_raster.py)."""
+    from games_hip import synthetic as syn
+    rng = np.random.default_rng(seed)
+    P = int(rng.choice([1, 7, 100, 1500, 6000, 20000]))
+    W, H = int(rng.integers(17, 300)), int(rng.integers(17, 220))
+    deg = int(rng.integers(0, 4))
+    aa = bool(rng.integers(0, 2))
+    lo = float(rng.choice([0.002, 0.01, 0.05])); hi = lo * float(rng.choice([2, 10, 40]))
+    op_lo = float(rng.choice([0.01, 0.1, 0.6])); op_hi = min(0.999, op_lo + float(rng.choice([0.05, 0.4])))
+    sc = syn.random_scene(P, seed=seed, scale_lo=lo, scale_hi=hi, opacity_lo=op_lo, opacity_hi=op_hi)
+    cam = syn.orbit_camera(int(rng.integers(0, 8)), width=W, height=H, radius=float(rng.choice([1.5, 3.0, 6.0])))
+    bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
+    kw = settings_kwargs(cam, bg, antialiasing=aa, sh_degree=deg, scale_modifier=float(rng.choice([1.0, 0.6, 1.8])))
+    inputs = dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+    tag = f"P={P} {W}x{H} deg={deg} aa={aa} scale=[{lo},{hi}] op=[{op_lo},{op_hi}]"
+    return inputs, kw, tag, rng
 
 
 def excused_rows(details):
@@ -169,6 +225,7 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
                 bad = bad & ~(row_alt & agrees)
         n_out = int(bad.sum())
         unexplained, worst = n_out, 0.0
+        ref_n, ref_q, q64 = 0, 0.0, None
         if n_out and go64 is not None and go64.get(k) is not None:
             t = np.asarray(go64[k], np.float64).reshape(b.shape)
             s64 = float(np.abs(t).max())
@@ -176,9 +233,15 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
             # the float32 oracle's own error, taken per ROW (per Gaussian / vertex: conditioning -- a flat covariance, a
             # cancelling conic gradient -- is a property of the row, and the rounding of one component can be lucky)
             e32 = np.abs(b.astype(np.float64) - t)
-            if go32acc is not None and go32acc.get(k) is not None:
-                # ... or of the float32 oracle that also ACCUMULATES in float32 (the default build sums in double)
-                e32 = np.maximum(e32, np.abs(np.asarray(go32acc[k], np.float64).reshape(b.shape) - t))
+            tol64 = np.abs(t) + 1e-3 * s64
+            ref_n, ref_q = int((e32 / tol64 > GRAD_REL).sum()), float(np.quantile(e32 / tol64, q))
+            # ... or of the other float32 realisations (float32 accumulators; FMA-contracted backward)
+            for r in ([go32acc] if isinstance(go32acc, dict) else (go32acc or [])):
+                if r.get(k) is not None:
+                    e_r = np.abs(np.asarray(r[k], np.float64).reshape(b.shape) - t)
+                    ref_n, ref_q = max(ref_n, int((e_r / tol64 > GRAD_REL).sum())), max(ref_q, float(np.quantile(e_r / tol64, q)))
+                    e32 = np.maximum(e32, e_r)
+            q64 = float(np.quantile(np.abs(a.astype(np.float64) - t) / tol64, q))
             if e32.ndim > 1:
                 e32 = np.broadcast_to(e32.reshape(e32.shape[0], -1).max(axis=1).reshape((-1,) + (1,) * (e32.ndim - 1)), e32.shape)
             e_o32 = e32[bad]
@@ -198,8 +261,32 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
         q_clean = float(np.quantile(rel[clean_mask], q)) if clean_mask.any() else 0.0
         rep[k] = dict(scale=scale, max_abs=float(err.max()), q_rel=float(np.quantile(rel, q)), q_rel_clean=q_clean, max_rel=float(rel.max()),
                       frac_bad=float(bad.mean()), outliers=n_out, unexplained=unexplained, zero_violation=False,
-                      worst_ratio=worst, excused=n_exc, alt_explained=n_alt, size=int(b.size))
+                      worst_ratio=worst, excused=n_exc, alt_explained=n_alt, size=int(b.size),
+                      ref_outliers=ref_n, ref_q=ref_q, q_rel64=q64)
     return rep
+
+
+def grad_fails(v):
+    """The assertions of `assert_grads` on one tensor's report, as a list of the rules it breaks (empty = passes)."""
+    out = []
+    if v["zero_violation"]:
+        out.append("zero_violation")
+    # explained outliers must stay rare: a fixed cap, or -- where the float32 oracle's own realisations leave the 1e-3 band
+    # against float64 on this tensor -- COND_COUNT x their count
+    if v["outliers"] > max(RARE_MIN, int(RARE_FRAC * v["size"]), int(COND_COUNT * v.get("ref_outliers", 0))):
+        out.append("outliers")
+    # entries that needed the excused-row or the alternate-outcome rule are counted and capped too
+    if v.get("excused", 0) + v.get("alt_explained", 0) > max(RARE_MIN, int(ROW_FRAC * v["size"])):
+        out.append("excused_rows")
+    # the 0.999 quantile against the float32 oracle (below 8000 entries over the non-excused entries: for < 1000 entries
+    # it is their maximum); where it is exceeded, HIP's quantile error against FLOAT64 must be within COND_Q x the float32
+    # oracle's own
+    q_ok = v["q_rel"] <= GRAD_REL or v["size"] < Q_MIN_SIZE or (v["size"] < 8000 and v.get("q_rel_clean", v["q_rel"]) <= GRAD_REL)
+    if not q_ok and not (v.get("q_rel64") is not None and v["q_rel64"] <= COND_Q * v.get("ref_q", 0.0)):
+        out.append("quantile")
+    if v["unexplained"] > int(UNEXPLAINED_PER_MILLION * 1e-6 * v["size"]):
+        out.append("unexplained")
+    return out
 
 
 def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_fn=None, alt=None):
@@ -213,18 +300,8 @@ def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_f
         rep = grad_report(gh, go, q=q, go64=go64_fn(), excuse=excuse, go32acc=go32acc_fn() if go32acc_fn is not None else None,
                           alt_rows=alt_rows, alts=alts)
     for k, v in rep.items():
-        assert not v["zero_violation"], (where, k, v)
-        # explained outliers must stay rare (float32 conditioning is the exception, not the rule: <= 1 % of a tensor -- the fuzz
-        # sweep's worst populations, faint large splats, reach 0.5 % of the rotation gradients at error ratios 1-3 against the
-        # float32 oracle); on tensors of a few hundred
-        # entries the 0.999 quantile IS the maximum, so the rarity rule is a count there
-        assert v["outliers"] <= max(RARE_MIN, int(RARE_FRAC * v["size"])), (where, k, v)
-        # entries that needed the excused-row or the alternate-outcome rule are counted and capped too
-        assert v.get("excused", 0) + v.get("alt_explained", 0) <= max(RARE_MIN, int(ROW_FRAC * v["size"])), (where, k, v)
-        # small tensors: the quantile over the non-excused entries (for < 1000 entries it is their maximum)
-        assert v["q_rel"] <= GRAD_REL or v["size"] < Q_MIN_SIZE or \
-            (v["size"] < 8000 and v.get("q_rel_clean", v["q_rel"]) <= GRAD_REL), (where, k, v)
-        assert v["unexplained"] <= int(UNEXPLAINED_PER_MILLION * 1e-6 * v["size"]), (where, k, v)
+        broken = grad_fails(v)
+        assert not broken, (where, k, broken, v)
     _log_parity(where, rep)
     return rep
 

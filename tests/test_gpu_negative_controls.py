@@ -46,7 +46,7 @@ def _case(P, seed, W, H, **scene_kw):
 def _assert(inputs, kw, gc, o, h, where):
     return U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, precision="f64")["grads"], where=where,
                           excuse=U.excused_rows(o["details"]),
-                          go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, precision="f32acc")["grads"],
+                          go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc),
                           alt=U.alt_oracles(inputs, kw, gc, None, o["details"]))
 
 

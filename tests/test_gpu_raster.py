@@ -32,7 +32,7 @@ def _check(inputs, kw, W, H, gd=True, q=0.999):
     assert rep["max_amb"] <= 0.02, rep          # a flipped alpha>=1/255 decision moves a pixel by < 1/255 * max colour
     g = U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f64")["grads"], q=q,
                        where=f"P={inputs['means3D'].shape[0]} {W}x{H}", excuse=U.excused_rows(o["details"]),
-                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f32acc")["grads"],
+                       go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, gdm),
                        alt=U.alt_oracles(inputs, kw, gc, gdm, o["details"]))
     return h, o, rep, g
 
@@ -286,7 +286,7 @@ def test_repeated_backward_reuses_the_rezeroed_gradient_records():
         gc_w, gd_w = (gc, None) if which == "a" else (-2.0 * gc, gdm)
         U.assert_grads(h["grads"], ref["grads"], lambda: U.oracle_render(inputs, kw, gc_w, gd_w, precision="f64")["grads"],
                        where=f"repeat {which}", excuse=U.excused_rows(ref["details"]),
-                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc_w, gd_w, precision="f32acc")["grads"],
+                       go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc_w, gd_w),
                        alt=U.alt_oracles(inputs, kw, gc_w, gd_w, ref["details"]))
 
 
@@ -387,7 +387,7 @@ def test_unit_count_overflow_reruns_with_full_size_launches():
     rep = U.forward_report(h, o, 416, 400)
     assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["max_amb"] <= 0.02, rep
     U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"], where="unit overflow",
-                   excuse=U.excused_rows(o["details"]), go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, None, precision="f32acc")["grads"],
+                   excuse=U.excused_rows(o["details"]), go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, None),
                    alt=U.alt_oracles(inputs, kw, gc, None, o["details"]))
 
 
@@ -433,7 +433,7 @@ def test_config5_size_parity_deep_tiles_two_phase_products():
         assert last_stats()["num_rendered"] == det["N"]
         U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"],
                        where=f"c5_flame_like_1m {size}x{size} frame {frame}", excuse=U.excused_rows(det),
-                       go32acc_fn=lambda: U.oracle_render(inputs, kw, gc, None, precision="f32acc")["grads"],
+                       go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, None),
                        alt=U.alt_oracles(inputs, kw, gc, None, det))
         assert float(U.excused_rows(det).mean()) < 0.02
     # (3) K0 backward at this size, upstream = the oracle's rasterizer gradients
