@@ -1,10 +1,12 @@
-# Round-3 evidence run (GPU box): full GPU suite, headline bench, secondary lines, rocprofv3 + PMC passes.
+# Round-3 evidence run (GPU box): rocprofv3 + PMC passes first (so the bench lines carry counters of THIS build), full GPU
+# suite, headline bench, secondary lines.
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-T=${1:-r03v2}
-python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_pytest_gpu.log
-tail -3 gpurun_out/${T}_pytest_gpu.log
+T=${1:-r03v3}
+bash tools/collect_profiles.sh $T > gpurun_out/${T}_collect.log 2>&1
+python tools/make_pmc_traffic.py gpurun_out/${T}_rocprofv3_summary_traffic.json c2_hotdog_like/trained - profiles/r02_blend_stats_c2.json > gpurun_out/${T}_make_pmc.log 2>&1
+cp profiles/pmc_traffic.json gpurun_out/pmc_traffic.json
 python bench.py --steps 200 --warmup 20 > gpurun_out/${T}_bench_full.json.log 2> gpurun_out/${T}_bench_full.err
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --loss l1_ssim --optimizer fused_adam > gpurun_out/${T}_bench_full_iteration.json.log 2>&1
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload c4_ficus_like > gpurun_out/${T}_bench_c4_single_gpu.json.log 2>&1
@@ -12,6 +14,9 @@ python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_lik
 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_1m --mode animate > gpurun_out/${T}_bench_c5_1m_animate.json.log 2>&1
 GMS_BENCH_FORCE_DDP=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload c4_ficus_like --profile-steps 0 > gpurun_out/${T}_bench_one_rank_rccl.json.log 2>&1
 python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --profile-steps 0 > gpurun_out/${T}_bench_gpus2_shared.json.log 2>&1
-bash tools/collect_profiles.sh $T > gpurun_out/${T}_collect.log 2>&1
 grep -h -o '"value": [0-9.]*' gpurun_out/${T}_bench_*.json.log
+grep -h -o '"roofline": {[^}]*}' gpurun_out/${T}_bench_full.json.log | cut -c1-300
 grep -E "^(micro|blend|tile_|preprocess|emit|mesh)" gpurun_out/${T}_rocprofv3_summary.txt | head -14 | cut -c1-130
+rm -f gpurun_out/parity_report.jsonl
+python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_pytest_gpu.log
+tail -3 gpurun_out/${T}_pytest_gpu.log
