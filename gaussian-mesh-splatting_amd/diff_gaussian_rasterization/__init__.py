@@ -98,6 +98,16 @@ _capacity_cache = {}
 _last_stats = {}
 
 
+def _quantize_capacity(x: int) -> int:
+    """Round a capacity hint UP to four significant bits (steps of 6-12 %): the binning buffer is sized by the hint, and a size
+    that creeps up frame by frame (an animated mesh growing 0.5 % per frame) would be a fresh hipMalloc in the caching
+    allocator on every frame.  Same rule as torch_binding.cpp::quantize_capacity."""
+    if x < 16:
+        return x
+    s = x.bit_length() - 1 - 3
+    return ((x + (1 << s) - 1) >> s) << s
+
+
 def set_capacity_hint(device_index: int, width: int, height: int, P: int, value: int) -> None:
     """Overwrite the learnt instance count the next forward of this (device, W, H, P) sizes its binning buffer from
     (x1.25 + 4096); `value` < 0 forgets it.  Tests use it to force the overflow re-run."""
@@ -324,7 +334,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if os.environ.get("GMS_SYNC_BINNING", "0") != "1":
             prev = _capacity_cache.get(key)
             if prev is not None:
-                hint = int(prev * 1.25) + 4096
+                hint = _quantize_capacity(int(prev * 1.25) + 4096)
         num_units = C.c_int64(0)
         a = _lib.RasterForwardArgs(
             P=P, D=int(rs.sh_degree), M=M, width=W, height=H,
