@@ -36,7 +36,12 @@
 // (no gain: the gather latency is already covered by the resident waves); fixed-quadrant rows instead of sorted ones (+6 us);
 // part of the ten sums by global atomics and part through the LDS table (+4 us); every non-first segment composited locally
 // from T = 1 and walked again only where a pixel can stop inside it (no gain: on the headline scene most later segments
-// hold a stopping pixel).
+// hold a stopping pixel); one gradient table per WAVE with a plain LDS read-add-write instead of ds_add_f32 (same-entry rows
+// inside one instruction are rare -- 2.8 % of the trips, tools/row_collisions.py -- and were sent to the atomic): 191 us
+// against 177 us for the atomic kernel padded to the same 52 KB of LDS (3 blocks per CU), 143 us at its own 25 KB (6 per CU);
+// 8-entry instead of 16-entry queues (18.9 KB, 8 blocks per CU): 144.7 against 142 us, the refills double.
+// The backward is bound by dependent latency, not by LDS atomic throughput: blocks per CU 3 / 4 / 5 / 6 -> 177 / 156 / 147 /
+// 143 us (unused dynamic LDS as the only change), VALU issue 0.28 of peak, 57 % of the wave cycles in s_waitcnt.
 #include <stdlib.h>
 
 #include "gms_common.h"
