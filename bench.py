@@ -140,16 +140,15 @@ def cpu_baseline(workload, state, max_seconds=12.0):
 
 
 def kernel_source_hash():
-    """sha256 (16 hex) over the kernel sources: profiles/pmc_traffic.json records the hash of the build its counters were
-    collected on (tools/make_pmc_traffic.py); counters from another build are NOT reported against this build's durations."""
-    import hashlib
-    d = os.path.join(ROOT, "gaussian-mesh-splatting_amd", "csrc")
-    h = hashlib.sha256()
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """sha256 (16 hex) over the kernel sources, comments stripped (tools/srchash.py): profiles/pmc_traffic.json records the
+    hash of the build its counters were collected on (tools/make_pmc_traffic.py); counters from another build are NOT
+    reported against this build's durations."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import srchash
+    finally:
+        sys.path.pop(0)
+    return srchash.kernel_source_hash()
 
 
 BASELINE_METRIC = "train iters/s (fwd+bwd raster) @800×800, 300k Gaussians; HBM GB/s vs roofline"

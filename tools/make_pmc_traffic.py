@@ -40,14 +40,9 @@ if stats_path and os.path.exists(stats_path):
                 sqo[k]["active_lane_frac"] = round(st["blocks"]["4x4"]["active_lane_frac_exact"], 3)      # micro-tile rows
 out["_sq"] = sqo
 # the build the counters belong to: bench.py withholds them from any other build (same hash function as bench.py)
-import hashlib
-_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gaussian-mesh-splatting_amd", "csrc")
-_h = hashlib.sha256()
-for _name in sorted(os.listdir(_d)):
-    if _name.endswith((".hip", ".h")):
-        with open(os.path.join(_d, _name), "rb") as _f:
-            _h.update(_name.encode() + b"\0" + _f.read())
-out["_source_hash"] = _h.hexdigest()[:16]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import srchash
+out["_source_hash"] = srchash.kernel_source_hash()
 allj = json.load(open(dst)) if os.path.exists(dst) else {}
 allj[key] = out
 allj["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB->bytes) from separate rocprofv3 --pmc passes; "
