@@ -56,6 +56,10 @@ struct BlendBwdArgs {
 // and in the length of the finalize / suffix chains) -- and leaves it in scan_out[3], where every later kernel of the
 // frame, forward and backward, reads it.  Buffers are sized for the shortest L that can be chosen.
 constexpr uint32_t SEG_LEN_SHALLOW = 128, SEG_LEN_DEEP = 256, SEG_DEEP_PER_TILE = 512;
+// Very deep scenes (config-5 size: 2 880 entries per tile, tiles up to 26 k): 512-entry segments -- measured at 997 600
+// Gaussians / 1024^2, forward-only renders/s 700 / 735 / 698 / 714 / 680 / 579 at L = 256 / 512 / 768 / 1024 / 1536 / 2048,
+// fwd+bwd 428 / 430 it/s at 256 / 512.
+constexpr uint32_t SEG_LEN_VERY_DEEP = 512, SEG_VERY_DEEP_PER_TILE = 2048;
 // Micro-tile compositing (blend_micro.hip; GMS_MICRO=0 selects the quadrant-wave kernels of blend.hip): one segment length
 // for every frame (GMS_SEG_LEN, default SEG_LEN_MICRO, at most 256: a block's list holds entry indices within the unit, one byte each).
 constexpr uint32_t SEG_LEN_MICRO = 256;

@@ -459,7 +459,8 @@ __global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(uint32_t *count
         __syncthreads();
         uint64_t total = 0;
         for (int w = 0; w < SCAN_THREADS / WAVE; w++) total += wave_n[w];
-        L = total > (uint64_t)SEG_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_DEEP : SEG_LEN_SHALLOW;
+        L = total > (uint64_t)SEG_VERY_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_VERY_DEEP
+          : total > (uint64_t)SEG_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_DEEP : SEG_LEN_SHALLOW;
     }
     uint32_t run[NSCAN], own[NSCAN];
     uint32_t deepest = 0;
@@ -1150,6 +1151,15 @@ uint32_t seg_len_forced()
     return (uint32_t)L;
 }
 uint32_t seg_len_min() { const uint32_t f = seg_len_forced(); return f ? f : SEG_LEN_SHALLOW; }
+// The L handed to the tile scan.  Micro-tile mode pins one L (<= 256) for the frames its kernels take; a frame whose
+// binning capacity says "very deep" goes to the quadrant kernels anyway (use_micro) and gets their long segments
+// (capacity > SEG_VERY_DEEP_PER_TILE * T implies capacity > 512 * T: never a micro frame).  GMS_SEG_LEN overrides everything.
+static uint32_t seg_len_for_frame(uint64_t capacity_hint, int T)
+{
+    const uint32_t f = seg_len_forced();
+    if (f == 0 || getenv("GMS_SEG_LEN")) return f;
+    return capacity_hint > (uint64_t)SEG_VERY_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_VERY_DEEP : f;
+}
 
 uint32_t unit_run()
 {
@@ -1332,7 +1342,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     static thread_local int32_t seq_counter = 0;
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, img.class_first, T, seg_len_forced(),
+                                                                                   img.unit_first, img.mseg_first, img.class_first, T, seg_len_for_frame((uint64_t)A->binning_capacity_hint, T),
                                                                                    slot, seq, sort_np, img.scan_out));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
     ctr->dirty = false;
