@@ -8,8 +8,9 @@ rasterizer deliberately deviates from naive autograd ar
   (ii)  cull / skip / stop tests are constants,
   (iv)  the t.x/t.z frustum clamp passes gradient only inside the limit and never to t.z,
   (x)   means2D receives d loss / d NDC (pixel-gradient * W/2, H/2).
-Not encoded (documented difference, bounded by 1e-7/det^2 relative): the `1/(det^2+1e-7)`
-regularised conic backward (A.5 vi) -- autograd uses the exact 1/det^2.
+  (vi)  the conic's backward divides by det^2 + 1e-7 instead of det^2 (`_RegularisedConic`: the three published lines;
+        `regularised_conic=False` gives the exact derivative -- the two differ by up to 1e-7/det^2 relative, i.e. ~1e-5 for
+        the smallest splats, whose det is ~0.09 after the 0.3 dilation).
 
 In-tree sub-stages restated with a device/dtype argument because the originals hard-code
 device="cuda": cov3D (scene/gaussian_model.py:27-31 + utils/general_utils.py:144-190) and
@@ -25,6 +26,27 @@ SH_C1 = 0.4886025119029199
 SH_C2 = [1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396]
 SH_C3 = [-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154,
          -0.4570457994644658, 1.445305721320277, -0.5900435899266435]
+
+
+class _RegularisedConic(torch.autograd.Function):
+    """conic = (c, -b, a) / det with the published backward (SURVEY.md appendix A.5 vi): 1 / (det^2 + 1e-7) in place of
+    1 / det^2.  The incoming gradient of the off-diagonal entry is the TRUE one here (the kernels store half of it)."""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        det = a * c - b * b
+        ctx.save_for_backward(a, b, c, det)
+        return c / det, -b / det, a / det
+
+    @staticmethod
+    def backward(ctx, gA, gB_true, gC):
+        a, b, c, det = ctx.saved_tensors
+        gB = 0.5 * gB_true
+        d2 = 1.0 / (det * det + 1e-7)
+        da = d2 * (-c * c * gA + 2 * b * c * gB + (det - a * c) * gC)
+        dc = d2 * (-a * a * gC + 2 * a * b * gB + (det - a * c) * gA)
+        db = d2 * 2 * (b * c * gA - (det + 2 * b * b) * gB + a * b * gC)
+        return da, db, dc
 
 
 def build_rotation_unnormalised(q):
@@ -78,7 +100,7 @@ def sh_colors_python(sh_degree, shs, means3D, campos):
 
 def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
                     cov3D_precomp=None, *, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier=1.0,
-                    viewmatrix, projmatrix, sh_degree=0, campos, antialiasing=False):
+                    viewmatrix, projmatrix, sh_degree=0, campos, antialiasing=False, regularised_conic=True):
     """Differentiable dense forward.  Returns (color[3,H,W], radii[P], invdepth[1,H,W])."""
     dt = means3D.dtype
     P = means3D.shape[0]
@@ -123,7 +145,11 @@ def rasterize_dense(means3D, means2D, opacities, shs=None, colors_precomp=None, 
         hconv = torch.sqrt(torch.clamp_min(det0 / det, 0.000025))
     visible = visible & (det != 0).detach()
     det_safe = torch.where(visible, det, torch.ones_like(det))
-    cA, cB, cC = c / det_safe, -b / det_safe, a / det_safe
+    if regularised_conic:
+        one, nil = torch.ones_like(det), torch.zeros_like(det)
+        cA, cB, cC = _RegularisedConic.apply(torch.where(visible, a, one), torch.where(visible, b, nil), torch.where(visible, c, one))
+    else:
+        cA, cB, cC = c / det_safe, -b / det_safe, a / det_safe
     with torch.no_grad():
         mid = 0.5 * (a + c)
         lam = mid + torch.sqrt(torch.clamp_min(mid * mid - det, 0.1))
