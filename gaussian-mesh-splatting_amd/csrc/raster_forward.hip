@@ -1157,7 +1157,7 @@ uint32_t seg_len_min() { const uint32_t f = seg_len_forced(); return f ? f : SEG
 static uint32_t seg_len_for_frame(uint64_t capacity_hint, int T)
 {
     const uint32_t f = seg_len_forced();
-    if (f == 0 || getenv("GMS_SEG_LEN")) return f;
+    if (f == 0 || getenv("GMS_SEG_LEN") || micro_setting() == 1) return f;      // (GMS_MICRO=1 forces the micro kernels on every frame)
     return capacity_hint > (uint64_t)SEG_VERY_DEEP_PER_TILE * (uint64_t)T ? SEG_LEN_VERY_DEEP : f;
 }
 

@@ -348,6 +348,35 @@ def test_tuning_knobs_do_not_change_results(env):
     assert r.returncode == 0 and "knob ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("env", [{}, {"GMS_MICRO": "1"}, {"GMS_MICRO": "0"}, {"GMS_MICRO": "1", "GMS_SEG_LEN": "128"}])
+def test_very_deep_frames_keep_a_segment_length_their_kernels_support(env):
+    """6 000 large splats on 9 tiles: ~6 000 list entries per tile, beyond SEG_VERY_DEEP_PER_TILE.  The second call has the
+    capacity hint that moves very deep frames to 512-entry segments -- which only the quadrant kernels can take (the
+    micro-tile kernels index a unit's entries with one byte): auto mode must switch kernels with the segment length,
+    GMS_MICRO=1 must keep its own L.  (A forced-micro run at config-5 size failed on exactly this in round 3.)"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, torch\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import conftest\n"
+        "import test_gpu_raster as T\n"
+        "from games_hip import synthetic as syn\n"
+        "import _util as U\n"
+        "import diff_gaussian_rasterization as dgr\n"
+        "sc, cam = syn.random_scene(6000, seed=33, extent=0.5, scale_lo=0.08, scale_hi=0.4, opacity_lo=0.02, opacity_hi=0.3), syn.orbit_camera(3, width=48, height=48, radius=2.0)\n"
+        "for call in range(3):\n"
+        "    h, o, rep, g = T._check(T._inputs(sc), U.settings_kwargs(cam, torch.tensor([0.3, 0.1, 0.2])), 48, 48)\n"
+        "assert o['N'] > 2048 * 9 * 1.3, o['N']\n"
+        "assert dgr.last_stats()['capacity_hint'] > 2048 * 9\n"
+        "print('deep ok')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "deep ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_visibility_filter_from_the_preprocess_kernel_equals_radii_positive():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     sc, cam = syn.random_scene(5000, seed=31, scale_lo=0.01, scale_hi=0.1), syn.orbit_camera(3, width=128, height=96, radius=1.2)
