@@ -1341,8 +1341,9 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     if (deepest_seen > (uint32_t)SORT_BIG_CHUNK) sort_np = sort_passes((uint64_t)deepest_seen + deepest_seen / 4);
     static thread_local int32_t seq_counter = 0;
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
+    const uint32_t frame_L = seg_len_for_frame((uint64_t)A->binning_capacity_hint, T);      // 0: the scan chooses from the depth
     GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, img.class_first, T, seg_len_for_frame((uint64_t)A->binning_capacity_hint, T),
+                                                                                   img.unit_first, img.mseg_first, img.class_first, T, frame_L,
                                                                                    slot, seq, sort_np, img.scan_out));
     GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
     ctr->dirty = false;
@@ -1398,7 +1399,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
         g.mlist = bin.mlist; g.mcount = bin.mcount;
         if (aux) GMS_HIP_CHECK(hipStreamWaitEvent(stream, aux->join, 0));      // the colours (second stream) before the compositing
-        if (use_micro(capacity, T)) return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
+        if (use_micro(capacity, T)) {
+            // the micro-tile kernels index a unit's entries with one byte: never launch them on a frame whose L they cannot hold
+            if (frame_L == 0 || frame_L > SEG_LEN_MICRO) {
+                set_error("internal: micro-tile compositing chosen for a frame with segment length %u", frame_L);
+                return GMS_ERR_INVALID_ARGUMENT;
+            }
+            return launch_micro_forward(g, bo, mu_launch, A->debug != 0, stream);
+        }
         return launch_blend_forward(g, bo, mu_launch, A->debug != 0, stream);
     };
 
