@@ -1,0 +1,191 @@
+"""CPU emulation of the two conservative culls of the compositing kernels against the per-pixel test they must never
+contradict (no GPU; numpy float32 arithmetic in the kernels' operation order):
+
+  * `gms_blend.h::rect_hit`     -- ellipse {alpha >= 1/255} against a wave's 8x8 quadrant (quadrant kernels, blend.hip)
+  * `blend_micro.hip::block_mask` -- against the sixteen 4x4 blocks of a tile (micro-tile kernels)
+
+Property: if ANY pixel of the rectangle accepts the splat (`pair_power <= 0` and `op * exp(power) >= 1/255`, evaluated with the
+documented float32 chain of `gms_blend.h::pair_power`, the exp taken with a 4e-6 relative margin for `__expf`), the cull keeps
+the pair.  Records are built as `preprocess_fwd` builds them (conic and extents from the dilated covariance in float32).  The
+culls are evaluated in two rounding realisations -- plain float32 and float64 on the same float32 records -- because hipcc is
+free to contract their expressions into FMAs.  Per test 2 x 10^5 splats, half of them ordinary (sigma 0.55 ... 400 px, aspect
+ratios up to 700, centres up to 1 200 px outside the tile, tile origins up to 4 000 px, opacities from below 1/255 to 1, a
+share of them at the threshold), half long, thin and far (`make_thin_far_records`).  The second half is what found, in round
+3, that a bounding box of the EXACT ellipse is not conservative: beyond the tip of a 1 000-px splat the float32 exponent's own
+noise accepts pixels up to ~250 px outside the box; boxes larger than HUGE_EXTENT are now re-tested with the inflated threshold."""
+import numpy as np
+
+F = np.float32
+
+
+def fma32(a, b, c):
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(F)
+
+
+def make_records(n, seed):
+    rng = np.random.default_rng(seed)
+    s1 = np.exp(rng.uniform(np.log(0.55), np.log(400.0), n))
+    s2 = np.exp(rng.uniform(np.log(0.55), np.log(s1)))
+    th = rng.uniform(0, np.pi, n)
+    c, s = np.cos(th), np.sin(th)
+    a = (c * c * s1 * s1 + s * s * s2 * s2).astype(F)          # dilated covariance (sigma >= sqrt(0.3))
+    b = (c * s * (s1 * s1 - s2 * s2)).astype(F)
+    d = (s * s * s1 * s1 + c * c * s2 * s2).astype(F)
+    det = (a * d - b * b).astype(F)
+    ok = det > 0
+    cA, cB, cC = (d / det).astype(F), (-b / det).astype(F), (a / det).astype(F)
+    op = rng.uniform(0.8 / 255, 1.0, n)
+    k = rng.integers(0, 4, n)
+    op = np.where(k == 0, (1.0 / 255) * (1 + rng.uniform(-2e-3, 5e-2, n)), op)      # at the threshold
+    op = np.where(k == 1, rng.uniform(0.003, 0.02, n), op).astype(F)                   # faint
+    tau = np.log(F(255.0) * op).astype(F)
+    with np.errstate(invalid="ignore"):
+        ex = np.where(tau < F(-1e-3), F(-1e30), np.sqrt(F(2) * a * (tau + F(1e-3)))).astype(F)
+        ey = np.where(tau < F(-1e-3), F(-1e30), np.sqrt(F(2) * d * (tau + F(1e-3)))).astype(F)
+    tx0 = (16 * rng.integers(0, 250, n)).astype(F)
+    ty0 = (16 * rng.integers(0, 250, n)).astype(F)
+    reach = 3.2 * s1 * rng.uniform(0, 1.2, n) ** 2
+    ang = rng.uniform(0, 2 * np.pi, n)
+    px = (tx0 + 8 + (8 + reach) * np.cos(ang) * rng.uniform(0, 1, n)).astype(F)
+    py = (ty0 + 8 + (8 + reach) * np.sin(ang) * rng.uniform(0, 1, n)).astype(F)
+    keep = ok & np.isfinite(cA) & np.isfinite(cC)
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+
+
+def pixel_accepts(px, py, A, B, C, op, tx0, ty0):
+    """[n, 16, 16] (row y, column x): the kernels' per-pixel decision, a superset by the exp margin."""
+    xs = (tx0[:, None, None] + np.arange(16, dtype=F)[None, None, :]).astype(F)
+    ys = (ty0[:, None, None] + np.arange(16, dtype=F)[None, :, None]).astype(F)
+    dx = (px[:, None, None] - xs).astype(F) + np.zeros_like(ys)
+    dy = (py[:, None, None] - ys).astype(F) + np.zeros_like(xs)
+    Ab, Bb, Cb = (np.broadcast_to(v[:, None, None], dx.shape) for v in (A, B, C))
+    inner = fma32((Ab * dx).astype(F), dx, ((Cb * dy).astype(F) * dy).astype(F))
+    power = fma32(np.full(dx.shape, F(-0.5)), inner, -((Bb * dx).astype(F) * dy).astype(F))
+    alpha = op[:, None, None].astype(np.float64) * np.exp(power.astype(np.float64)) * (1 + 4e-6)
+    return (power <= 0) & (alpha >= 1.0 / 255.0)
+
+
+HUGE_EXTENT = 256.0
+
+
+def rect_hit(px, py, A, B, C, op, ex, ey, wx0, wy0, wx1, wy1, dt):
+    px, py, A, B, C, op, ex, ey, wx0, wy0, wx1, wy1 = (v.astype(dt) for v in (px, py, A, B, C, op, ex, ey, wx0, wy0, wx1, wy1))
+    out = (px + ex < wx0) | (px - ex > wx1) | (py + ey < wy0) | (py - ey > wy1)
+    small_out = out & (np.maximum(ex, ey) <= dt(HUGE_EXTENT))
+    dx0, dx1, dy0, dy1 = wx0 - px, wx1 - px, wy0 - py, wy1 - py
+    inside = (dx0 <= 0) & (dx1 >= 0) & (dy0 <= 0) & (dy1 >= 0)
+    thr = (2 * (np.log(dt(255.0) * op) + dt(1e-3))).astype(dt)
+    B2 = 2 * B
+    mx, my = np.maximum(np.abs(dx0), np.abs(dx1)), np.maximum(np.abs(dy0), np.abs(dy1))
+    gross = mx * (A * mx + np.abs(B2) * my) + C * my * my
+    thr2 = thr * dt(1.0001) + dt(0.01) + dt(4e-6) * gross
+    g = np.sqrt(thr2 * (1 / thr).astype(dt)).astype(dt)
+    exg, eyg = ex * g, ey * g
+    big_out = out & (~(thr > dt(1e-4)) | (px + exg < wx0) | (px - exg > wx1) | (py + eyg < wy0) | (py - eyg > wy1))
+    iA, iC = (1 / A).astype(dt), (1 / C).astype(dt)
+    ya = np.minimum(np.maximum(-B * dx0 * iC, dy0), dy1); yb = np.minimum(np.maximum(-B * dx1 * iC, dy0), dy1)
+    xa = np.minimum(np.maximum(-B * dy0 * iA, dx0), dx1); xb = np.minimum(np.maximum(-B * dy1 * iA, dx0), dx1)
+    e0 = dx0 * (A * dx0 + B2 * ya) + C * ya * ya; e1 = dx1 * (A * dx1 + B2 * yb) + C * yb * yb
+    e2 = xa * (A * xa + B2 * dy0) + C * dy0 * dy0; e3 = xb * (A * xb + B2 * dy1) + C * dy1 * dy1
+    qmin = np.minimum(np.minimum(e0, e1), np.minimum(e2, e3))
+    return ~small_out & (inside | (~big_out & (qmin <= thr2)))
+
+
+def block_mask(px, py, A, B, C, op, ex, ey, tx0, ty0, dt):
+    """[n, 4, 4] (band by, column block bx)."""
+    px, py, A, B, C, op, ex, ey, tx0, ty0 = (v.astype(dt) for v in (px, py, A, B, C, op, ex, ey, tx0, ty0))
+    n = px.shape[0]
+    thr = (2 * (np.log(dt(255.0) * op) + dt(1e-3))).astype(dt)
+    out = (px + ex < tx0) | (px - ex > tx0 + 15) | (py + ey < ty0) | (py - ey > ty0 + 15)
+    small_out = out & (np.maximum(ex, ey) <= dt(HUGE_EXTENT))
+    m = np.zeros((n, 4, 4), bool)
+    x0 = tx0[:, None] + 4 * np.arange(4, dtype=dt)[None, :]
+    y0 = ty0[:, None] + 4 * np.arange(4, dtype=dt)[None, :]
+    # (a) threshold within rounding of the centre: bounding box per block
+    yhit = ~((py[:, None] + ey[:, None] < y0) | (py[:, None] - ey[:, None] > y0 + 3))
+    xhit = ~((px[:, None] + ex[:, None] < x0) | (px[:, None] - ex[:, None] > x0 + 3))
+    tiny = ~(thr > dt(1e-4))
+    m_tiny = yhit[:, :, None] & xhit[:, None, :]
+    # (b) band intervals
+    with np.errstate(all="ignore"):
+        mx = np.maximum(np.abs(tx0 - px), np.abs(tx0 + 15 - px)); my = np.maximum(np.abs(ty0 - py), np.abs(ty0 + 15 - py))
+        gross = mx * (A * mx + 2 * np.abs(B) * my) + C * my * my
+        thr2 = thr * dt(1.0001) + dt(0.01) + dt(4e-6) * gross
+        grow = thr2 * (1 / thr).astype(dt)
+        g = np.sqrt(grow).astype(dt)
+        big_out = out & ((px + ex * g < tx0) | (px - ex * g > tx0 + 15) | (py + ey * g < ty0) | (py - ey * g > ty0 + 15))
+        iA, iC = (1 / A).astype(dt), (1 / C).astype(dt)
+        AT = A * thr2
+        inv_ey2 = (1 / (ey * ey * grow)).astype(dt)
+        dyR = -B * ex * np.sqrt(grow).astype(dt) * iC
+        dya = y0 - py[:, None]; dyb = dya + 3
+        c1 = np.minimum(np.maximum(dyR[:, None], dya), dyb); c2 = np.minimum(np.maximum(-dyR[:, None], dya), dyb)
+        D1 = AT[:, None] * (1 - c1 * c1 * inv_ey2[:, None]); D2 = AT[:, None] * (1 - c2 * c2 * inv_ey2[:, None])
+        band = D1 >= 0
+        xr = px[:, None] + (np.sqrt(np.maximum(D1, 0)).astype(dt) - B[:, None] * c1) * iA[:, None] + dt(1e-3)
+        xl = px[:, None] - (np.sqrt(np.maximum(D2, 0)).astype(dt) + B[:, None] * c2) * iA[:, None] - dt(1e-3)
+    m_band = band[:, :, None] & (xr[:, :, None] >= x0[:, None, :]) & (xl[:, :, None] <= x0[:, None, :] + 3)
+    m = np.where(tiny[:, None, None], m_tiny & ~out[:, None, None], m_band & ~big_out[:, None, None])
+    return m & ~small_out[:, None, None]
+
+
+def make_thin_far_records(n, seed):
+    """Long thin splats (sigma_1 30 ... 10 000 px, sigma_2 0.55 ... 3 px) with the tile placed ALONG the major axis up to three
+    sigma_1 from the centre: the regime where the per-pixel exponent is a difference of terms ~10^7 and its float32 noise
+    accepts pixels far outside the exact ellipse (up to ~250 px beyond its bounding box at sigma_1 = 1 000)."""
+    rng = np.random.default_rng(seed)
+    s1 = np.exp(rng.uniform(np.log(30.0), np.log(10000.0), n)); s2 = np.exp(rng.uniform(np.log(0.55), np.log(3.0), n))
+    th = rng.uniform(0, np.pi, n)
+    c, s = np.cos(th), np.sin(th)
+    a = (c * c * s1 * s1 + s * s * s2 * s2).astype(F); b = (c * s * (s1 * s1 - s2 * s2)).astype(F); d = (s * s * s1 * s1 + c * c * s2 * s2).astype(F)
+    with np.errstate(all="ignore"):
+        det = (a * d - b * b).astype(F)
+        cA, cB, cC = (d / det).astype(F), (-b / det).astype(F), (a / det).astype(F)
+    op = rng.uniform(0.05, 1.0, n).astype(F)
+    tau = np.log(F(255) * op).astype(F)
+    ex = np.sqrt(F(2) * a * (tau + F(1e-3))).astype(F); ey = np.sqrt(F(2) * d * (tau + F(1e-3))).astype(F)
+    tx0 = (16 * rng.integers(0, 64, n)).astype(F); ty0 = (16 * rng.integers(0, 64, n)).astype(F)
+    t = rng.uniform(0, 3.0, n) * s1; u = rng.normal(0, 1.5, n) * s2 + rng.uniform(-10, 10, n)
+    px = (tx0 + 8 - (t * c - u * s)).astype(F); py = (ty0 + 8 - (t * s + u * c)).astype(F)
+    keep = (det > 0) & np.isfinite(cA) & np.isfinite(cC) & (cA > 0) & (cC > 0)
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+
+
+def _sweep(seed, n=50000):
+    rec = make_records(n, seed) if seed % 2 == 0 else make_thin_far_records(n, seed)
+    px, py, A, B, C, op, ex, ey, tx0, ty0 = rec
+    acc = pixel_accepts(px, py, A, B, C, op, tx0, ty0)                       # [n,16,16]
+    blk = acc.reshape(-1, 4, 4, 4, 4).any(axis=(2, 4))                      # [n, by, bx]
+    quad = acc.reshape(-1, 2, 8, 2, 8).any(axis=(2, 4))                     # [n, qy, qx]
+    return rec, blk, quad
+
+
+def test_block_mask_never_drops_a_block_a_pixel_accepts():
+    kept = total = hits = 0
+    for seed in range(4):
+        (px, py, A, B, C, op, ex, ey, tx0, ty0), blk, _ = _sweep(seed)
+        for dt in (np.float32, np.float64):
+            m = block_mask(px, py, A, B, C, op, ex, ey, tx0, ty0, dt)
+            bad = blk & ~m
+            assert not bad.any(), (dt.__name__, seed, int(bad.sum()), [float(v[np.nonzero(bad.any(axis=(1, 2)))[0][0]]) for v in (px, py, A, B, C, op, ex, ey, tx0, ty0)])
+        kept += int(m.sum()); total += m.size; hits += int(blk.sum())
+    assert hits > 100000                                   # the sweep does exercise accepted pairs ...
+    assert kept < 2 * hits                                 # ... and the cull is a cull (1.02x on ordinary splats, 1.3x on the thin / far ones)
+
+
+def test_rect_hit_never_drops_a_quadrant_a_pixel_accepts():
+    kept = hits = 0
+    for seed in range(4):
+        (px, py, A, B, C, op, ex, ey, tx0, ty0), _, quad = _sweep(100 + seed)
+        for dt in (np.float32, np.float64):
+            for qy in range(2):
+                for qx in range(2):
+                    wx0, wy0 = tx0 + F(8 * qx), ty0 + F(8 * qy)
+                    with np.errstate(all="ignore"):
+                        h = rect_hit(px, py, A, B, C, op, ex, ey, wx0, wy0, wx0 + F(7), wy0 + F(7), dt)
+                    bad = quad[:, qy, qx] & ~h
+                    assert not bad.any(), (dt.__name__, seed, qy, qx, int(bad.sum()),
+                                           [float(v[np.nonzero(bad)[0][0]]) for v in (px, py, A, B, C, op, ex, ey, tx0, ty0)])
+                    if dt is np.float32:
+                        kept += int(h.sum()); hits += int(quad[:, qy, qx].sum())
+    assert hits > 50000 and kept < 2 * hits

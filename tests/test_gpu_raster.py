@@ -377,6 +377,57 @@ def test_very_deep_frames_keep_a_segment_length_their_kernels_support(env):
     assert r.returncode == 0 and "deep ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
 
 
+def huge_thin_scene(P=120, seed=7, S=16.0):
+    """Splats ~1 000 px long (sigma) and a fraction of a pixel wide whose TIPS lie inside a 192x192 image, centres up to
+    3 500 px outside it: beyond the tip the float32 exponent is a difference of terms ~10^7 and accepts pixels outside the
+    exact ellipse's bounding box (tests/test_filter_emulation.py; on this scene the exact box drops 16 (splat, 4x4 block)
+    pairs some pixel accepts)."""
+    rng = np.random.default_rng(seed)
+    phi = rng.uniform(0, np.pi, P)
+    axis = np.stack([np.cos(phi), np.zeros(P), np.sin(phi)], 1)
+    t = rng.uniform(2.7, 3.5, P) * S
+    off = rng.normal(0, 0.4, (P, 3)); off[:, 1] = rng.uniform(-0.5, 0.5, P)
+    means = -(t[:, None] * axis) + off
+    q = np.stack([np.cos(-phi / 2), np.zeros(P), np.sin(-phi / 2), np.zeros(P)], 1)
+    scales = np.stack([np.full(P, S), np.full(P, 0.002), rng.uniform(0.002, 0.02, P)], 1)
+    g = torch.Generator().manual_seed(seed)
+    return dict(means3D=torch.tensor(means, dtype=torch.float32), opacities=torch.tensor(rng.uniform(0.3, 0.9, (P, 1)), dtype=torch.float32),
+                shs=torch.randn(P, 16, 3, generator=g) * 0.3, scales=torch.tensor(scales, dtype=torch.float32),
+                rotations=torch.tensor(q, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("env", [{}, {"GMS_MICRO": "0"}])
+def test_huge_thin_splats_keep_the_pixels_their_float32_exponent_accepts(env):
+    """Both compositing implementations against the oracle on `huge_thin_scene` (forward image, radii, inverse depth; the
+    gradients of such splats are float32 noise on both sides and are only required to be finite)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, os, torch, numpy as np\n"
+        "sys.path.insert(0, os.path.join(%r, 'tests'))\n"
+        "import conftest\n"
+        "import test_gpu_raster as T\n"
+        "from games_hip import synthetic as syn\n"
+        "import _util as U\n"
+        "inputs = T.huge_thin_scene()\n"
+        "cam = syn.look_at_camera((0.0, -3.0, 0.0), width=192, height=192, fovx=0.9)\n"
+        "kw = U.settings_kwargs(cam, torch.tensor([0.1, 0.2, 0.3]), sh_degree=1)\n"
+        "o = U.oracle_render(inputs, kw)\n"
+        "gc = syn.upstream_grad(torch.from_numpy(o['color'])).numpy() * 1000.0\n"
+        "for call in range(2):\n"
+        "    h = U.hip_render(inputs, kw, grad_color=gc)\n"
+        "    rep = U.forward_report(h, o, 192, 192)\n"
+        "    assert rep['radii_unexplained'] == 0 and rep['max_clean'] <= 1e-4 and rep['max_invdepth_clean'] <= 1e-4 and rep['max_amb'] <= 0.02, rep\n"
+        "    assert all(np.isfinite(v).all() for v in h['grads'].values() if v is not None)\n"
+        "assert int((o['radii'] > 3000).sum()) > 20 and o['N'] > 5000\n"
+        "print('huge ok', rep)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "huge ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_visibility_filter_from_the_preprocess_kernel_equals_radii_positive():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     sc, cam = syn.random_scene(5000, seed=31, scale_lo=0.01, scale_hi=0.1), syn.orbit_camera(3, width=128, height=96, radius=1.2)
