@@ -112,29 +112,29 @@ constexpr float HUGE_EXTENT = 256.f;
 //       far corner (the three terms cancel for a thin splat whose centre is hundreds of pixels away).
 __device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float op, const float4 q2, const RectF &p, bool bbox_only = false)
 {
-    const bool out = q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1;
-    // The box is that of the EXACT ellipse.  For a splat hundreds of pixels long the per-pixel exponent is itself only known
-    // to ~1e-7 of its gross terms, and just beyond the tip of a long thin ellipse Q grows so slowly (2 sqrt(thr) / sigma_1 per
-    // pixel) that this noise reaches past the box: a 1 000-px sigma accepts pixels up to ~250 px outside it (CPU emulation:
-    // tests/test_filter_emulation.py; first seen at sigma_1 = 300 px, aspect 260).  Small boxes reject right here; large ones
-    // are tested again below with the box of the inflated threshold.
-    if (out && fmaxf(q2.z, q2.w) <= HUGE_EXTENT) return false;
-    if (bbox_only) return !out;                                       // experiment switch (GMS_DBG & 512)
-    const float A = q0.z, B = q0.w;
-    const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
-    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
-    const float thr = 2.f * (__logf(255.f * op) + 1e-3f);
-    const float B2 = 2.f * B;
-    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
-    const float gross = mx * (A * mx + fabsf(B2) * my) + C * my * my;
-    const float thr2 = thr * 1.0001f + 0.01f + 4e-6f * gross;
-    if (out) {            // large splat outside its exact box: the box of {Q <= thr2} (extents scale with sqrt(thr2 / thr))
-        if (!(thr > 1e-4f)) return false;
-        const float g = __builtin_amdgcn_sqrtf(thr2 * __builtin_amdgcn_rcpf(thr));
+    if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) {
+        // The box is that of the EXACT ellipse.  For a splat hundreds of pixels long the per-pixel exponent is itself only
+        // known to ~1e-7 of its gross terms, and just beyond the tip of a long thin ellipse Q grows so slowly (2 sqrt(thr) /
+        // sigma_1 per pixel) that this noise reaches past the box: a 1 000-px sigma accepts pixels up to ~250 px outside it
+        // (CPU emulation: tests/test_filter_emulation.py; first seen at an extent of 321 px).  Small boxes reject right here;
+        // a large one (rare: the cold path of this function) is tested again with the box of the inflated threshold and, if
+        // that one is hit, goes on to the exact test below.
+        if (__builtin_expect(fmaxf(q2.z, q2.w) <= HUGE_EXTENT, 1)) return false;
+        const float thr_h = 2.f * (__logf(255.f * op) + 1e-3f);
+        if (!(thr_h > 1e-4f)) return false;
+        const float hx = fmaxf(fabsf(p.wx0 - q0.x), fabsf(p.wx1 - q0.x)), hy = fmaxf(fabsf(p.wy0 - q0.y), fabsf(p.wy1 - q0.y));
+        const float gross_h = hx * (q0.z * hx + fabsf(2.f * q0.w) * hy) + C * hy * hy;
+        const float g = __builtin_amdgcn_sqrtf((thr_h * 1.0001f + 0.01f + 4e-6f * gross_h) * __builtin_amdgcn_rcpf(thr_h));
         const float ex = q2.z * g, ey = q2.w * g;
         if (q0.x + ex < p.wx0 || q0.x - ex > p.wx1 || q0.y + ey < p.wy0 || q0.y - ey > p.wy1) return false;
     }
+    if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
+    const float A = q0.z, B = q0.w;
+    const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
+    if (dx0 <= 0.f && dx1 >= 0.f && dy0 <= 0.f && dy1 >= 0.f) return true;          // centre inside the quadrant
     const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
+    const float thr = 2.f * (__logf(255.f * op) + 1e-3f);
+    const float B2 = 2.f * B;
     float qmin;
     {
         const float ya = fminf(fmaxf(-B * dx0 * iC, dy0), dy1), yb = fminf(fmaxf(-B * dx1 * iC, dy0), dy1);
@@ -143,7 +143,9 @@ __device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const f
         const float e2 = xa * (A * xa + B2 * dy0) + C * dy0 * dy0, e3 = xb * (A * xb + B2 * dy1) + C * dy1 * dy1;
         qmin = fminf(fminf(e0, e1), fminf(e2, e3));
     }
-    return qmin <= thr2;
+    const float mx = fmaxf(fabsf(dx0), fabsf(dx1)), my = fmaxf(fabsf(dy0), fabsf(dy1));
+    const float gross = mx * (A * mx + fabsf(B2) * my) + C * my * my;
+    return qmin <= thr * 1.0001f + 0.01f + 4e-6f * gross;
 }
 // per-pixel state of the back-to-front recurrence
 struct BwdState {
