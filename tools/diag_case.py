@@ -8,17 +8,9 @@ import numpy as np, torch
 import _util as U
 from games_hip import synthetic as syn
 seed = int(sys.argv[1])
-rng = np.random.default_rng(seed)
-P = int(rng.choice([1, 7, 100, 1500, 6000, 20000]))
-W, H = int(rng.integers(17, 300)), int(rng.integers(17, 220))
-deg = int(rng.integers(0, 4)); aa = bool(rng.integers(0, 2))
-lo = float(rng.choice([0.002, 0.01, 0.05])); hi = lo * float(rng.choice([2, 10, 40]))
-op_lo = float(rng.choice([0.01, 0.1, 0.6])); op_hi = min(0.999, op_lo + float(rng.choice([0.05, 0.4])))
-sc = syn.random_scene(P, seed=seed, scale_lo=lo, scale_hi=hi, opacity_lo=op_lo, opacity_hi=op_hi)
-cam = syn.orbit_camera(int(rng.integers(0, 8)), width=W, height=H, radius=float(rng.choice([1.5, 3.0, 6.0])))
-bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
-kw = U.settings_kwargs(cam, bg, antialiasing=aa, sh_degree=deg, scale_modifier=float(rng.choice([1.0, 0.6, 1.8])))
-inputs = dict(means3D=sc.means3D, opacities=sc.opacities, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+inputs, kw, tag, rng = U.fuzz_case(seed)       # the sweep's generator (tests/_util.py)
+W, H = kw["image_width"], kw["image_height"]
+P, deg, aa = inputs["means3D"].shape[0], kw["sh_degree"], kw["antialiasing"]
 o = U.oracle_render(inputs, kw)
 gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
 gd = np.full((1, H, W), 1e-3, np.float32) if rng.integers(0, 2) else None
