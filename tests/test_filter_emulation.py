@@ -14,6 +14,7 @@ share of them at the threshold), half long, thin and far (`make_thin_far_records
 3, that a bounding box of the EXACT ellipse is not conservative: beyond the tip of a 1 000-px splat the float32 exponent's own
 noise accepts pixels up to ~250 px outside the box; boxes larger than HUGE_EXTENT are now re-tested with the inflated threshold."""
 import numpy as np
+import pytest
 
 F = np.float32
 
@@ -189,3 +190,42 @@ def test_rect_hit_never_drops_a_quadrant_a_pixel_accepts():
                     if dt is np.float32:
                         kept += int(h.sum()); hits += int(quad[:, qy, qx].sum())
     assert hits > 50000 and kept < 2 * hits
+
+
+def make_worst_case_tip_records(n, seed, s1_lo=20.0, s1_hi=140.0):
+    """The minimum-width splat (sigma_2 = sqrt(0.3), the dilation) with its TIP inside the tile, low opacities, pixel
+    coordinates up to 4 096: extents below HUGE_EXTENT where the exponent's float32 noise (~2 eps sqrt(thr) sigma_1^3 / sigma_2^2
+    pixels of overshoot beyond the exact box: 2 px at sigma_1 = 100, 0.3 px at 50) can still beat the exact bounding box."""
+    rng = np.random.default_rng(seed)
+    s1 = np.exp(rng.uniform(np.log(s1_lo), np.log(s1_hi), n)); s2 = np.sqrt(0.3) * np.exp(rng.uniform(0, 0.15, n))
+    th = rng.uniform(0, np.pi, n)
+    c, s = np.cos(th), np.sin(th)
+    a = (c * c * s1 * s1 + s * s * s2 * s2).astype(F); b = (c * s * (s1 * s1 - s2 * s2)).astype(F); d = (s * s * s1 * s1 + c * c * s2 * s2).astype(F)
+    with np.errstate(all="ignore"):
+        det = (a * d - b * b).astype(F)
+        cA, cB, cC = (d / det).astype(F), (-b / det).astype(F), (a / det).astype(F)
+    op = np.exp(rng.uniform(np.log(0.005), np.log(1.0), n)).astype(F)
+    tau = np.log(F(255) * op).astype(F)
+    with np.errstate(invalid="ignore"):
+        ex = np.sqrt(F(2) * a * (tau + F(1e-3))).astype(F); ey = np.sqrt(F(2) * d * (tau + F(1e-3))).astype(F)
+    tx0 = (16 * rng.integers(0, 256, n)).astype(F); ty0 = (16 * rng.integers(0, 256, n)).astype(F)
+    thr = 2 * (tau.astype(np.float64) + 1e-3)
+    t = np.sqrt(np.maximum(thr, 0)) * rng.uniform(0.97, 1.08, n) * s1; u = rng.normal(0, 0.8, n) * s2 + rng.uniform(-7, 7, n)
+    px = (tx0 + 8 - (t * c - u * s)).astype(F); py = (ty0 + 8 - (t * s + u * c)).astype(F)
+    keep = (det > 0) & np.isfinite(cA) & np.isfinite(cC) & (cA > 0) & (cC > 0) & (tau > 0)
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+
+
+@pytest.mark.xfail(strict=False, reason="OPEN (round 3): the exact bounding box is still the only first-stage test below HUGE_EXTENT; for minimum-width "
+                   "splats of sigma_1 ~ 100 px whose tip lies in the tile the float32 exponent accepts pixels 1-2 px outside it -- about 0.6 per "
+                   "10^5 such (splat, tile) pairs (24 x 10^5 searched: extents 144 ... 253 px).  Fix prepared: extents inflated per Gaussian by the noise "
+                   "bound in preprocess_fwd (DESIGN.md section 9)")
+def test_open_issue_exact_box_below_huge_extent():
+    drops = 0
+    for seed in (0, 9, 10):           # (seeds with a known drop: extents 209, 144, 217 / 236 px)
+        px, py, A, B, C, op, ex, ey, tx0, ty0 = make_worst_case_tip_records(100000, seed)
+        acc = pixel_accepts(px, py, A, B, C, op, tx0, ty0)
+        blk = acc.reshape(-1, 4, 4, 4, 4).any(axis=(2, 4))
+        m = block_mask(px, py, A, B, C, op, ex, ey, tx0, ty0, np.float32)
+        drops += int((blk & ~m).sum())
+    assert drops == 0, drops
