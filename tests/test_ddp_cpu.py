@@ -4,6 +4,7 @@ Parity statement: all-reduced gradient == sum of the ranks' sin
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -280,11 +281,11 @@ def _packed_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_packed_single_collective_exchange_world2():
+@pytest.mark.parametrize("world", [2, 3])
+def test_packed_single_collective_exchange(world):
     """ONE all-gather of [small gradients | SH factors]: the small gradients come out as the sum over ranks, the SH gradient as
-    the sum of the views' dense gradients, bit-identical on both ranks."""
+    the sum of the views' dense gradients, bit-identical on every rank (world sizes 2 and 3)."""
     import numpy as np
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -295,11 +296,11 @@ def test_packed_single_collective_exchange_world2():
     for p in procs:
         p.join(60)
     for k in range(3):
-        total = res[0][1][k] + res[1][1][k]
+        total = sum(r[1][k] for r in res)
         for r in res:
             np.testing.assert_allclose(r[2][k], total, rtol=1e-6, atol=1e-7)
-        assert np.array_equal(res[0][2][k], res[1][2][k])
-    dense = res[0][4] + res[1][4]
+            assert np.array_equal(res[0][2][k], r[2][k])
+    dense = sum(r[4] for r in res)
     for r in res:
         assert np.abs(r[3] - dense).max() <= 2e-6 * np.abs(dense).max()
-    assert np.array_equal(res[0][3], res[1][3])
+        assert np.array_equal(res[0][3], r[3])
