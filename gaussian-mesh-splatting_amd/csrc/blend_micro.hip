@@ -103,14 +103,14 @@ __device__ __forceinline__ uint32_t block_mask(const SplatRec &r, float tx0, flo
 {
     const float px = r.q0.x, py = r.q0.y, A = r.q0.z, B = r.q0.w, C = r.q1.x, ex = r.q2.z, ey = r.q2.w;
     const float thr = 2.f * (__logf(255.f * r.q1.y) + 1e-3f);
-    // bounding box of the ellipse against the tile (also rejects the ext = -1e30 records of splats below 1/255 everywhere);
-    // a box larger than HUGE_EXTENT is tested again below with the inflated threshold (gms_blend.h::rect_hit says why)
-    const bool out = px + ex < tx0 || px - ex > tx0 + 15.f || py + ey < ty0 || py - ey > ty0 + 15.f;
-    if (out && fmaxf(ex, ey) <= HUGE_EXTENT) return 0u;
+    // bounding box against the tile (also rejects the ext = -1e30 records of splats below 1/255 everywhere).  The stored
+    // extents are those of {Q <= thrG}, thrG = 1.0001 thr + 0.01 + 4e-6 (gross terms of Q at the box's own corner): they carry
+    // the float32 noise of the per-pixel exponent (raster_forward.hip::cull_extents); 1e30 = noise over the whole footprint.
+    if (px + ex < tx0 || px - ex > tx0 + 15.f || py + ey < ty0 || py - ey > ty0 + 15.f) return 0u;
+    if (ex > 1e29f) return 0xffffu;
     uint32_t m = 0;
     if (!(thr > 1e-4f)) {
         // a splat that reaches 1/255 only within rounding of its centre: the bounding box alone (it carries the inflation)
-        if (out) return 0u;
 #pragma unroll
         for (int by = 0; by < 4; by++) {
             const float y0 = ty0 + 4.f * by;
@@ -123,14 +123,11 @@ __device__ __forceinline__ uint32_t block_mask(const SplatRec &r, float tx0, flo
         }
         return m;
     }
+    const float thrG = thr * 1.0001f + 0.01f + 4e-6f * (ex * (A * ex + 2.f * fabsf(B) * ey) + C * ey * ey);   // what (ex, ey) belong to
     const float mx = fmaxf(fabsf(tx0 - px), fabsf(tx0 + 15.f - px)), my = fmaxf(fabsf(ty0 - py), fabsf(ty0 + 15.f - py));
     const float gross = mx * (A * mx + 2.f * fabsf(B) * my) + C * my * my;
-    const float thr2 = thr * 1.0001f + 0.01f + 4e-6f * gross;            // inflated threshold
-    const float grow = thr2 * __builtin_amdgcn_rcpf(thr);                // ex'^2 / ex^2 = ey'^2 / ey^2
-    if (out) {                                                           // large splat outside its exact box: the inflated one
-        const float g = __builtin_amdgcn_sqrtf(grow);
-        if (px + ex * g < tx0 || px - ex * g > tx0 + 15.f || py + ey * g < ty0 || py - ey * g > ty0 + 15.f) return 0u;
-    }
+    const float thr2 = fmaxf(thrG, thr * 1.0001f + 0.01f + 4e-6f * gross);   // inflated threshold for this tile
+    const float grow = thr2 * __builtin_amdgcn_rcpf(thrG);               // ex'^2 / ex^2 = ey'^2 / ey^2
     const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
     const float AT = A * thr2;
     const float inv_ey2 = __builtin_amdgcn_rcpf(ey * ey * grow);        // 1 / ey'^2  (det = A thr2 / ey'^2)

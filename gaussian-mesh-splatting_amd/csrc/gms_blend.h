@@ -97,8 +97,6 @@ __device__ __forceinline__ float pair_power(float A, float B, float C, float dx,
 
 // inclusive rectangle of pixel centres
 struct RectF { float wx0, wy0, wx1, wy1; };
-// half extent (pixels) from which a splat's bounding box is re-tested with the float32 noise of the per-pixel exponent
-constexpr float HUGE_EXTENT = 256.f;
 
 // Does any pixel centre of the rectangle (a wave's 8x8 quadrant, a 4x4 block) see this splat with alpha >= 1/255?  Conservative (it may keep a
 // pair the per-pixel test skips, never the reverse):
@@ -112,22 +110,8 @@ constexpr float HUGE_EXTENT = 256.f;
 //       far corner (the three terms cancel for a thin splat whose centre is hundreds of pixels away).
 __device__ __forceinline__ bool rect_hit(const float4 q0, const float C, const float op, const float4 q2, const RectF &p, bool bbox_only = false)
 {
-    if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) {
-        // The box is that of the EXACT ellipse.  For a splat hundreds of pixels long the per-pixel exponent is itself only
-        // known to ~1e-7 of its gross terms, and just beyond the tip of a long thin ellipse Q grows so slowly (2 sqrt(thr) /
-        // sigma_1 per pixel) that this noise reaches past the box: a 1 000-px sigma accepts pixels up to ~250 px outside it
-        // (CPU emulation: tests/test_filter_emulation.py; first seen at an extent of 321 px).  Small boxes reject right here;
-        // a large one (rare: the cold path of this function) is tested again with the box of the inflated threshold and, if
-        // that one is hit, goes on to the exact test below.
-        if (__builtin_expect(fmaxf(q2.z, q2.w) <= HUGE_EXTENT, 1)) return false;
-        const float thr_h = 2.f * (__logf(255.f * op) + 1e-3f);
-        if (!(thr_h > 1e-4f)) return false;
-        const float hx = fmaxf(fabsf(p.wx0 - q0.x), fabsf(p.wx1 - q0.x)), hy = fmaxf(fabsf(p.wy0 - q0.y), fabsf(p.wy1 - q0.y));
-        const float gross_h = hx * (q0.z * hx + fabsf(2.f * q0.w) * hy) + C * hy * hy;
-        const float g = __builtin_amdgcn_sqrtf((thr_h * 1.0001f + 0.01f + 4e-6f * gross_h) * __builtin_amdgcn_rcpf(thr_h));
-        const float ex = q2.z * g, ey = q2.w * g;
-        if (q0.x + ex < p.wx0 || q0.x - ex > p.wx1 || q0.y + ey < p.wy0 || q0.y - ey > p.wy1) return false;
-    }
+    // (the record's extents already carry the float32 noise of the per-pixel exponent: raster_forward.hip::cull_extents)
+    if (q0.x + q2.z < p.wx0 || q0.x - q2.z > p.wx1 || q0.y + q2.w < p.wy0 || q0.y - q2.w > p.wy1) return false;
     if (bbox_only) return true;                                       // experiment switch (GMS_DBG & 512)
     const float A = q0.z, B = q0.w;
     const float dx0 = p.wx0 - q0.x, dx1 = p.wx1 - q0.x, dy0 = p.wy0 - q0.y, dy1 = p.wy1 - q0.y;
