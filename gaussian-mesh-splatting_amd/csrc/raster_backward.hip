@@ -491,7 +491,9 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     const bool sr = A->scales && A->rotations;
     if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
         !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || !A->dL_dopacity || (A->colors_precomp && !A->dL_dcolors) ||
-        !A->dL_dmeans3D || (A->shs && !A->dL_dsh && !A->dL_dcolors) || (A->shs_rest && ((!A->dL_dsh_rest && !A->dL_dcolors) || A->M != 16)) ||
+        !A->dL_dmeans3D || (A->sh_factor_mode != 0 && A->sh_factor_mode != 1) || (A->sh_factor_mode && (!A->shs || !A->dL_dcolors)) ||
+        (A->factor_campos_row && !A->sh_factor_mode) ||
+        (A->shs && !A->sh_factor_mode && !A->dL_dsh) || (A->shs_rest && ((!A->sh_factor_mode && !A->dL_dsh_rest) || A->M != 16)) ||
         ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
         (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
         (A->cov3D_precomp && !A->dL_dcov3D)) {
@@ -530,7 +532,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
     p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = fault_mode() == 3 ? 0 : A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
-    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = A->shs ? A->dL_dcolors : nullptr; p.campos_row = A->factor_campos_row; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
+    p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = (A->shs && A->sh_factor_mode) ? A->dL_dcolors : nullptr; p.campos_row = A->factor_campos_row; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
     GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");

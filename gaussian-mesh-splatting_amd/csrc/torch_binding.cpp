@@ -167,9 +167,12 @@ struct Backward { Tensor dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dsh
 // enqueued" -- the stretch in which a slow host lets the GPU run dry -- no allocation remains.
 // ---- factorised SH gradient (multi-view steps; gms_sh_grad_expand in include/gmsplat.h).  While the mode is on, a backward on
 // the SH path writes no dL/dsh: it leaves a [P+1,3] tensor -- rows 0..P-1 the clamp-masked dL/dcolour of that view, row P the
-// view's camera centre -- in a per-process list that the caller takes (take_sh_factors), exchanges between ranks and expands.
+// view's camera centre -- in a per-DEVICE list that the caller takes (take_sh_factors), exchanges between ranks and expands.  The
+// queue is keyed by device so two models on two GPUs of one process do not take each other's factors, and bounded: a caller that
+// switches the mode on and never takes the factors gets an error instead of an ever-growing list of [P+1,3] tensors.
 static std::atomic<bool> g_sh_factor{false};
-static std::vector<Tensor> g_factors;
+static std::map<int, std::vector<Tensor>> g_factors;
+constexpr size_t MAX_QUEUED_FACTORS = 256;
 
 Backward alloc_backward(const Tensor &means3D, const Tensor &opac, const Tensor &sh, const Tensor &sh_rest, const Tensor &cov)
 {
@@ -233,11 +236,17 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
     a.dL_dmeans3D = mf(b.dmeans3D); a.dL_dcov3D = mf(b.dcov3D); a.dL_dsh = mf(b.dsh); a.dL_dsh_rest = mf(b.dsh_rest);
     a.dL_dscales = mf(b.dscales); a.dL_drotations = mf(b.drots);
     a.grad_accum_rezero = 1; a.num_units = num_units;
-    a.factor_campos_row = (has_sh && b.dcolors.defined() && b.dcolors.size(0) == P + 1) ? 1 : 0;      // row P = the camera centre
-    if (P > 0) check_rc(gms_rasterize_backward(&a, stream), "gms_rasterize_backward");
-    if (has_sh && b.dcolors.defined()) {          // factorised mode: queue the factor (rows 0..P-1 + camera centre) for the exchange
+    a.sh_factor_mode = (has_sh && b.dcolors.defined()) ? 1 : 0;
+    a.factor_campos_row = (a.sh_factor_mode && b.dcolors.size(0) == P + 1) ? 1 : 0;      // row P = the camera centre
+    if (a.sh_factor_mode) {
         std::lock_guard<std::mutex> lk(g_mu);
-        g_factors.push_back(b.dcolors);
+        TORCH_CHECK(g_factors[(int)dev.index()].size() < MAX_QUEUED_FACTORS, "factorised SH mode: ", MAX_QUEUED_FACTORS,
+                    " factors queued on this device and never taken (call take_sh_factors() every step, or set_sh_factor_mode(False))");
+    }
+    if (P > 0) check_rc(gms_rasterize_backward(&a, stream), "gms_rasterize_backward");
+    if (a.sh_factor_mode) {          // factorised mode: queue the factor (rows 0..P-1 + camera centre) for the exchange
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_factors[(int)dev.index()].push_back(b.dcolors);
     }
     {   // only a call that completed hands its (re-zeroed) buffer back
         std::lock_guard<std::mutex> lk(g_mu);
@@ -370,11 +379,14 @@ void set_sh_factor_mode(bool on)
     g_factors.clear();
 }
 bool sh_factor_mode() { return g_sh_factor.load(); }
-std::vector<Tensor> take_sh_factors()
+// device < 0: the current device
+std::vector<Tensor> take_sh_factors(int64_t device)
 {
+    if (device < 0) { int d = 0; if (hipGetDevice(&d) != hipSuccess) d = 0; device = d; }
     std::lock_guard<std::mutex> lk(g_mu);
     std::vector<Tensor> out;
-    out.swap(g_factors);
+    auto it = g_factors.find((int)device);
+    if (it != g_factors.end()) { out.swap(it->second); g_factors.erase(it); }
     return out;
 }
 
@@ -612,7 +624,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("clear_accum", &clear_accum);
     m.def("set_sh_factor_mode", &set_sh_factor_mode, "factorised SH gradient: backward calls queue [P+1,3] factors instead of writing dL/dsh");
     m.def("sh_factor_mode", &sh_factor_mode);
-    m.def("take_sh_factors", &take_sh_factors);
+    m.def("take_sh_factors", &take_sh_factors, py::arg("device") = -1);
     m.def("sh_grad_expand", &sh_grad_expand, "dsh (+)= sum_v Y(dir_v) (x) factor_v over the [V,P+1,3] factors", nogil());
     m.def("last_stats", &last_stats);
     m.def("set_capacity", &set_capacity);

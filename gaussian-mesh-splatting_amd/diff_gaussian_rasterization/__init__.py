@@ -139,9 +139,13 @@ def sh_factor_mode() -> bool:
     return _C is not None and bool(_C.sh_factor_mode())
 
 
-def take_sh_factors() -> list:
-    """The factors queued by the backward calls since the last take (or since the mode was switched on), oldest first."""
-    return list(_C.take_sh_factors()) if _C is not None else []
+def take_sh_factors(device=None) -> list:
+    """The factors queued by the backward calls ON `device` (a torch.device / index; None = the current device) since the last
+    take (or since the mode was switched on), oldest first.  The queue is per device and bounded (256 factors)."""
+    if _C is None:
+        return []
+    idx = -1 if device is None else (device if isinstance(device, int) else (torch.device(device).index if torch.device(device).index is not None else -1))
+    return list(_C.take_sh_factors(int(idx)))
 
 
 def sh_grad_expand(factors: torch.Tensor, means3D: torch.Tensor, sh_degree: int, dL_dsh: torch.Tensor,

@@ -195,15 +195,21 @@ class ShFactorExchange:
     `ops` = (set_mode, take, expand) defaults to the HIP path of `diff_gaussian_rasterization`; the CPU tests inject the
     oracle's restatements (tests/test_ddp_cpu.py)."""
 
-    def __init__(self, features_dc: torch.Tensor, features_rest: torch.Tensor, world: int, group=None, force: bool = False, ops=None):
+    def __init__(self, features_dc: torch.Tensor, features_rest: torch.Tensor, world: int, group=None, force: bool = False, ops=None,
+                 average: bool = True):
+        """`average` (default True, as `OverlappedGradAllReduce` / `allreduce_gradients`): the SH gradient is the MEAN over the
+        ranks (sum over all views of all ranks / world), so that pairing this exchange with `OverlappedGradAllReduce` under
+        default arguments gives every parameter the same semantics.  Pass False when the 1/world already rides in the upstream
+        gradient (bench.py does that: the collective is then a plain sum)."""
         if ops is None:
             import diff_gaussian_rasterization as dgr
             ops = (dgr.set_sh_factor_mode, dgr.take_sh_factors, dgr.sh_grad_expand)
         self._set_mode, self._take, self._expand = ops
         self.f_dc, self.f_rest = features_dc, features_rest
-        self.world, self.group = int(world), group
+        self.world, self.group, self.average = int(world), group, bool(average)
         self._comm = (self.world > 1 or force) and dist.is_initialized()
         self._work, self._gathered, self._local = None, None, None
+        self._views_checked = None
 
     def enable(self) -> "ShFactorExchange":
         self._set_mode(True)
@@ -233,14 +239,17 @@ class ShFactorExchange:
         local = facs[0].unsqueeze(0) if len(facs) == 1 else torch.stack(facs)          # [v, P+1, 3]
         self._local = local                       # (kept alive until the gather has completed)
         if self._comm:
+            self._views_checked = _check_equal_views(local.shape[0], self._views_checked, self.group, local.device)
             self._gathered = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             self._work = dist.all_gather_into_tensor(self._gathered, local.contiguous(), group=self.group, async_op=True)
         else:
             self._gathered, self._work = local.contiguous(), None
 
-    def finish(self, means3D: torch.Tensor, sh_degree: int, scale: float = 1.0) -> None:
-        """Wait for the gather and write the SH gradients.  `scale` multiplies the sum (1/world for an averaged loss whose
-        upstream gradient was not pre-divided)."""
+    def finish(self, means3D: torch.Tensor, sh_degree: int, scale: float = None) -> None:
+        """Wait for the gather and write the SH gradients.  `scale` multiplies the sum over all views of all ranks; None =
+        1/world if `average` else 1."""
+        if scale is None:
+            scale = 1.0 / self.world if (self.average and self.world > 1) else 1.0
         if self._gathered is None:
             self.start()
         if self._work is not None:
@@ -258,6 +267,20 @@ class ShFactorExchange:
 
 
 
+def _check_equal_views(v: int, checked, group, device):
+    """all_gather_into_tensor needs the same number of queued views on every rank; verify it once per view count (one tiny
+    collective on the first step and whenever the local count changes) instead of failing inside the collective."""
+    if checked == v:
+        return checked
+    t = torch.tensor([v, -v], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    lo, hi = -int(t[1]), int(t[0])
+    if lo != hi:
+        raise RuntimeError(f"view-parallel exchange: ranks queued different numbers of views this step (min {lo}, max {hi}); "
+                           "every rank must render the same number of views per step")
+    return v
+
+
 class PackedGradExchange:
     """The whole gradient exchange of a view-parallel step as ONE collective.
 
@@ -271,15 +294,19 @@ class PackedGradExchange:
     `ops` = (set_mode, take, expand) as for `ShFactorExchange`."""
 
     def __init__(self, params: Iterable[torch.Tensor], features_dc: torch.Tensor, features_rest: torch.Tensor, world: int, group=None,
-                 force: bool = False, ops=None):
+                 force: bool = False, ops=None, average: bool = True):
+        """`average` (default True, the semantics of `allreduce_gradients` / `OverlappedGradAllReduce`): every gradient -- the
+        small ones and the expanded SH gradient -- is the mean over the ranks.  False = plain sums (the caller folded 1/world
+        into the upstream gradient, as bench.py does)."""
         if ops is None:
             import diff_gaussian_rasterization as dgr
             ops = (dgr.set_sh_factor_mode, dgr.take_sh_factors, dgr.sh_grad_expand)
         self._set_mode, self._take, self._expand = ops
         self.f_dc, self.f_rest = features_dc, features_rest
         self.small = [p for p in params if p is not features_dc and p is not features_rest]
-        self.world, self.group = int(world), group
+        self.world, self.group, self.average = int(world), group, bool(average)
         self._comm = (self.world > 1 or force) and dist.is_initialized()
+        self._views_checked = None
 
     def enable(self) -> "PackedGradExchange":
         self._set_mode(True)
@@ -298,12 +325,16 @@ class PackedGradExchange:
         n, nf = send.numel(), local.numel()
         W = self.world if self._comm else 1
         if self._comm:
+            self._views_checked = _check_equal_views(local.shape[0], self._views_checked, self.group, local.device)
             gathered = torch.empty(W * n, dtype=send.dtype, device=send.device)
             dist.all_gather_into_tensor(gathered, send, group=self.group)
         else:
             gathered = send
         G = gathered.view(W, n)
         flat = G[:, :n - nf].sum(dim=0) if W > 1 else G[0, :n - nf]
+        inv = 1.0 / self.world if (self.average and self.world > 1) else 1.0
+        if inv != 1.0:
+            flat = flat * inv
         off = 0
         for p, g in zip(self.small, grads):
             p.grad = flat[off:off + g.numel()].view(g.shape)
@@ -313,6 +344,8 @@ class PackedGradExchange:
         dc = torch.empty((P, 1, 3), dtype=torch.float32, device=means3D.device)
         rest = torch.empty((P, self.f_rest.shape[1], 3), dtype=torch.float32, device=means3D.device)
         self._expand(factors, means3D.detach(), int(sh_degree), dc, rest, False)
+        if inv != 1.0:
+            dc.mul_(inv); rest.mul_(inv)
         for p, g in ((self.f_dc, dc), (self.f_rest, rest)):
             g = g.view(p.shape).to(p.dtype)
             p.grad = g if p.grad is None else p.grad.add_(g)

@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 2
+#define GMS_ABI_VERSION 3   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17 */
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -137,9 +137,9 @@ typedef struct GmsRasterBackwardArgs {
     /* outputs (device), all fully overwritten (no zero-fill needed) */
     float *dL_dmeans2D;    /* [P,3] gradient w.r.t. NDC mean (x,y), z column = 0 */
     float *dL_dopacity;    /* [P] */
-    float *dL_dcolors;     /* [P,3] colors_precomp path: gradient of the colours.  SH path: NULL for the dense SH gradient; when
-                              non-NULL the call runs in FACTORISED mode -- it writes the clamp-masked dL/dcolour of this view here and
-                              does NOT write dL_dsh / dL_dsh_rest (they may be NULL): dL/dsh = Y(dir) (x) dL/dcolour is formed later by
+    float *dL_dcolors;     /* [P,3] colors_precomp path: gradient of the colours.  SH path: ignored unless sh_factor_mode == 1
+                              (below); in FACTORISED mode the call writes the clamp-masked dL/dcolour of this view here and does
+                              NOT write dL_dsh / dL_dsh_rest (they may be NULL): dL/dsh = Y(dir) (x) dL/dcolour is formed later by
                               gms_sh_grad_expand, for one view or for the gathered factors of many (multi-GPU: 3 floats per Gaussian
                               per view travel instead of 48) */
     float *dL_dmeans3D;    /* [P,3] */
@@ -156,6 +156,10 @@ typedef struct GmsRasterBackwardArgs {
     /* factorised mode only: 1 = dL_dcolors has P+1 rows and the call writes the view's camera centre into row P (the factor then
      * carries everything gms_sh_grad_expand needs about its view: one buffer to exchange, no separate copy) */
     int32_t factor_campos_row;
+    /* SH path only.  0 (default): dense SH gradient -- dL_dsh (and dL_dsh_rest in split storage) are required and written,
+     * dL_dcolors is not touched.  1: factorised mode -- dL_dcolors is required and written, dL_dsh / dL_dsh_rest are not.
+     * (ABI 2 switched on `dL_dcolors != NULL`; an explicit flag cannot be set by accident through a reused scratch pointer.) */
+    int32_t sh_factor_mode;
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);

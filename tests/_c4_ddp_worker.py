@@ -33,9 +33,9 @@ def main():
     for variant in ("ring", "direct", "direct_ag", "factor", "packed"):
         sh_factor = variant == "factor"
         algo = "ring" if variant in ("factor", "packed") else variant
-        packed = PackedGradExchange(params, model._features_dc, model._features_rest, world) if variant == "packed" else None
+        packed = PackedGradExchange(params, model._features_dc, model._features_rest, world, average=False) if variant == "packed" else None
         reducer = OverlappedGradAllReduce(params, world if packed is None else 1, average=False, algorithm=algo, big_numel=1 << 16)
-        exchange = ShFactorExchange(model._features_dc, model._features_rest, world) if sh_factor else None
+        exchange = ShFactorExchange(model._features_dc, model._features_rest, world, average=False) if sh_factor else None
         try:
             for p in params:
                 p.grad = None

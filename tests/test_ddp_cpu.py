@@ -220,7 +220,7 @@ def _factor_worker(rank, world, port, q):
 
         f_dc = torch.zeros(sc.means3D.shape[0], 1, 3, requires_grad=True)
         f_rest = torch.zeros(sc.means3D.shape[0], 15, 3, requires_grad=True)
-        ex = ShFactorExchange(f_dc, f_rest, world, ops=(lambda on: state.update(mode=on), lambda: [queue.pop(0) for _ in range(len(queue))], expand))
+        ex = ShFactorExchange(f_dc, f_rest, world, ops=(lambda on: state.update(mode=on), lambda: [queue.pop(0) for _ in range(len(queue))], expand), average=False)
         ex.enable()
         ex.start()
         ex.finish(sc.means3D, 3)
@@ -271,7 +271,7 @@ def _packed_worker(rank, world, port, q):
         local = [torch.randn(p.shape, generator=torch.Generator().manual_seed(900 + 10 * rank + k)) for k, p in enumerate(small)]
         for p, g in zip(small, local):
             p.grad = g.clone()
-        ex = PackedGradExchange(small + [f_dc, f_rest], f_dc, f_rest, world, ops=(lambda on: None, lambda: [queue.pop(0) for _ in range(len(queue))], expand))
+        ex = PackedGradExchange(small + [f_dc, f_rest], f_dc, f_rest, world, ops=(lambda on: None, lambda: [queue.pop(0) for _ in range(len(queue))], expand), average=False)
         ex.enable()
         ex.finish(sc.means3D, 3)
         ex.disable()
@@ -304,3 +304,90 @@ def test_packed_single_collective_exchange(world):
     for r in res:
         assert np.abs(r[3] - dense).max() <= 2e-6 * np.abs(dense).max()
         assert np.array_equal(res[0][3], r[3])
+
+
+def _default_semantics_worker(rank, world, port, q, variant, views_on_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from games_hip.ddp import OverlappedGradAllReduce, PackedGradExchange, ShFactorExchange, allreduce_gradients
+        from oracle import sh_expand_ref
+        mine = [_sh_view(rank * 2 + j) for j in range(views_on_rank[rank])]
+        sc = mine[0][0]
+        queue = [m[2] for m in mine]
+        P = sc.means3D.shape[0]
+
+        def expand(factors, means3D, deg, dc, rest, accumulate):
+            full = sh_expand_ref.expand(factors, means3D, deg, 16)
+            dc.copy_(full[:, :1]); rest.copy_(full[:, 1:])
+
+        ops = (lambda on: None, lambda: [queue.pop(0) for _ in range(len(queue))], expand)
+        f_dc = torch.zeros(P, 1, 3, requires_grad=True)
+        f_rest = torch.zeros(P, 15, 3, requires_grad=True)
+        small = [torch.zeros(s_, requires_grad=True) for s_ in ((P, 1), (7, 3))]
+        local = [torch.randn(p.shape, generator=torch.Generator().manual_seed(700 + 10 * rank + k)) for k, p in enumerate(small)]
+        # the REFERENCE semantics: allreduce_gradients with default arguments on the dense gradients
+        ref_params = [torch.zeros_like(p) for p in small] + [torch.zeros(P, 16, 3)]
+        for p, g in zip(ref_params, local + [sum(m[1] for m in mine)]):
+            p.grad = g.clone()
+        allreduce_gradients(ref_params, world)
+        for p, g in zip(small, local):
+            p.grad = g.clone()
+        err = None
+        try:
+            if variant == "packed":
+                ex = PackedGradExchange(small + [f_dc, f_rest], f_dc, f_rest, world, ops=ops).enable()
+                ex.finish(sc.means3D, 3)
+            else:
+                red = OverlappedGradAllReduce(small, world, big_numel=1 << 30)
+                for p in small:
+                    red._hook(p)
+                ex = ShFactorExchange(f_dc, f_rest, world, ops=ops).enable()
+                ex.start()
+                red.finish()
+                ex.finish(sc.means3D, 3)
+        except RuntimeError as e:
+            err = str(e)
+        if err is None:
+            got = [p.grad.clone() for p in small] + [torch.cat([f_dc.grad, f_rest.grad], dim=1)]
+            q.put((rank, None, [float((a - b.grad).abs().max() / (b.grad.abs().max() + 1e-30)) for a, b in zip(got, ref_params)]))
+        else:
+            q.put((rank, err, None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", ["packed", "factor"])
+def test_exchanges_default_to_the_mean_like_allreduce_gradients(variant):
+    """Default arguments everywhere: `PackedGradExchange`, and `OverlappedGradAllReduce` + `ShFactorExchange`, give every
+    parameter -- the SH features included -- the MEAN over the ranks, exactly what `allreduce_gradients(params, world)` gives
+    on the dense gradients (round-3 advisor finding: the factor exchanges summed while everything else averaged)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_default_semantics_worker, args=(r, world, port, q, variant, [1, 1])) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, err, rel in res:
+        assert err is None, err
+        assert max(rel) <= 3e-6, (rank, rel)
+
+
+def test_unequal_view_counts_raise_instead_of_corrupting_the_gather():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_default_semantics_worker, args=(r, world, port, q, "packed", [1, 2])) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for rank, err, _ in res:
+        assert err is not None and "different numbers of views" in err, (rank, err)
