@@ -265,6 +265,48 @@ class _StandaloneBase:
         if self.active_sh_degree < self.max_sh_degree:
             self.active_sh_degree += 1
 
+    # ---- point_cloud.ply in the reference's layout (scene/gaussian_model.py:177-217 construct_list_of_attributes + save_ply,
+    # :229-268 load_ply), through the plyfile stand-in
+    def construct_list_of_attributes(self):
+        names = ["x", "y", "z", "nx", "ny", "nz"]
+        names += [f"f_dc_{i}" for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
+        names += [f"f_rest_{i}" for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
+        names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+        return names
+
+    def _save_point_cloud(self, path):
+        import os
+        import numpy as np
+        from ._plyfile_compat import PlyData, PlyElement
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        xyz = self._xyz.detach().cpu().numpy()
+        cols = [xyz, np.zeros_like(xyz),
+                self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
+                self._opacity.detach().cpu().numpy(), self._scaling.detach().cpu().numpy(), self._rotation.detach().cpu().numpy()]
+        elements = np.empty(xyz.shape[0], dtype=[(a, "f4") for a in self.construct_list_of_attributes()])
+        elements[:] = list(map(tuple, np.concatenate(cols, axis=1)))
+        PlyData([PlyElement.describe(elements, "vertex")]).write(path)
+
+    def _load_point_cloud(self, path, device):
+        """-> dict of float32 device tensors: xyz [P,3], features_dc [P,1,3], features_rest [P,15,3], opacity [P,1],
+        scaling [P,3], rotation [P,4] (the columns of scene/gaussian_model.py:229-268)."""
+        import numpy as np
+        from ._plyfile_compat import PlyData
+        el = PlyData.read(path).elements[0]
+        col = lambda n: np.asarray(el[n], dtype=np.float32)
+        P = el.count
+        f_dc = np.stack([col(f"f_dc_{i}") for i in range(3)], axis=1).reshape(P, 3, 1)
+        rest_names = sorted([p.name for p in el.properties if p.name.startswith("f_rest_")], key=lambda x: int(x.split("_")[-1]))
+        assert len(rest_names) == 3 * (self.max_sh_degree + 1) ** 2 - 3
+        f_rest = np.stack([col(n) for n in rest_names], axis=1).reshape(P, 3, (self.max_sh_degree + 1) ** 2 - 1)
+        scale_names = sorted([p.name for p in el.properties if p.name.startswith("scale_")], key=lambda x: int(x.split("_")[-1]))
+        rot_names = sorted([p.name for p in el.properties if p.name.startswith("rot_")], key=lambda x: int(x.split("_")[-1]))
+        t = lambda a: torch.tensor(a, dtype=torch.float, device=device).contiguous()
+        return dict(xyz=t(np.stack([col("x"), col("y"), col("z")], axis=1)), features_dc=t(np.transpose(f_dc, (0, 2, 1))),
+                    features_rest=t(np.transpose(f_rest, (0, 2, 1))), opacity=t(col("opacity")[:, None]),
+                    scaling=t(np.stack([col(n) for n in scale_names], axis=1)), rotation=t(np.stack([col(n) for n in rot_names], axis=1)))
+
     def _make_optimizer(self, groups, fused):
         if fused:       # one HIP launch per step (csrc/adam.hip); same state layout as torch.optim.Adam
             from .optim import FusedAdam
@@ -309,45 +351,19 @@ class HipGaussianMeshModel(HipMeshMixin, _StandaloneBase):
 
     # ---- checkpoints: the reference's on-disk format (scene/gaussian_model.py:177-268 point_cloud.ply +
     # games/mesh_splatting/scene/gaussian_mesh_model.py:189-222 model_params.pt), through the plyfile stand-in
-    def construct_list_of_attributes(self):
-        names = ["x", "y", "z", "nx", "ny", "nz"]
-        names += [f"f_dc_{i}" for i in range(self._features_dc.shape[1] * self._features_dc.shape[2])]
-        names += [f"f_rest_{i}" for i in range(self._features_rest.shape[1] * self._features_rest.shape[2])]
-        names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
-        return names
-
     def save_ply(self, path):
-        import os
-        import numpy as np
-        from ._plyfile_compat import PlyData, PlyElement
         self.update_alpha()
         self.prepare_scaling_rot()
-        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
-        xyz = self._xyz.detach().cpu().numpy()
-        cols = [xyz, np.zeros_like(xyz),
-                self._features_dc.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
-                self._features_rest.detach().transpose(1, 2).flatten(start_dim=1).contiguous().cpu().numpy(),
-                self._opacity.detach().cpu().numpy(), self._scaling.detach().cpu().numpy(), self._rotation.detach().cpu().numpy()]
-        elements = np.empty(xyz.shape[0], dtype=[(a, "f4") for a in self.construct_list_of_attributes()])
-        elements[:] = list(map(tuple, np.concatenate(cols, axis=1)))
-        PlyData([PlyElement.describe(elements, "vertex")]).write(path)
+        self._save_point_cloud(path)
         torch.save({"_alpha": self._alpha, "_scale": self._scale, "point_cloud": None, "triangles": self.triangles,
                     "vertices": self.vertices, "faces": self.faces}, path.replace("point_cloud.ply", "model_params.pt"))
 
     def load_ply(self, path, device="cuda"):
-        import numpy as np
-        from ._plyfile_compat import PlyData
-        el = PlyData.read(path).elements[0]
-        col = lambda n: np.asarray(el[n], dtype=np.float32)
-        P = el.count
-        f_dc = np.stack([col(f"f_dc_{i}") for i in range(3)], axis=1).reshape(P, 3, 1)
-        rest_names = sorted([p.name for p in el.properties if p.name.startswith("f_rest_")], key=lambda x: int(x.split("_")[-1]))
-        assert len(rest_names) == 3 * (self.max_sh_degree + 1) ** 2 - 3
-        f_rest = np.stack([col(n) for n in rest_names], axis=1).reshape(P, 3, (self.max_sh_degree + 1) ** 2 - 1)
-        par = lambda a: nn.Parameter(torch.tensor(a, dtype=torch.float, device=device).contiguous().requires_grad_(True))
-        self._features_dc = par(np.transpose(f_dc, (0, 2, 1)))
-        self._features_rest = par(np.transpose(f_rest, (0, 2, 1)))
-        self._opacity = par(col("opacity")[:, None])
+        pc = self._load_point_cloud(path, device)
+        par = lambda a: nn.Parameter(a.requires_grad_(True))
+        self._features_dc = par(pc["features_dc"])
+        self._features_rest = par(pc["features_rest"])
+        self._opacity = par(pc["opacity"])
         params = torch.load(path.replace("point_cloud.ply", "model_params.pt"), map_location=device, weights_only=False)
         self.vertices = nn.Parameter(params["vertices"].detach().to(device))
         self.faces = params["faces"].to(device)
@@ -414,6 +430,12 @@ class _SyntheticFlameLayer:
         return v[None], None
 
 
+def _squeeze_and_enlarge(vertices, enlargement):
+    """transform_vertices_function of games/flame_splatting/scene/dataset_readers.py:41-46 without the axis swap (a module-level
+    function, not a lambda: `point_cloud` is pickled into flame_params.pt as the reference does with its FLAMEPointCloud)."""
+    return torch.squeeze(vertices, 0) * enlargement
+
+
 class _FlameCloud:
     """The attributes of FLAMEPointCloud (games/flame_splatting/utils/graphics_utils.py) the model reads."""
 
@@ -431,8 +453,7 @@ class HipGaussianFlameModel(HipFlameMixin, _StandaloneBase):
         m.active_sh_degree = scene.active_sh_degree
         par = lambda t: nn.Parameter(t.to(device).float().contiguous())
         template = scene.vertices.to(device).float()
-        m.point_cloud = _FlameCloud(_SyntheticFlameLayer(template),
-                                    lambda v, c: torch.squeeze(v, 0) * c)       # dataset_readers.py:41-46 (axis swap omitted)
+        m.point_cloud = _FlameCloud(_SyntheticFlameLayer(template), _squeeze_and_enlarge)
         m.faces = scene.faces.to(device)
         m._flame_shape = par(torch.zeros(1, 4))
         m._flame_exp = par(torch.zeros(1, 4))
@@ -452,6 +473,53 @@ class HipGaussianFlameModel(HipFlameMixin, _StandaloneBase):
     def parameters(self):
         return [self._flame_exp, self._flame_pose, self._flame_trans, self._vertices_enlargement, self._alpha,
                 self._features_dc, self._features_rest, self._opacity, self._scales]
+
+    # ---- checkpoints: point_cloud.ply + flame_params.pt (games/flame_splatting/scene/gaussian_flame_model.py:232-265)
+    FLAME_ATTRS = ("_flame_shape", "_flame_exp", "_flame_pose", "_flame_neck_pose", "_flame_trans", "_vertices_enlargement",
+                   "faces", "alpha", "point_cloud")                 # the reference's `flame_additional_attrs` (:238-244), same order
+    FLAME_EXTRA_ATTRS = ("_alpha", "_scales")                       # not in the reference's file: see load_ply
+
+    def save_ply(self, path):
+        """`save_ply` of the reference (:232-251): refresh alpha / scaling / rotation, write point_cloud.ply, then a dict of
+        the FLAME attributes next to it.  Two extra keys (`_alpha`, `_scales`: the RAW barycentric logits and the per-splat
+        scale multipliers) ride along -- the reference's own `load_ply` ignores unknown keys; without them a loaded model can
+        only replay the PLY's scaling / rotation, not re-derive them per animated frame (BASELINE
+        config 5)."""
+        self.update_alpha()
+        self.prepare_scaling_rot()
+        self._save_point_cloud(path)
+        save_dict = {k: getattr(self, k) for k in self.FLAME_ATTRS + self.FLAME_EXTRA_ATTRS}
+        torch.save(save_dict, path.replace("point_cloud.ply", "flame_params.pt"))
+
+    def load_ply(self, path, device="cuda"):
+        """`load_ply` of the reference (:253-265): the base model's PLY columns (`_xyz`, features, `_opacity`, `_scaling`,
+        `_rotation` as Parameters, scene/gaussian_model.py:229-268) and the nine FLAME attributes.  A file written by the
+        reference has no `_alpha` / `_scales`: the model then holds exactly what the reference's holds after loading --
+        `alpha` (activated) for `flame_render`'s xyz, scaling / rotation from the PLY, `vertices = None`
+        (renderer/flame_gaussian_renderer/__init__.py:59-80).  A file written by `save_ply` above restores the raw
+        parameters as well and re-derives everything on the device."""
+        pc = self._load_point_cloud(path, device)
+        par = lambda a: nn.Parameter(a.requires_grad_(True))
+        self._xyz = par(pc["xyz"])
+        self._features_dc = par(pc["features_dc"])
+        self._features_rest = par(pc["features_rest"])
+        self._opacity = par(pc["opacity"])
+        self._scaling = par(pc["scaling"])
+        self._rotation = par(pc["rotation"])
+        self.active_sh_degree = self.max_sh_degree
+        params = torch.load(path.replace("point_cloud.ply", "flame_params.pt"), map_location=device, weights_only=False)
+        for k in self.FLAME_ATTRS:
+            setattr(self, k, params[k])
+        self.vertices = None
+        self.__dict__["_hip_cached"] = None
+        self.__dict__["_hip_opacity"] = None
+        # the getters serve exp(_scaling) / normalize(_rotation) of the PLY columns until something re-derives them
+        self.__dict__["_hip_activated"] = None
+        if all(k in params for k in self.FLAME_EXTRA_ATTRS):
+            self._alpha = nn.Parameter(params["_alpha"].detach().to(device))
+            self._scales = nn.Parameter(params["_scales"].detach().to(device))
+            self.update_alpha()
+            self.prepare_scaling_rot()
 
 
 _MIXINS = {"gs_mesh": HipMeshMixin, "gs_multi_mesh": HipMultiMeshMixin, "gs_flame": HipFlameMixin}

@@ -401,6 +401,28 @@ def test_checkpoint_roundtrip_in_the_reference_file_format(tmp_path):
     assert torch.equal(render(cam, m, PipelineParams(), bg)["render"], render(cam, m2, PipelineParams(), bg)["render"])
 
 
+def test_flame_checkpoint_roundtrip_renders_identically(tmp_path):
+    """flame_params.pt + point_cloud.ply (gaussian_flame_model.py:232-265) through the HIP op: the loaded model renders the
+    same image and keeps animating with re-derived face-local scale / rotation."""
+    from games_hip.model import HipGaussianFlameModel
+    from games_hip.render import PipelineParams, render
+    m = HipGaussianFlameModel.from_scene(syn.mesh_scene("tiny"), "cuda")
+    with torch.no_grad():
+        m._flame_exp.fill_(0.4); m._flame_pose[0, 0] = 0.3
+    path = str(tmp_path / "point_cloud" / "iteration_9" / "point_cloud.ply")
+    m.save_ply(path)
+    m2 = HipGaussianFlameModel(3)
+    m2.load_ply(path)
+    cam = syn.orbit_camera(1, width=96, height=96).to("cuda")
+    bg = torch.ones(3, device="cuda")
+    assert torch.equal(render(cam, m, PipelineParams(), bg)["render"], render(cam, m2, PipelineParams(), bg)["render"])
+    with torch.no_grad():
+        m._flame_exp.fill_(-0.5); m2._flame_exp.fill_(-0.5)
+    for g in (m, m2):
+        g.update_alpha(); g.prepare_scaling_rot()
+    assert torch.equal(render(cam, m, PipelineParams(), bg)["render"], render(cam, m2, PipelineParams(), bg)["render"])
+
+
 def test_backward_twice_through_one_graph_and_without_vertex_gradient():
     """The forward pre-clears the vertex-gradient buffer for ONE backward (fused single launch); a second backward through
     a retained graph takes the two-launch path with its own clearing, and a graph without vertex gradient needs none."""
