@@ -86,69 +86,8 @@ struct UnitShared {
     uint32_t order[16], ocnt[16];
 };
 // ------------------------------------------------------------------------------------ filter
-// Which of the tile's sixteen 4x4 blocks can see the splat with alpha >= 1/255 (bit by * 4 + bx).  Conservative: it may keep
-// a (splat, block) pair no pixel of the block accepts, never the reverse.
-//
-// The region {alpha >= 1/255} is the ellipse Q(d) = A dx^2 + 2 B dx dy + C dy^2 <= thr, thr = 2 (ln(255 op) + 1e-3) (the same
-// inflated threshold the record's extents were built from).  A block spans a whole band of four pixel rows, so it meets the
-// (convex) ellipse iff the x-projection of (ellipse intersected with the band) overlaps the block's columns.  The slice of the
-// ellipse at height dy is dx in (-B dy -+ sqrt(D)) / A with D(dy) = A thr - det dy^2; the right end is concave in dy with its
-// maximum at the ellipse's rightmost point dy_R = -B ex / C, the left end convex with its minimum at -dy_R, so the band's
-// projection is [left(clamp(-dy_R)), right(clamp(dy_R))] with the clamp to the band, and the band misses the ellipse iff D
-// is negative at the clamped point.  Four bands x (2 square roots + 8 compares) instead of sixteen rectangle tests.
-// det = A C - B^2 cancels badly for long thin splats; it is taken from the record's extent instead (ey^2 = thr A / det,
-// computed from the covariance in the preprocess kernel).  Slack as in rect_hit: 0.01 + 1e-4 thr + 4e-6 x the gross terms of Q
-// at the far corner of the tile (the float error of the per-pixel exponent itself), plus 1e-3 pixel on the interval ends.
-__device__ __forceinline__ uint32_t block_mask(const SplatRec &r, float tx0, float ty0)
-{
-    const float px = r.q0.x, py = r.q0.y, A = r.q0.z, B = r.q0.w, C = r.q1.x, ex = r.q2.z, ey = r.q2.w;
-    const float thr = 2.f * (__logf(255.f * r.q1.y) + 1e-3f);
-    // bounding box against the tile (also rejects the ext = -1e30 records of splats below 1/255 everywhere).  The stored
-    // extents are those of {Q <= thrG}, thrG = 1.0001 thr + 0.01 + 4e-6 (gross terms of Q at the box's own corner): they carry
-    // the float32 noise of the per-pixel exponent (raster_forward.hip::cull_extents); 1e30 = noise over the whole footprint.
-    if (px + ex < tx0 || px - ex > tx0 + 15.f || py + ey < ty0 || py - ey > ty0 + 15.f) return 0u;
-    if (ex > 1e29f) return 0xffffu;
-    uint32_t m = 0;
-    if (!(thr > 1e-4f)) {
-        // a splat that reaches 1/255 only within rounding of its centre: the bounding box alone (it carries the inflation)
-#pragma unroll
-        for (int by = 0; by < 4; by++) {
-            const float y0 = ty0 + 4.f * by;
-            const bool yhit = !(py + ey < y0 || py - ey > y0 + 3.f);
-#pragma unroll
-            for (int bx = 0; bx < 4; bx++) {
-                const float x0 = tx0 + 4.f * bx;
-                if (yhit && !(px + ex < x0 || px - ex > x0 + 3.f)) m |= 1u << (by * 4 + bx);
-            }
-        }
-        return m;
-    }
-    const float thrG = thr * 1.0001f + 0.01f + 4e-6f * (ex * (A * ex + 2.f * fabsf(B) * ey) + C * ey * ey);   // what (ex, ey) belong to
-    const float mx = fmaxf(fabsf(tx0 - px), fabsf(tx0 + 15.f - px)), my = fmaxf(fabsf(ty0 - py), fabsf(ty0 + 15.f - py));
-    const float gross = mx * (A * mx + 2.f * fabsf(B) * my) + C * my * my;
-    const float thr2 = fmaxf(thrG, thr * 1.0001f + 0.01f + 4e-6f * gross);   // inflated threshold for this tile
-    const float grow = thr2 * __builtin_amdgcn_rcpf(thrG);               // ex'^2 / ex^2 = ey'^2 / ey^2
-    const float iA = __builtin_amdgcn_rcpf(A), iC = __builtin_amdgcn_rcpf(C);
-    const float AT = A * thr2;
-    const float inv_ey2 = __builtin_amdgcn_rcpf(ey * ey * grow);        // 1 / ey'^2  (det = A thr2 / ey'^2)
-    const float dyR = -B * ex * __builtin_amdgcn_sqrtf(grow) * iC;       // height of the rightmost point (the leftmost: -dyR)
-#pragma unroll
-    for (int by = 0; by < 4; by++) {
-        const float dya = ty0 + 4.f * by - py, dyb = dya + 3.f;
-        const float c1 = fminf(fmaxf(dyR, dya), dyb), c2 = fminf(fmaxf(-dyR, dya), dyb);
-        const float D1 = AT * (1.f - c1 * c1 * inv_ey2), D2 = AT * (1.f - c2 * c2 * inv_ey2);
-        const bool band = D1 >= 0.f;                                   // (D2 >= 0 says the same: both points lie in the band)
-        const float xr = px + (__builtin_amdgcn_sqrtf(fmaxf(D1, 0.f)) - B * c1) * iA + 1e-3f;
-        const float xl = px - (__builtin_amdgcn_sqrtf(fmaxf(D2, 0.f)) + B * c2) * iA - 1e-3f;
-#pragma unroll
-        for (int bx = 0; bx < 4; bx++) {
-            const float x0 = tx0 + 4.f * bx;
-            if (band && xr >= x0 && xl <= x0 + 3.f) m |= 1u << (by * 4 + bx);
-        }
-    }
-    return m;
-}
-
+// (block_mask, the exact ellipse-vs-band test of a splat against the tile's sixteen 4x4 blocks, lives in gms_blend.h: the test
+// hooks run the same device function on adversarial records.)
 // What every unit block does first.  FILTER = this launch is the first to touch the unit: each thread takes one entry,
 // gathers its splat record, finds the 4x4 blocks it can reach (block_mask) and the survivors' entry indices are written per
 // block in list order -- ballot ranks inside a wave, wave bases after ONE barrier, no atomics -- to the unit's byte lists in

@@ -122,27 +122,7 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
 // the binning needs: projection, conic, radius, extents, tile counts; 8 KB of LDS instead of 53), 2 = SH -> RGB (57 MB of
 // coefficient reads that only the compositing needs: runs on a second stream beside scan / emit / sort / filter).  The two
 // write disjoint bytes of the 48-byte record.
-// Half extents of the bounding box the culls test (record words 10, 11).  {alpha >= 1/255} is the ellipse Q <= thr with
-// thr = 2 (ln(255 op) + 1e-3), whose box is sqrt(cov_xx thr) x sqrt(cov_yy thr).  The per-pixel exponent, though, is only known
-// to ~1e-7 of its GROSS terms, and beyond the tip of a long thin splat Q grows so slowly that this noise accepts pixels outside
-// that box (tests/test_filter_emulation.py: 2 px at sigma_1 = 100 px and minimum width, 250 px at 1 000).  So the box stored is
-// that of {Q <= thr_G}, thr_G = 1.0001 thr + 0.01 + 4e-6 * (gross terms of Q at the corner of this very box).  With
-// rho = (gross at the corner) / thr_G = A cov_xx + 2 |B| sqrt(cov_xx cov_yy) + C cov_yy (a property of the shape: 2 for a
-// circle, ~4 (sigma_1 / sigma_2)^2 for a thin diagonal splat) the fixed point is thr_G = (1.0001 thr + 0.01) / (1 - 4e-6 rho);
-// from rho = 1.25e5 on (aspect ~180 and beyond) the exponent is noise over the whole footprint and the box is infinite.
-// block_mask recovers thr_G from the stored extents (thr_G = 1.0001 thr + 0.01 + 4e-6 (A ex^2 + 2 |B| ex ey + C ey^2)).
-__device__ __forceinline__ void cull_extents(float a_d, float c_d, float cA, float cB, float cC, float opp, float &ex, float &ey)
-{
-    const float tau = __logf(255.f * opp);
-    if (tau < -1e-3f) { ex = -1e30f; ey = -1e30f; return; }
-    const float thr0 = 2.f * (tau + 1e-3f) * 1.0001f + 0.01f;
-    const float rho = cA * a_d + 2.f * fabsf(cB) * sqrtf(a_d * c_d) + cC * c_d;
-    const float k = 1.f - 4e-6f * rho;
-    if (!(k > 0.5f)) { ex = 1e30f; ey = 1e30f; return; }
-    const float thrG = thr0 / k;
-    ex = sqrtf(a_d * thrG); ey = sqrtf(c_d * thrG);
-}
-
+// (cull_extents -- the noise-aware half extents stored in record words 10, 11 -- lives in gms_blend.h)
 template <int SHDEG, bool SPLIT, int MODE = 0>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {

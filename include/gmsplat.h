@@ -327,8 +327,8 @@ size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
 /* ---- fault injection (test infrastructure of the PARITY CRITERION, not of the kernels) -------------------------------
  * tests/test_gpu_negative_controls.py must show that the gradient criterion of tests/_util.py can FAIL: a deliberately
- * wrong backward has to trip it.  `fault` selects one defect for the calling process until reset to 0 (the default; also
- * settable through the environment variable GMS_FAULT read at the first backward).  The faulty code lives in separate
+ * wrong backward has to trip it.  `fault` selects one defect for the calling process until reset to 0 (the default).  Only this
+ * call switches a fault on: no environment variable does (a stray one must not be able to corrupt gradients).  The faulty code lives in separate
  * template instantiations of the kernels: the production instantiations contain no fault branch.
  *   1  blend_bwd: the second moment sum(q dx^2) of every 1000th Gaussian (id % 1000 == 0) is scaled by 1 + 2e-3
  *   2  blend_bwd: a unit that restarts the back-to-front recurrence at a segment boundary drops the colour composited

@@ -39,7 +39,7 @@ def cull_extents(a, d, cA, cB, cC, op):
     return np.where(dead, F(-1e30), ex).astype(F), np.where(dead, F(-1e30), ey).astype(F)
 
 
-def make_records(n, seed):
+def make_records(n, seed, with_cov=False):
     rng = np.random.default_rng(seed)
     s1 = np.exp(rng.uniform(np.log(0.55), np.log(400.0), n))
     s2 = np.exp(rng.uniform(np.log(0.55), np.log(s1)))
@@ -63,7 +63,7 @@ def make_records(n, seed):
     px = (tx0 + 8 + (8 + reach) * np.cos(ang) * rng.uniform(0, 1, n)).astype(F)
     py = (ty0 + 8 + (8 + reach) * np.sin(ang) * rng.uniform(0, 1, n)).astype(F)
     keep = ok & np.isfinite(cA) & np.isfinite(cC)
-    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0) + ((a, d) if with_cov else ()))      # (with_cov: the covariance diagonal, for tests/test_gpu_cull.py)
 
 
 def pixel_accepts(px, py, A, B, C, op, tx0, ty0):
@@ -131,7 +131,7 @@ def block_mask(px, py, A, B, C, op, ex, ey, tx0, ty0, dt):
     return m & ~out[:, None, None]
 
 
-def make_thin_far_records(n, seed):
+def make_thin_far_records(n, seed, with_cov=False):
     """Long thin splats (sigma_1 30 ... 10 000 px, sigma_2 0.55 ... 3 px) with the tile placed ALONG the major axis up to three
     sigma_1 from the centre: the regime where the per-pixel exponent is a difference of terms ~10^7 and its float32 noise
     accepts pixels far outside the exact ellipse (up to ~250 px beyond its bounding box at sigma_1 = 1 000)."""
@@ -149,7 +149,7 @@ def make_thin_far_records(n, seed):
     t = rng.uniform(0, 3.0, n) * s1; u = rng.normal(0, 1.5, n) * s2 + rng.uniform(-10, 10, n)
     px = (tx0 + 8 - (t * c - u * s)).astype(F); py = (ty0 + 8 - (t * s + u * c)).astype(F)
     keep = (det > 0) & np.isfinite(cA) & np.isfinite(cC) & (cA > 0) & (cC > 0)
-    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0) + ((a, d) if with_cov else ()))      # (with_cov: the covariance diagonal, for tests/test_gpu_cull.py)
 
 
 def _sweep(seed, n=50000):
@@ -192,7 +192,7 @@ def test_rect_hit_never_drops_a_quadrant_a_pixel_accepts():
     assert hits > 50000 and kept < 2 * hits
 
 
-def make_worst_case_tip_records(n, seed, s1_lo=20.0, s1_hi=140.0):
+def make_worst_case_tip_records(n, seed, s1_lo=20.0, s1_hi=140.0, with_cov=False):
     """The minimum-width splat (sigma_2 = sqrt(0.3), the dilation) with its TIP inside the tile, low opacities, pixel
     coordinates up to 4 096: moderate extents (144 ... 253 px) where the exponent's float32 noise (~2 eps sqrt(thr) sigma_1^3 / sigma_2^2
     pixels of overshoot beyond the exact box: 2 px at sigma_1 = 100, 0.3 px at 50) can still beat the exact bounding box."""
@@ -212,7 +212,7 @@ def make_worst_case_tip_records(n, seed, s1_lo=20.0, s1_hi=140.0):
     t = np.sqrt(np.maximum(thr, 0)) * rng.uniform(0.97, 1.08, n) * s1; u = rng.normal(0, 0.8, n) * s2 + rng.uniform(-7, 7, n)
     px = (tx0 + 8 - (t * c - u * s)).astype(F); py = (ty0 + 8 - (t * s + u * c)).astype(F)
     keep = (det > 0) & np.isfinite(cA) & np.isfinite(cC) & (cA > 0) & (cC > 0) & (tau > 0)
-    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0))
+    return tuple(v[keep] for v in (px, py, cA, cB, cC, op, ex, ey, tx0, ty0) + ((a, d) if with_cov else ()))      # (with_cov: the covariance diagonal, for tests/test_gpu_cull.py)
 
 
 def test_worst_case_tips_minimum_width_low_opacity():
