@@ -303,7 +303,10 @@ __global__ void __launch_bounds__(BLOCK) blend_finalize_kernel(BlendGrid g, Blen
 // work at a quarter of the granularity; the price is that each quadrant gathers the unit's records itself (from L2).
 // FAULT: 0 in production; 2 = the negative control "drop the colour composited behind a segment restart" (gmsplat.h,
 // gms_set_fault): a separate instantiation, so the production kernel carries no fault branch.
-template <bool INVD, int NE, int WPB, int FAULT = 0>
+// DET (deterministic mode, gmsplat.h): the ten totals of a (quadrant wave, splat) pair are STORED into the partial record of
+// (instance, quadrant) -- a.part[(sorted position * 4 + quadrant) * 16 + field], visited exactly once per frame, zero-filled by
+// the host -- instead of being added to the Gaussian's record with atomics.
+template <bool INVD, int NE, int WPB, int FAULT = 0, bool DET = false>
 __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     constexpr int QN = WPB == 4 ? QUEUE : WAVE;
@@ -435,7 +438,12 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
                 wave_reduce10x2(va, vb, y0a, y1a, y0b, y1b);
                 if (noatomics) { if (y0a == 123.456f) a.accum[0] = y1a + y0b + y1b; continue; }
                 const size_t ida = ids[k[e]], idb = ids[k[f]];
-                if (alane) {
+                if (DET) {
+                    if (alane) {
+                        a.part[((size_t)(u.tile_beg + hi - 1u - (uint32_t)k[e]) * 4 + wave) * GRAD_STRIDE + afield] = use_y1 ? y1a : y0a;
+                        a.part[((size_t)(u.tile_beg + hi - 1u - (uint32_t)k[f]) * 4 + wave) * GRAD_STRIDE + afield] = use_y1 ? y1b : y0b;
+                    }
+                } else if (alane) {
                     unsafeAtomicAdd(abase + ida * GRAD_STRIDE, use_y1 ? y1a : y0a);   // 10 lanes, one 64-B line
                     unsafeAtomicAdd(abase + idb * GRAD_STRIDE, use_y1 ? y1b : y0b);
                 }
@@ -446,7 +454,9 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
                 float y0, y1;
                 wave_reduce10(va[0], va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], va[9], y0, y1);
                 if (noatomics) { if (y0 == 123.456f) a.accum[0] = y1; continue; }
-                if (alane) unsafeAtomicAdd(abase + (size_t)ids[any[e] ? k[e] : k[f]] * GRAD_STRIDE, use_y1 ? y1 : y0);
+                if (DET) {
+                    if (alane) a.part[((size_t)(u.tile_beg + hi - 1u - (uint32_t)(any[e] ? k[e] : k[f])) * 4 + wave) * GRAD_STRIDE + afield] = use_y1 ? y1 : y0;
+                } else if (alane) unsafeAtomicAdd(abase + (size_t)ids[any[e] ? k[e] : k[f]] * GRAD_STRIDE, use_y1 ? y1 : y0);
             }
         }
     }
@@ -533,7 +543,10 @@ int32_t launch_blend_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     const bool invd = a.has_invd && a.dL_dinvd;
     static int wpb = -1;
     if (wpb < 0) { const char *e = getenv("GMS_BWD_WPB"); wpb = (e && atoi(e) == 4) ? 4 : 1; }
-    if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
+    if (a.part) {                           // deterministic mode (gmsplat.h): stores into per-(instance, quadrant) partial records
+        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (blend_bwd_kernel<true, 4, 1, 0, true><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (blend_bwd_kernel<false, 4, 1, 0, true><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
+    } else if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (blend_bwd_kernel<false, 4, 1, 2><<<4u * blocks, WAVE, 0, stream>>>(g, a)));
     } else if (wpb == 4) {
         auto kern = trip == 4 ? (invd ? blend_bwd_kernel<true, 4, 4> : blend_bwd_kernel<false, 4, 4>)

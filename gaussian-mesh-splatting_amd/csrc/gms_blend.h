@@ -48,6 +48,8 @@ struct BlendBwdArgs {
     const float *dL_dinvd;      // [H,W] or NULL
     float *accum;               // [P,16] zero-filled 64-B gradient records (see GRAD_* below)
     int has_invd;
+    float *part;                // deterministic mode (gmsplat.h): partial records [instances][nsub][16], indexed by the instance's
+                                // position in the sorted key list; micro-tile kernels nsub = 1, quadrant kernels nsub = 4; else NULL
 };
 
 // Segment length L (entries per work unit).  GMS_SEG_LEN forces it (multiple of 64); otherwise the tile scan picks it

@@ -346,6 +346,12 @@ __device__ __forceinline__ float dot3p(float a, float b, float c, float d, float
 // fault injection for the parity criterion's negative controls (gmsplat.h, gms_set_fault); 0 in production
 int fault_mode();
 
+// Deterministic-reduction mode (gmsplat.h, gms_set_deterministic / env GAMES_HIP_DETERMINISTIC=1): every floating-point sum
+// of the backward passes runs in a fixed order -- no float atomics anywhere -- so two runs give bit-identical gradients.
+int det_mode();
+// library-owned device scratch of the deterministic mode, one growing buffer per (device, stream, slot); nullptr on failure
+void *det_scratch(int slot, size_t bytes, hipStream_t stream);
+
 // thread-local error text for gms_last_error()
 void set_error(const char *fmt, ...);
 

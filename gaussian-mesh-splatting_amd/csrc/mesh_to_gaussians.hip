@@ -336,8 +336,10 @@ __device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, in
 }
 
 // few splats per face: one thread per face
+// `corner_grad` != NULL (deterministic mode, gmsplat.h): the nine values of a face are STORED at corner_grad[9 f ..] and summed
+// per vertex, in ascending corner order, by det_vertex_gather_kernel -- no float atomics.
 __device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsigned block, const float *dL_dxyz, const float *dL_dscaling,
-                                                     const float *dL_drot, float *dL_dvertices, float *lds9, int *ldsi)
+                                                     const float *dL_drot, float *dL_dvertices, float *lds9, int *ldsi, float *corner_grad = nullptr)
 {
     const int f = (int)(block * BLOCK + threadIdx.x);
     const bool valid = f < a.F;
@@ -352,6 +354,13 @@ __device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsig
     face_splat_range(a, f, b, e);
     for (int64_t p = b; p < e; p++) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
     face_backward(a, f, fr, G, out);
+    }
+    if (corner_grad) {
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) corner_grad[9 * (size_t)f + k] = out[k];
+        }
+        return;
     }
     // Scatter into vertices.grad: the wave's 64 x 9 values are transposed through LDS so that three adjacent
     // lanes add the x, y, z of ONE vertex (same cache line -> one L2 transaction instead of three).
@@ -373,11 +382,11 @@ __device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsig
 }
 
 __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_thread_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
-                                                                     const float *dL_drot, float *dL_dvertices)
+                                                                     const float *dL_drot, float *dL_dvertices, float *corner_grad)
 {
     __shared__ float lds9[4 * WAVE * 9];
     __shared__ int ldsi[4 * WAVE * 3];
-    bwd_face_thread_body(a, blockIdx.x, dL_dxyz, dL_dscaling, dL_drot, dL_dvertices, lds9, ldsi);
+    bwd_face_thread_body(a, blockIdx.x, dL_dxyz, dL_dscaling, dL_drot, dL_dvertices, lds9, ldsi, corner_grad);
 }
 
 // One launch for the whole backward when the vertex gradient buffer was cleared ahead of time (by the forward's
@@ -396,7 +405,7 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_fused_kernel(GmsMeshArgs a, co
 
 // many splats per face (FLAME-like, 50-100): one wave per face, lanes stride over the splats
 __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_wave_kernel(GmsMeshArgs a, const float *dL_dxyz, const float *dL_dscaling,
-                                                                   const float *dL_drot, float *dL_dvertices)
+                                                                   const float *dL_drot, float *dL_dvertices, float *corner_grad)
 {
     const int lane = threadIdx.x & 63;
     const int f = blockIdx.x * (BLOCK / WAVE) + (threadIdx.x >> 6);
@@ -415,11 +424,71 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_face_wave_kernel(GmsMeshArgs a
     if (lane == 63) {
         float out[9];
         face_backward(a, f, fr, G, out);
+        if (corner_grad) {          // deterministic mode: stored, summed per vertex by det_vertex_gather_kernel
+            for (int k = 0; k < 9; k++) corner_grad[9 * (size_t)f + k] = out[k];
+            return;
+        }
         for (int k = 0; k < 3; k++) {
             const int64_t vi = a.faces[3 * (size_t)f + k];
             for (int c = 0; c < 3; c++) unsafeAtomicAdd(dL_dvertices + 3 * vi + c, out[3 * k + c]);
         }
     }
+}
+
+// ------------------------------------------------------------------ deterministic mode: vertex gradient without float atomics
+// vertex -> incident corners (corner c = 3 f + k) as a CSR built per call: integer counts, one-block exclusive scan, fill through
+// integer cursors (slot ORDER is arbitrary), then each vertex adds its corners' stored gradients in ASCENDING corner index --
+// found by repeated selection of the next larger index, O(degree^2) loads (degree ~ 6; the two poles of a UV sphere: hundreds).
+__global__ void __launch_bounds__(BLOCK) det_corner_count_kernel(int64_t n_corners, const int64_t *faces, uint32_t *cnt)
+{
+    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c < n_corners) atomicAdd(&cnt[faces[c]], 1u);
+}
+
+__global__ void __launch_bounds__(1024) det_scan_kernel(const uint32_t *cnt, uint32_t *off, int n)
+{
+    __shared__ uint32_t wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int b = min(n, tid * per), e = min(n, b + per);
+    uint32_t sum = 0;
+    for (int k = b; k < e; k++) sum += cnt[k];
+    uint32_t run = sum;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)run, d);
+        if (lane >= d) run += x;
+    }
+    if (lane == WAVE - 1) wave_tot[wave] = run;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; w++) base += wave_tot[w];
+    uint32_t pre = base + run - sum;                 // exclusive prefix of this thread's chunk
+    for (int k = b; k < e; k++) { off[k] = pre; pre += cnt[k]; }
+    if (tid == 1023) off[n] = pre;
+}
+
+__global__ void __launch_bounds__(BLOCK) det_corner_fill_kernel(int64_t n_corners, const int64_t *faces, const uint32_t *off, uint32_t *cur, uint32_t *adj)
+{
+    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n_corners) return;
+    const int64_t v = faces[c];
+    adj[off[v] + atomicAdd(&cur[v], 1u)] = (uint32_t)c;
+}
+
+__global__ void __launch_bounds__(BLOCK) det_vertex_gather_kernel(int V, const uint32_t *off, const uint32_t *adj, const float *corner_grad, float *dL_dvertices)
+{
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= V) return;
+    const uint32_t b = off[v], e = off[v + 1];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    int64_t last = -1;
+    for (uint32_t n = b; n < e; n++) {
+        int64_t next = INT64_MAX;
+        for (uint32_t k = b; k < e; k++) { const int64_t c = adj[k]; if (c > last && c < next) next = c; }
+        gx += corner_grad[3 * next]; gy += corner_grad[3 * next + 1]; gz += corner_grad[3 * next + 2];
+        last = next;
+    }
+    dL_dvertices[3 * (size_t)v] = gx; dL_dvertices[3 * (size_t)v + 1] = gy; dL_dvertices[3 * (size_t)v + 2] = gz;
 }
 
 }  // namespace gms
@@ -480,6 +549,33 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
         return GMS_ERR_INVALID_ARGUMENT;
     }
     const double avg_splats = (double)A->P / (double)(A->F > 0 ? A->F : 1);
+    if (det_mode()) {
+        // deterministic mode (gmsplat.h): per-corner gradients stored, then summed per vertex in ascending corner index
+        const int64_t nc = 3 * (int64_t)A->F;
+        float *corner_grad = static_cast<float *>(det_scratch(1, (size_t)nc * 3 * sizeof(float), stream));
+        uint32_t *cnt = static_cast<uint32_t *>(det_scratch(2, ((size_t)A->V * 3 + 2) * sizeof(uint32_t), stream));
+        uint32_t *adj = static_cast<uint32_t *>(det_scratch(3, (size_t)(nc > 0 ? nc : 1) * sizeof(uint32_t), stream));
+        if (!corner_grad || !cnt || !adj) { set_error("deterministic mode: scratch allocation failed"); return GMS_ERR_ALLOC; }
+        uint32_t *cur = cnt + A->V, *off = cnt + 2 * (size_t)A->V;
+        GMS_HIP_CHECK(hipMemsetAsync(cnt, 0, (size_t)A->V * 2 * sizeof(uint32_t), stream));
+        GMS_LAUNCH(GMS_K_MESH_BWD_SPLAT, stream, mesh_bwd_splat_kernel<<<(unsigned)((A->P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_dalpha, dL_dscale, dL_dvertices, dL_dopacity_act, dL_d_opacity));
+        if (avg_splats >= 16.0) {
+            const int fpb = BLOCK / WAVE;
+            GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices, corner_grad));
+        } else {
+            GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices, corner_grad));
+        }
+        if (nc > 0) {
+            det_corner_count_kernel<<<(unsigned)((nc + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(nc, A->faces, cnt);
+            det_scan_kernel<<<1, 1024, 0, stream>>>(cnt, off, A->V);
+            det_corner_fill_kernel<<<(unsigned)((nc + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(nc, A->faces, off, cur, adj);
+        } else {
+            GMS_HIP_CHECK(hipMemsetAsync(off, 0, ((size_t)A->V + 1) * sizeof(uint32_t), stream));
+        }
+        det_vertex_gather_kernel<<<(unsigned)((A->V + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(A->V, off, adj, corner_grad, dL_dvertices);
+        GMS_KERNEL_CHECK(0, stream, "mesh_bwd (deterministic)");
+        return GMS_OK;
+    }
     if (A->vertex_grad_prezeroed && avg_splats < 16.0) {
         const unsigned fb = (unsigned)((A->F + BLOCK - 1) / BLOCK), sb = (unsigned)((A->P + BLOCK - 1) / BLOCK);
         GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_fused_kernel<<<fb + sb, BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices,
@@ -492,9 +588,9 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
     const double avg = (double)A->P / (double)(A->F > 0 ? A->F : 1);
     if (avg >= 16.0) {
         const int fpb = BLOCK / WAVE;
-        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices));
+        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_wave_kernel<<<(unsigned)((A->F + fpb - 1) / fpb), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices, nullptr));
     } else {
-        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices));
+        GMS_LAUNCH(GMS_K_MESH_BWD_FACE, stream, mesh_bwd_face_thread_kernel<<<(unsigned)((A->F + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(*A, dL_dxyz, dL_dscaling, dL_drotation, dL_dvertices, nullptr));
     }
     GMS_KERNEL_CHECK(0, stream, "mesh_bwd_face");
     return GMS_OK;

@@ -65,6 +65,38 @@ static int g_fault = 0;
 int fault_mode() { return g_fault; }
 #endif
 
+// ---- deterministic-reduction mode (gmsplat.h)
+static int g_det = -1;          // -1: not yet read from the environment
+int det_mode()
+{
+    if (g_det < 0) { const char *e = getenv("GAMES_HIP_DETERMINISTIC"); g_det = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_det;
+}
+
+namespace {
+struct DetBuf { int device; hipStream_t stream; int slot; void *p; size_t cap; };
+std::mutex g_det_mu;
+std::vector<DetBuf> g_det_bufs;
+}  // namespace
+
+void *det_scratch(int slot, size_t bytes, hipStream_t stream)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    DetBuf *b = nullptr;
+    for (auto &x : g_det_bufs) if (x.device == device && x.stream == stream && x.slot == slot) b = &x;
+    if (!b) { g_det_bufs.push_back({device, stream, slot, nullptr, 0}); b = &g_det_bufs.back(); }
+    if (b->cap < bytes) {
+        // (the previous buffer may still be in use by work queued on this stream)
+        if (b->p) { if (hipStreamSynchronize(stream) != hipSuccess) return nullptr; (void)hipFree(b->p); b->p = nullptr; b->cap = 0; }
+        const size_t want = bytes + bytes / 4;
+        if (hipMalloc(&b->p, want) != hipSuccess) { b->p = nullptr; return nullptr; }
+        b->cap = want;
+    }
+    return b->p;
+}
+
 namespace {
 struct Pair { int kid; hipEvent_t e0, e1; };
 std::mutex g_mu;
@@ -146,5 +178,7 @@ extern "C" const char *gms_profile_kernel_name(int32_t kid)
     return (kid >= 0 && kid < GMS_K_COUNT) ? k_names[kid] : "";
 }
 
+extern "C" void gms_set_deterministic(int32_t on) { gms::g_det = on ? 1 : 0; }
+extern "C" int32_t gms_get_deterministic(void) { return gms::det_mode(); }
 extern "C" void gms_set_fault(int32_t fault) { gms::g_fault = fault > 0 ? fault : 0; }
 extern "C" int32_t gms_get_fault(void) { return gms::fault_mode(); }

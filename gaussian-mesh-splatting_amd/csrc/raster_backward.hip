@@ -398,6 +398,42 @@ __global__ void fault_scale_kernel(float *base, int rows, int stride, int field,
     if (i < rows) base[(size_t)i * stride + field] *= factor;
 }
 
+// ------------------------------------------------------------------------------------ deterministic mode: ordered reduction
+// The blend kernels left one partial record per (Gaussian, tile) instance (NSUB = 1, micro-tile kernels) or per instance and 8x8
+// quadrant (NSUB = 4), indexed by the instance's position in the sorted key list.  Sixteen lanes per Gaussian (lane = field of the
+// 64-byte record): walk the Gaussian's tile rectangle in emission order (y outer, x inner), find the instance in the tile's sorted
+// list by binary search on its unique (depth bits, id) key, and add its NSUB records in index order.  Plain store into the
+// Gaussian's gradient record (all zero on entry, as always).
+template <int NSUB>
+__global__ void __launch_bounds__(BLOCK) det_reduce_kernel(int P, int gx, int gy, const int *radii, const SplatRec *rec, const float *depth,
+                                                           const uint32_t *tile_offset, const uint64_t *keys, uint64_t capacity,
+                                                           const float *part, float *accum)
+{
+    const int i = (int)((blockIdx.x * (unsigned)BLOCK + threadIdx.x) >> 4), f = (int)(threadIdx.x & 15u);
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float4 q0 = rec[i].q0;
+    int minx, miny, maxx, maxy;
+    tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
+    const uint64_t key = ((uint64_t)__float_as_uint(depth[i]) << 32) | (uint32_t)i;
+    float acc = 0.f;
+    for (int ty = miny; ty < maxy; ty++)
+        for (int tx = minx; tx < maxx; tx++) {
+            const int t = ty * gx + tx;
+            uint32_t lo = tile_offset[t], hi = tile_offset[t + 1];
+            if ((uint64_t)hi > capacity) return;
+            while (lo < hi) {                                    // first position with keys[pos] >= key
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                if (keys[mid] < key) lo = mid + 1; else hi = mid;
+            }
+            // (keys[lo] == key by construction: every tile of the rectangle holds this Gaussian exactly once)
+#pragma unroll
+            for (int sub = 0; sub < NSUB; sub++) acc += part[((size_t)lo * NSUB + sub) * GRAD_STRIDE + f];
+        }
+    if (f < 10) accum[(size_t)i * GRAD_STRIDE + f] = acc;
+}
+
 // ------------------------------------------------------------------------------------ factorised SH gradient
 // dL/dsh[k][c] of one view is the outer product Y_k(dir) * dL/dcolour_c (clamp mask folded into dL/dcolour), and dir depends
 // only on the Gaussian's position and that view's camera centre.  A multi-view step therefore exchanges the [P,3] factors of
@@ -519,10 +555,27 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
         b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.accum = A->grad_accum;
         b.has_invd = A->dL_dout_invdepth != nullptr;
+        b.part = nullptr;
         uint32_t mu = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L);
         if (A->num_units > 0 && (uint64_t)A->num_units < mu) mu = (uint32_t)A->num_units;      // exact count from the forward
-        int32_t rc = use_micro(cap, T) ? launch_micro_backward(g, b, mu, A->debug != 0, stream) : launch_blend_backward(g, b, mu, A->debug != 0, stream);
+        const bool micro = use_micro(cap, T);
+        const bool det = det_mode() != 0 && fault_mode() == 0;
+        if (det) {      // deterministic mode (gmsplat.h): partial records per instance, then an ordered reduction per Gaussian
+            const size_t nsub = micro ? 1 : 4, bytes = (size_t)A->num_rendered * nsub * GRAD_STRIDE * sizeof(float);
+            b.part = static_cast<float *>(det_scratch(0, bytes, stream));
+            if (!b.part) { set_error("deterministic mode: scratch allocation of %zu bytes failed", bytes); return GMS_ERR_ALLOC; }
+            // the quadrant kernels store only the (instance, quadrant) pairs that survive their culls; the micro-tile flush writes
+            // every instance (zeros included) and needs no clearing
+            if (!micro) GMS_HIP_CHECK(hipMemsetAsync(b.part, 0, bytes, stream));
+        }
+        int32_t rc = micro ? launch_micro_backward(g, b, mu, A->debug != 0, stream) : launch_blend_backward(g, b, mu, A->debug != 0, stream);
         if (rc != GMS_OK) return rc;
+        if (det) {
+            const unsigned rblocks = (unsigned)(((size_t)P * 16 + BLOCK - 1) / BLOCK);
+            if (micro) det_reduce_kernel<1><<<rblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom.rec, geom.depth, img.tile_offset, bin.keys, cap, b.part, A->grad_accum);
+            else det_reduce_kernel<4><<<rblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom.rec, geom.depth, img.tile_offset, bin.keys, cap, b.part, A->grad_accum);
+            GMS_KERNEL_CHECK(A->debug, stream, "det_reduce");
+        }
         if (fault_mode() == 1)      // negative control: sum(q dx^2) of every 1000th Gaussian off by 2e-3
             fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->grad_accum, P, GRAD_STRIDE, GRAD_CA, 1000, 1.002f);
     }
@@ -538,6 +591,9 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
     if (fault_mode() == 4 && A->dL_dscales)      // negative control: dL/dscale.x of every 1000th Gaussian off by 2e-3
         fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->dL_dscales, P, 3, 0, 1000, 1.002f);
+    if (fault_mode() == 5 && A->dL_dscales)      // negative control: dL/dscale of every 100th Gaussian off by 1.3e-3 (between 1e-3 and 2e-3)
+        for (int f = 0; f < 3; f++)
+            fault_scale_kernel<<<(unsigned)((P / 100 + 256) / 256), 256, 0, stream>>>(A->dL_dscales, P, 3, f, 100, 1.0013f);
     return GMS_OK;
 }
 

@@ -125,6 +125,17 @@ def clear_capacity_hints() -> None:
     _capacity_cache.clear()
 
 
+def set_deterministic(on: bool) -> None:
+    """Deterministic-reduction mode (include/gmsplat.h, gms_set_deterministic): the backward passes of the rasterizer and of the
+    mesh op sum in a fixed order with no float atomics -- two runs on the same inputs give bit-identical gradients.  Slower;
+    process-wide; also switched on by the environment variable GAMES_HIP_DETERMINISTIC=1."""
+    _lib.load().gms_set_deterministic(1 if on else 0)
+
+
+def deterministic() -> bool:
+    return bool(_lib.load().gms_get_deterministic())
+
+
 def set_sh_factor_mode(on: bool) -> None:
     """Factorised SH gradient for multi-view steps (include/gmsplat.h, gms_sh_grad_expand).  While on, a backward on the SH path
     writes NO dL/dsh (the `shs` gradient is None): it queues a [P+1,3] tensor -- rows 0..P-1 the clamp-masked dL/dcolour of that

@@ -97,7 +97,7 @@ EXPORTS = (
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
-    "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault",
+    "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault", "gms_set_deterministic", "gms_get_deterministic",
 )
 K_COUNT = 17
 
@@ -164,6 +164,9 @@ def load():
         lib.gms_set_fault.argtypes = [C.c_int32]
         lib.gms_set_fault.restype = None
         lib.gms_get_fault.restype = C.c_int32
+        lib.gms_set_deterministic.argtypes = [C.c_int32]
+        lib.gms_set_deterministic.restype = None
+        lib.gms_get_deterministic.restype = C.c_int32
         if lib.gms_abi_version() != GMS_ABI_VERSION:
             raise RuntimeError(f"libgmsplat.so ABI {lib.gms_abi_version()} != binding ABI {GMS_ABI_VERSION}; rebuild")
         _lib = lib

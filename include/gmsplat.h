@@ -325,6 +325,22 @@ size_t gms_image_bytes(int32_t width, int32_t height);
 size_t gms_image_n_contrib_offset(int32_t width, int32_t height);
 size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
+/* ---- deterministic-reduction mode (SURVEY.md section 5 "race detection", section 7 hard part 1) ---------------------------
+ * The reference's CUDA rasterizer accumulates gradients with float atomics (run-to-run noise of
+ * 1e-7..1e-6 relative) and so does this library by default (the blend kernels' per-Gaussian records, the vertex gradient of the
+ * mesh op).  With the mode ON every floating-point sum of gms_rasterize_backward and gms_mesh_to_gaussians_backward runs in a
+ * FIXED order and no float atomic is issued, so two runs on the same inputs give bit-identical gradients:
+ *   - compositing backward: each wave keeps its own LDS table, the rows of a wave add in row order, a unit leaves ONE partial
+ *     record per (Gaussian, tile) instance (quadrant kernels: one per instance and 8x8 quadrant) with plain stores;
+ *   - a reduction kernel sums a Gaussian's partial records in the order of its tile rectangle (y outer, x inner), finding each
+ *     instance in the tile's sorted list by binary search on its (depth, id) key;
+ *   - mesh op: per-(face, corner) gradients are stored, and each vertex sums its incident corners in ascending corner index.
+ * Scratch comes from library-owned buffers (64 B per instance; 256 B with the quadrant kernels; 36 B per face).  Slower (the
+ * default path's cost is stated in DESIGN.md); meant for tests, debugging and bit-reproducible training runs.
+ * Default: off, or the environment variable GAMES_HIP_DETERMINISTIC=1 read at first use; process-wide. */
+void gms_set_deterministic(int32_t on);
+int32_t gms_get_deterministic(void);
+
 /* ---- fault injection (test infrastructure of the PARITY CRITERION, not of the kernels) -------------------------------
  * tests/test_gpu_negative_controls.py must show that the gradient criterion of tests/_util.py can FAIL: a deliberately
  * wrong backward has to trip it.  `fault` selects one defect for the calling process until reset to 0 (the default).  Only this
@@ -335,7 +351,9 @@ size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
  *      behind it (the suffix of the later segments)
  *   3  the gradient records are NOT cleared after preprocess_bwd consumed them: the next backward of this (device,
  *      stream, P) adds the previous frame's moments to its own
- *   4  preprocess_bwd: dL/dscale of every 1000th Gaussian is scaled by 1 + 2e-3 */
+ *   4  preprocess_bwd: dL/dscale of every 1000th Gaussian is scaled by 1 + 2e-3
+ *   5  preprocess_bwd: dL/dscale (all three components) of every 100th Gaussian is scaled by 1 + 1.3e-3 -- a defect between the
+ *      1e-3 tolerance and the 2e-3 of faults 1 / 4, on 1 % of the rows */
 void gms_set_fault(int32_t fault);
 int32_t gms_get_fault(void);
 

@@ -1,6 +1,16 @@
+# Round-4 GPU run (bash tools/r04_run.sh TAG [what]): what = tests | ab | all
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-python -m pytest tests -m gpu -q -x 2>&1 | tail -15 > gpurun_out/r04a_pytest_gpu.log
-tail -3 gpurun_out/r04a_pytest_gpu.log
-python bench.py --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/r04a_bench.json.log 2> gpurun_out/r04a_bench.err
-python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_1m --profile-steps 10 > gpurun_out/r04a_bench_c5.json.log 2>&1
-grep -h -o '"value": [0-9.]*' gpurun_out/r04a_bench*.json.log
+T=${1:-r04}; WHAT=${2:-all}
+B="python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "ab" ]; then
+  for v in "GMS_BWD_PIPE=0" "GMS_BWD_PIPE=1" "GMS_BWD_PIPE=2" "GMS_BWD_PIPE=1 GMS_TRIP_BWD=1" "GMS_TRIP_BWD=1"; do
+    tag=$(echo "$v" | tr ' =' '__')
+    env $v $B > gpurun_out/${T}_ab_${tag}.json.log 2> gpurun_out/${T}_ab_${tag}.err
+    echo "$v: $(grep -o '"value": [0-9.]*' gpurun_out/${T}_ab_${tag}.json.log) $(grep -o '"blend_bwd": {"avg_us": [0-9.]*' gpurun_out/${T}_ab_${tag}.json.log)"
+  done
+fi
+if [ "$WHAT" = "all" ] || [ "$WHAT" = "tests" ]; then
+  rm -f gpurun_out/parity_report.jsonl
+  python -m pytest tests -m gpu -q -x 2>&1 | tail -25 > gpurun_out/${T}_pytest_gpu.log
+  tail -4 gpurun_out/${T}_pytest_gpu.log
+fi
