@@ -40,6 +40,13 @@
 // inside one instruction are rare -- 2.8 % of the trips, tools/row_collisions.py -- and were sent to the atomic): 191 us
 // against 177 us for the atomic kernel padded to the same 52 KB of LDS (3 blocks per CU), 143 us at its own 25 KB (6 per CU);
 // 8-entry instead of 16-entry queues (18.9 KB, 8 blocks per CU): 144.7 against 142 us, the refills double.
+// Round 4, the trip loop software-pipelined over its LDS traffic (reads of trip t+1 issued before the recurrence of trip t and
+// consumed after it; the ds_adds deferred by one trip so that the single lgkmcnt wait of an iteration covers only operations
+// issued a whole trip earlier -- the compiler branches around every exec-masked DS instruction and must then assume at the join
+// that it was skipped, so any later wait for an older read is lgkmcnt(0)): 166 us at two entries per trip (92 VGPRs: 5 waves
+// per SIMD instead of 6), 147 us at one entry per trip (154 unpipelined) against 143 us for this kernel; with unconditional
+// 64-lane ds_adds on dummy targets (exact wait counts) 247 us.  Timing experiments of the same round (wrong results): a plain
+// LDS store instead of the ds_add 118 us, no LDS write at all 136 us, no global atomics in the flush 140 us.
 // The backward is bound by dependent latency, not by LDS atomic throughput: blocks per CU 3 / 4 / 5 / 6 -> 177 / 156 / 147 /
 // 143 us (unused dynamic LDS as the only change), VALU issue 0.28 of peak, 57 % of the wave cycles in s_waitcnt.
 #include <stdlib.h>
@@ -410,24 +417,17 @@ __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, 
 // DET (deterministic mode, gmsplat.h): one table per WAVE (no cross-wave adds), the four rows of a wave add one after the other
 // (two rows of one instruction can hold the same entry), and the flush sums the four tables in wave-group order into ONE partial
 // record per instance, stored -- not added -- at the instance's position in the sorted list: no float atomic, fixed order.
-// PIPE (round 4): the trip loop software-pipelined over its LDS reads.  Before, a trip was  ds_read (records) -> wait -> exponent,
-// exp, alpha -> ds_read (entry ids, colours) -> wait -> recurrence -> row reduction -> ds_add: two exposed LDS round trips per
-// trip in a kernel whose waves spend 57 % of their cycles in s_waitcnt.  Now the reads of trip t+1 are issued BEFORE the
-// recurrence of trip t and consumed AFTER its ds_adds, in straight-line code with exactly NE ds_adds in between (they are issued
-// unconditionally, exec-masked): LDS operations of a wave complete in order, so the compiler can wait with lgkmcnt(NE) -- for the
-// reads only, not for the fire-and-forget adds -- and the independent front of the next trip (exponent -> exp -> alpha ->
-// activity test) runs while this trip's adds drain.  Same arithmetic per pair, same order of the adds: results are bit-identical.
-template <bool INVD, int NE, int FAULT, bool DET = false, bool PIPE = false, int WAVES = 1>
-__global__ void __launch_bounds__(BLOCK, WAVES) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
+template <bool INVD, int NE, int FAULT, bool DET = false>
+__global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    __shared__ SplatRec recs_all[4][QSLOTS + (PIPE ? NE : 0)];      // (PIPE: the last trip of a batch pre-reads NE slots past the queue)
-    __shared__ uint32_t eid_all[4][QSLOTS + (PIPE ? NE : 0)];       // entry index (within the unit) of every queue slot
-    __shared__ float table_all[(DET ? 4 : 1) * LMAX * 10 + (PIPE ? BLOCK : 0)];      // (PIPE: + one dummy word per thread)
+    __shared__ SplatRec recs_all[4][QSLOTS];
+    __shared__ uint32_t eid_all[4][QSLOTS];            // entry index (within the unit) of every queue slot
+    __shared__ float table_all[(DET ? 4 : 1) * LMAX * 10];
     __shared__ UnitShared S;
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
-    for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10 + (PIPE ? BLOCK : 0); k += BLOCK) table_all[k] = 0.f;
+    for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     unit_setup<false>(g, u, S, a.rec);                  // (its barrier also orders the table clear)
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     float *const table = table_all + (DET ? q * LMAX * 10 : 0);
@@ -518,76 +518,6 @@ __global__ void __launch_bounds__(BLOCK, WAVES) micro_bwd_kernel(BlendGrid g, Bl
         }
         wave_sync();
         const int nt = (int)min(16u, maxtop - g0);
-        if (PIPE) {
-            bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE]; uint32_t se[NE];
-            float4 n0[NE], n1[NE], n2[NE]; uint32_t nse[NE];
-            // raw LDS reads of the trip that starts at queue slot t (slots past the batch hold stale records: masked by `trip < top`)
-#define GMS_BWD_LOAD(t)                                                                       \
-            _Pragma("unroll") for (int e = 0; e < NE; e++) {                                  \
-                const SplatRec *sr = recs + row * QROW + (t) + e;                             \
-                n0[e] = sr->q0; n1[e] = sr->q1; n2[e] = sr->q2;                               \
-                nse[e] = eid[row * QROW + (t) + e];                                           \
-            }
-            // the part of a trip that does not depend on the recurrence: exponent, exp, alpha, activity
-#define GMS_BWD_PRE(t)                                                                        \
-            _Pragma("unroll") for (int e = 0; e < NE; e++) {                                  \
-                r1[e] = n1[e]; r2[e] = n2[e]; se[e] = nse[e];                                 \
-                dx[e] = n0[e].x - p.xf; dy[e] = n0[e].y - p.yf;                               \
-                const float pw = pair_power(n0[e].z, n0[e].w, r1[e].x, dx[e], dy[e]);         \
-                G[e] = __expf(pw);                                                            \
-                al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);                                     \
-                const uint32_t trip = g0 + (uint32_t)((t) + e);                               \
-                act[e] = trip < top && (top - 1u - trip) < lrel && pw <= 0.f && al[e] >= ALPHA_MIN; \
-            }
-            GMS_BWD_LOAD(0)
-            GMS_BWD_PRE(0)
-            for (int t = 0; t < nt; t += NE) {
-                GMS_BWD_LOAD(t + NE)
-                bool anyact = false;
-#pragma unroll
-                for (int e = 0; e < NE; e++) anyact = anyact || act[e];
-                float y[NE];
-#pragma unroll
-                for (int e = 0; e < NE; e++) y[e] = 0.f;
-                if (__any(anyact)) {
-#pragma unroll
-                    for (int e = 0; e < NE; e++) {
-                        float v[10];
-                        bwd_step<INVD>(st8, act[e], r1[e], r2[e], dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
-                        y[e] = row_reduce10(v, b3, b2, b1, b0);
-                    }
-                }
-                // always issued (exec-masked): the number of LDS operations between the reads above and their first use below is
-                // the same on every path
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    if (DET) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            if (row == r && alane && y[e] != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y[e]);
-                            asm volatile("" ::: "memory");
-                        }
-                    } else {
-                        // UNCONDITIONAL ds_add (all 64 lanes): the compiler always branches around an exec-masked DS instruction
-                        // (s_cbranch_execz), and at the join it must assume the add was skipped -- every later lgkmcnt wait for
-                        // the pre-read records then waits for the adds as well.  Lanes with nothing to add put an exact 0 into
-                        // a per-lane dummy word behind the table instead.
-                        const bool doadd = alane && y[e] != 0.f;
-                        atomicAdd(&table[doadd ? se[e] * 10u + (uint32_t)afield : (uint32_t)(LMAX * 10 + (threadIdx.x & 255))], doadd ? y[e] : 0.f);
-                    }
-                }
-                // the pre-read records become visible to the code below only here, after the adds: their wait sits behind a
-                // whole trip of arithmetic (without this the scheduler hoists a register copy of a pre-read word to the top)
-#pragma unroll
-                for (int e = 0; e < NE; e++)
-                    asm volatile("" : "+v"(n0[e].x), "+v"(n0[e].y), "+v"(n0[e].z), "+v"(n0[e].w), "+v"(n1[e].x), "+v"(n1[e].y), "+v"(n1[e].z),
-                                 "+v"(n1[e].w), "+v"(n2[e].x), "+v"(n2[e].y), "+v"(nse[e]));
-                GMS_BWD_PRE(t + NE)
-            }
-#undef GMS_BWD_LOAD
-#undef GMS_BWD_PRE
-            continue;
-        }
         for (int t = 0; t < nt; t += NE) {
             bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE], r2[NE]; uint32_t se[NE];
             bool anyact = false;
@@ -674,8 +604,6 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
-    static int pipe = -1;
-    if (pipe < 0) { const char *e = getenv("GMS_BWD_PIPE"); pipe = e ? atoi(e) : 0; }
     const bool invd = a.has_invd && a.dL_dinvd;
     if (a.part) {                           // deterministic mode (gmsplat.h): per-wave tables, ordered adds, per-instance partial records
         if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
@@ -684,12 +612,6 @@ int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else if (fault_mode() == 9 && !invd) {      // timing experiment (wrong results): no atomics
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<blocks, BLOCK, 0, stream>>>(g, a)));
-    } else if (pipe == 2 && !invd) {        // (experiment: NE = 2 register-capped for 6 waves per SIMD -- spills 116 B)
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, false, true, 6><<<blocks, BLOCK, 0, stream>>>(g, a)));
-    } else if (pipe && trip == 2) {
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (invd ? micro_bwd_kernel<true, 2, 0, false, true, 4> : micro_bwd_kernel<false, 2, 0, false, true, 5>)<<<blocks, BLOCK, 0, stream>>>(g, a));
-    } else if (pipe && trip == 1) {
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (invd ? micro_bwd_kernel<true, 1, 0, false, true, 6> : micro_bwd_kernel<false, 1, 0, false, true, 6>)<<<blocks, BLOCK, 0, stream>>>(g, a));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)

@@ -124,7 +124,9 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
 
     int64_t hint = 0;
     const auto key = std::make_tuple((int)dev.index(), (int)W, (int)H, P);
-    if (use_hint) {
+    // deterministic mode (gmsplat.h): no capacity hint -- the segment length and the choice of compositing kernels then depend on the
+    // frame alone (the exact instance count), not on what earlier frames of this shape looked like: run 1 == run 2 bit for bit
+    if (use_hint && !gms_get_deterministic()) {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_capacity.find(key);
         if (it != g_capacity.end()) hint = quantize_capacity(it->second + it->second / 4 + 4096);

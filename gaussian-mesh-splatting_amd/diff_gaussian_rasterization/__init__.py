@@ -346,7 +346,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         scratch = _Scratch(device)
         key = (device.index, W, H, P)
         hint = 0
-        if os.environ.get("GMS_SYNC_BINNING", "0") != "1":
+        # (deterministic mode: no hint -- segment length / kernel choice then depend on this frame alone, not on earlier ones)
+        if os.environ.get("GMS_SYNC_BINNING", "0") != "1" and not lib.gms_get_deterministic():
             prev = _capacity_cache.get(key)
             if prev is not None:
                 hint = _quantize_capacity(int(prev * 1.25) + 4096)

@@ -335,6 +335,9 @@ size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
  *   - a reduction kernel sums a Gaussian's partial records in the order of its tile rectangle (y outer, x inner), finding each
  *     instance in the tile's sorted list by binary search on its (depth, id) key;
  *   - mesh op: per-(face, corner) gradients are stored, and each vertex sums its incident corners in ascending corner index.
+ * Callers should also pass binning_capacity_hint = 0 in this mode (both bindings do): with a hint, the segment length and the
+ * choice between the micro-tile and the quadrant kernels follow the hint -- the history of earlier frames -- and a frame's sums
+ * are then grouped differently from the same frame rendered first.
  * Scratch comes from library-owned buffers (64 B per instance; 256 B with the quadrant kernels; 36 B per face).  Slower (the
  * default path's cost is stated in DESIGN.md); meant for tests, debugging and bit-reproducible training runs.
  * Default: off, or the environment variable GAMES_HIP_DETERMINISTIC=1 read at first use; process-wide. */
