@@ -12,7 +12,8 @@ import os
 import sys
 import types
 
-REFERENCE_ROOT = os.environ.get("GAMES_REFERENCE_ROOT", "/root/reference")
+# GMS_REFERENCE_DIR (or the older GAMES_REFERENCE_ROOT): where a checkout of waczjoan/gaussian-mesh-splatting lives
+REFERENCE_ROOT = os.environ.get("GMS_REFERENCE_DIR", os.environ.get("GAMES_REFERENCE_ROOT", "/root/reference"))
 
 
 def available() -> bool:
@@ -95,10 +96,20 @@ def cuda_literals_on_cpu():
 
     orig_cuda = torch.Tensor.cuda
     orig_mod_cuda = torch.nn.Module.cuda
+    orig_to = torch.Tensor.to
+
+    def to(self, *a, **k):          # `.to("cuda")` (train.py:204)
+        if a and isinstance(a[0], str) and a[0].startswith("cuda"):
+            a = ("cpu",) + tuple(a[1:])
+        if isinstance(k.get("device"), str) and k["device"].startswith("cuda"):
+            k = dict(k, device="cpu")
+        return orig_to(self, *a, **k)
+
     for n in names:
         setattr(torch, n, wrap(orig[n]))
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.Tensor.to = to
     try:
         yield
     finally:
@@ -106,3 +117,4 @@ def cuda_literals_on_cpu():
             setattr(torch, n, orig[n])
         torch.Tensor.cuda = orig_cuda
         torch.nn.Module.cuda = orig_mod_cuda
+        torch.Tensor.to = orig_to

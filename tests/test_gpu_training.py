@@ -48,3 +48,104 @@ def test_training_loop_fits_a_target_image():
     assert after < 0.5 * before, (before, after)
     for p in student.parameters():
         assert torch.isfinite(p).all()
+
+
+def _c3_setup(workload, views, size=None, seed=0):
+    """BASELINE config 3 in small: teacher targets, student from the reference's initialisation (tools/train_c3.py does the same
+    at the hotdog size for 7 000 iterations)."""
+    import random
+    from games_hip.model import HipGaussianMeshModel
+    from games_hip.render import PipelineParams, render
+    random.seed(seed); torch.manual_seed(seed)
+    teacher_scene = syn.mesh_scene(workload, state="trained")
+    size = size or teacher_scene.meta["image"]
+    cams = [syn.orbit_camera(k, n_views=views, width=size, height=size).to("cuda") for k in range(views)]
+    bg = torch.ones(3, device="cuda")
+    teacher = HipGaussianMeshModel.from_scene(teacher_scene, "cuda")
+    with torch.no_grad():
+        for c in cams:
+            c.original_image = render(c, teacher, PipelineParams(), bg)["render"].clone()
+    student = HipGaussianMeshModel.from_scene(syn.mesh_scene(workload, state="init"), "cuda")
+    student.active_sh_degree = 0
+    return student, cams, bg
+
+
+def test_config3_loop_of_train_py_ramps_sh_and_improves_psnr():
+    """games_hip/train.py (= train.py:39-157; the reference's own function walks the same trajectory:
+    tests/test_reference_train_cpu.py) on the HIP kernels: random camera order, SH degree raised at iterations 1000 and 2000, fused
+    loss, FusedAdam, K0 refresh after every step."""
+    from games_hip.render import PipelineParams
+    from games_hip.train import OptimizationParamsMesh, training
+    student, cams, bg = _c3_setup("small", views=4)
+    opt = OptimizationParamsMesh(iterations=2100, vertices_lr=0.00016)
+    student.training_setup(vertices_lr=opt.vertices_lr, alpha_lr=opt.alpha_lr, feature_lr=opt.feature_lr, opacity_lr=opt.opacity_lr,
+                           scaling_lr=opt.scaling_lr, fused=True)
+    losses = training(student, cams, opt, PipelineParams(), bg, report_iterations=[1, 1000, 2100])
+    assert student.active_sh_degree == 2
+    assert losses[1] < 0.6 * losses[0] and losses[2] <= losses[1] * 1.05, losses
+    assert all(torch.isfinite(p).all() for p in student.parameters())
+
+
+def test_deterministic_mode_makes_the_training_trajectory_reproducible():
+    """Two runs of 40 training iterations in deterministic-reduction mode end in bit-identical parameters (fixed-order gradient
+    sums, deterministic fused loss, elementwise Adam); the same two runs with float atomics do not."""
+    import diff_gaussian_rasterization as dgr
+    from games_hip.render import PipelineParams
+    from games_hip.train import OptimizationParamsMesh, training
+
+    def run():
+        student, cams, bg = _c3_setup("small", views=3)
+        opt = OptimizationParamsMesh(iterations=40, vertices_lr=0.00016)
+        student.training_setup(vertices_lr=opt.vertices_lr, alpha_lr=opt.alpha_lr, feature_lr=opt.feature_lr, opacity_lr=opt.opacity_lr,
+                               scaling_lr=opt.scaling_lr, fused=True)
+        training(student, cams, opt, PipelineParams(), bg)
+        return [p.detach().clone() for p in student.parameters()]
+
+    was = dgr.deterministic()
+    try:
+        dgr.set_deterministic(True)
+        a, b = run(), run()
+        dgr.set_deterministic(False)
+        c, d = run(), run()
+    finally:
+        dgr.set_deterministic(was)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not all(torch.equal(x, y) for x, y in zip(c, d))
+    # the two modes compute the same thing: after 40 steps the parameters agree to the accumulated atomics noise
+    for x, y in zip(a, c):
+        assert float((x - y).abs().max()) <= 1e-3 * float(x.abs().max()) + 1e-6
+
+
+def test_config3_gradcheck_on_a_1k_gaussian_slice_of_the_hotdog_model():
+    """BASELINE config 3: "gradcheck vs reference on 1k-Gaussian slice".  The hotdog-size model after 30 training iterations (a
+    mid-training state: opacities, scales, colours and vertices have moved); Gaussians 150 000 .. 151 001 (334 faces x 3) are
+    rendered alone at 800x800 through the HIP rasterizer and through the oracle on identical inputs; every gradient tensor meets
+    the suite's criterion (1e-3 relative) and the image 1e-4."""
+    import numpy as np
+    import _util as U
+    from games_hip.render import PipelineParams
+    from games_hip.train import OptimizationParamsMesh, training
+    student, cams, bg = _c3_setup("c2_hotdog_like", views=8)
+    opt = OptimizationParamsMesh(iterations=30, vertices_lr=0.00016)
+    student.training_setup(vertices_lr=opt.vertices_lr, alpha_lr=opt.alpha_lr, feature_lr=opt.feature_lr, opacity_lr=opt.opacity_lr,
+                           scaling_lr=opt.scaling_lr, fused=True)
+    training(student, cams, opt, PipelineParams(), bg)
+    student.active_sh_degree = 3
+    sl = slice(150000, 151002)
+    with torch.no_grad():
+        student.update_alpha(); student.prepare_scaling_rot()
+        feats = torch.cat([student._features_dc, student._features_rest], dim=1)
+        inputs = dict(means3D=student.get_xyz[sl].cpu(), opacities=student.get_opacity[sl].cpu(), shs=feats[sl].cpu(),
+                      scales=student.get_scaling[sl].cpu(), rotations=student.get_rotation[sl].cpu())
+    cam = syn.orbit_camera(3, width=800, height=800)
+    kw = U.settings_kwargs(cam, torch.ones(3))
+    o = U.oracle_render(inputs, kw)
+    assert int((o["radii"] > 0).sum()) > 500                        # the slice faces this camera
+    gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
+    o = U.oracle_render(inputs, kw, gc)
+    h = U.hip_render(inputs, kw, grad_color=gc)
+    rep = U.forward_report(h, o, 800, 800)
+    assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= 1e-4 and rep["max_amb"] <= 0.02, rep
+    U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, precision="f64")["grads"],
+                   where="config 3: 1k-Gaussian slice", excuse=U.excused_rows(o["details"]),
+                   go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc), alt=U.alt_oracles(inputs, kw, gc, None, o["details"]))

@@ -1,0 +1,173 @@
+"""CPU, authoring container (or any machine that holds the reference: GAMES_REFERENCE_ROOT / GMS_REFERENCE_DIR): the REFERENCE's own
+`train.training()` (train.py:39-157) runs UNMODIFIED on the drop-in packages -- its `render()`, its `l1_loss` / `ssim`, its
+`GaussianMeshModel` with the installed HIP mixins, its optimizer, its `scene.save()` -- through BASELINE config 3's loop, and the
+restatement the GPU box runs (games_hip/train.py, which has no reference tree to import) walks the SAME parameter trajectory.
+
+Without a GPU the innermost kernel calls are served by the CPU oracle (as in tests/test_reference_render_cpu.py).  With
+GMS_REFERENCE_DEVICE=cuda on a machine that has both the reference and an MI355X, nothing is replaced: `train.training()` drives the
+HIP kernels (the `Scene` is still the synthetic stand-in below: the reference ships no dataset)."""
+import argparse
+import os
+import random
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from games_hip import synthetic as syn
+from oracle import ref_import
+
+DEVICE = os.environ.get("GMS_REFERENCE_DEVICE", "cpu")
+
+
+class _Cam:
+    """What train.py and renderer/gaussian_renderer/__init__.py read from scene/cameras.py:Camera."""
+
+    def __init__(self, k, size, device):
+        c = syn.orbit_camera(k, width=size, height=size).to(device)
+        self.FoVx, self.FoVy, self.image_width, self.image_height = c.FoVx, c.FoVy, c.image_width, c.image_height
+        self.world_view_transform, self.full_proj_transform, self.camera_center = c.world_view_transform, c.full_proj_transform, c.camera_center
+        self.projection_matrix = c.projection_matrix
+        self.tanfovx, self.tanfovy = c.tanfovx, c.tanfovy          # (games_hip.render reads these; the reference computes them)
+        self.image_name = f"view_{k}"
+        self.original_image = None
+
+
+def _targets(cams, device):
+    """Ground-truth images: the "trained" state of the same mesh, rendered by the oracle (CPU) -- a teacher."""
+    from oracle import gs_oracle, mesh_oracle
+    sc = syn.mesh_scene("tiny", state="trained")
+    with torch.no_grad():
+        _, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(sc.vertices, sc.faces, sc._alpha, sc._scale)
+        xa, sa, ra, oa, shs = mesh_oracle.activated(xyz, scaling, rot, sc._opacity, sc._features_dc, sc._features_rest)
+    for c in cams:
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=c.image_height,
+                                image_width=c.image_width, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=torch.ones(3),
+                                viewmatrix=c.world_view_transform.cpu(), projmatrix=c.full_proj_transform.cpu(), sh_degree=3,
+                                campos=c.camera_center.cpu())
+        c.original_image = torch.from_numpy(o.color.copy()).to(device)
+
+
+def _point_cloud(MeshPointCloud):
+    sc = syn.mesh_scene("tiny", state="init")
+    tri = sc.vertices[sc.faces]
+    P = sc.num_gaussians
+    return MeshPointCloud(alpha=sc._alpha, points=torch.matmul(sc._alpha, tri).reshape(-1, 3), colors=np.full((P, 3), 0.5),
+                          normals=np.zeros((P, 3)), vertices=sc.vertices, faces=sc.faces.numpy(), transform_vertices_function=None,
+                          triangles=tri), sc
+
+
+class _Event:                       # torch.cuda.Event stand-in for the CPU run (train.py:55-56,81,110,121)
+    def __init__(self, enable_timing=False):
+        pass
+
+    def record(self):
+        pass
+
+    def elapsed_time(self, other):
+        return 0.0
+
+
+def _patch_kernels(monkeypatch):
+    """CPU only: the two kernel entry points are served by the oracle / the restatement."""
+    import diff_gaussian_rasterization as dgr
+    from games_hip import model as hip_model
+    import test_abi
+    import test_reference_render_cpu as R
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", R._oracle_rasterize)
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", test_abi._cpu_op)
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
+
+
+ITERS = 14
+
+
+def test_reference_training_loop_runs_unmodified_and_the_restatement_follows_it(monkeypatch, tmp_path):
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import games
+    from games.mesh_splatting.utils.graphics_utils import MeshPointCloud
+    from games_hip import model as hip_model
+    from games_hip import train as hip_train
+    from games_hip.render import PipelineParams, render as hip_render
+    from oracle import loss_oracle
+    train = importlib.import_module("train")                       # the reference's train.py
+    on_cpu = DEVICE == "cpu"
+    if on_cpu:
+        _patch_kernels(monkeypatch)
+    real_load = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: real_load(*a, **{"weights_only": False, **k}))
+    cams = [_Cam(k, 48, DEVICE) for k in range(4)]
+    _targets(cams, DEVICE)
+    made = {}
+
+    class SyntheticScene:                                          # stands in for scene/__init__.py:Scene (no dataset ships)
+        def __init__(self, args, gaussians, *a, **k):
+            self.model_path, self.gaussians, self.cameras_extent = args.model_path, gaussians, 1.0
+            pcd, _ = _point_cloud(MeshPointCloud)
+            gaussians.create_from_pcd(pcd, self.cameras_extent)     # scene/__init__.py:103
+            made["gaussians"] = gaussians
+
+        def getTrainCameras(self, scale=1.0):
+            return cams
+
+        def getTestCameras(self, scale=1.0):
+            return cams[:1]
+
+        def save(self, iteration):                                  # scene/__init__.py:105-107
+            self.gaussians.save_ply(os.path.join(self.model_path, f"point_cloud/iteration_{iteration}", "point_cloud.ply"))
+
+    monkeypatch.setattr(train, "Scene", SyntheticScene)
+    monkeypatch.setattr(train, "TENSORBOARD_FOUND", False)
+    monkeypatch.setattr(train, "args", argparse.Namespace(gs_type="gs_mesh"), raising=False)     # train.py:129 reads the global
+    dataset = argparse.Namespace(sh_degree=3, model_path=str(tmp_path / "out"), white_background=True, source_path="", images="images",
+                                 eval=False, gs_type="gs_mesh", num_splats=[2], meshes=[])
+    opt = argparse.Namespace(**vars(hip_train.OptimizationParamsMesh(iterations=ITERS, vertices_lr=0.00016)))
+    pipe = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, antialiasing=False)
+    out = hip_model.install(games)
+    try:
+        random.seed(0); np.random.seed(0); torch.manual_seed(0)      # safe_state (utils/general_utils.py:203-213)
+        ctx = ref_import.cuda_literals_on_cpu() if on_cpu else _null()
+        with ctx:
+            train.training("gs_mesh", dataset, opt, pipe, [ITERS], [ITERS], [], None, -1, False)
+        ref_model = made["gaussians"]
+        assert isinstance(ref_model, hip_model.HipMeshMixin)        # the reference class, K0 methods overridden by install()
+        assert os.path.exists(os.path.join(dataset.model_path, f"point_cloud/iteration_{ITERS}", "point_cloud.ply"))
+        assert os.path.exists(os.path.join(dataset.model_path, f"point_cloud/iteration_{ITERS}", "model_params.pt"))
+        assert os.path.exists(os.path.join(dataset.model_path, "cfg_args"))
+        ref_params = {n: getattr(ref_model, n).detach().clone() for n in ("vertices", "_alpha", "_features_dc", "_features_rest", "_opacity", "_scale")}
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
+
+    # ---- the restatement (what tools/train_c3.py runs on the GPU box), same start, same seeds
+    _, sc = _point_cloud(MeshPointCloud)
+    from games_hip.synthetic import RGB2SH, inverse_sigmoid
+    P = sc.num_gaussians
+    sc._scale = torch.ones(P, 1); sc._opacity = torch.full((P, 1), inverse_sigmoid(0.1))
+    sc._features_dc = RGB2SH(torch.full((P, 1, 3), 0.5)); sc._features_rest = torch.zeros(P, 15, 3)
+    m = hip_model.HipGaussianMeshModel.from_scene(sc, DEVICE)
+    m.active_sh_degree = 0
+    m.training_setup(vertices_lr=opt.vertices_lr, alpha_lr=opt.alpha_lr, feature_lr=opt.feature_lr, opacity_lr=opt.opacity_lr,
+                     scaling_lr=opt.scaling_lr, fused=not on_cpu)
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    losses = hip_train.training(m, cams, hip_train.OptimizationParamsMesh(**vars(opt)), PipelineParams(), torch.ones(3, device=DEVICE),
+                                render=hip_render, loss_fn=loss_oracle.l1_ssim_loss if on_cpu else None, report_iterations=[1, ITERS])
+    assert losses[-1] < losses[0]                                    # it trains
+    for n, want in ref_params.items():
+        got = getattr(m, n).detach()
+        scale = float(want.abs().max()) + 1e-12
+        assert float((got - want).abs().max()) <= (2e-5 if on_cpu else 2e-3) * scale, n
+    # ... and it moved: the comparison is not between two untouched initialisations
+    assert float((m._features_dc.detach() - RGB2SH(torch.full((P, 1, 3), 0.5))).abs().max()) > 1e-3
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
