@@ -35,16 +35,16 @@ def algorithmic_bytes(P, N, F, W, H):
         "tile_scan": 8 * ((W + 15) // 16) * ((H + 15) // 16),
         "emit_instances": 12 * N,                  # binning lower bound 28*N = emit 12 + sort 16
         "tile_sort": 16 * N,
-        "blend_fwd": 0,         # (segments 1.. of the walk: part of blend_head's algorithmic bytes, see below)
+        "blend_fwd": None,      # (segments 1.. of the forward walk: priced with the `forward_compositing` stage, see STAGES)
         "blend_bwd": 84 * N + 24 * HW,             # 44 + one reduced 40-B gradient record per instance
         "preprocess_bwd": 569 * P,                 # read 321 + write 248 per Gaussian
         "mesh_fwd": 36 * F + 56 * P,               # tri 36/face; alpha 12 + scale 4 in, 40 out per splat
         "mesh_bwd_splat": 56 * P,
         "mesh_bwd_face": 40 * P + 36 * F,
-        # forward compositing = blend_head (first segments + products) + blend_fwd (later segments) + blend_finalize: the
-        # algorithmic bytes of the whole forward walk are booked on the first launch, the other two are implementation passes
-        "blend_head": 44 * N + 24 * HW,            # id 4 + gathered record 40 per instance; 24 B per pixel
-        "blend_finalize": 0,
+        # forward compositing = blend_head (first segments + products) + blend_fwd (later segments) + blend_finalize: three
+        # launches of ONE stage; its algorithmic bytes (44 N + 24 HW) are priced against the SUM of the three durations
+        "blend_head": None,
+        "blend_finalize": None,
         "micro_filter": 52 * N,                    # micro-tile mode: key 8 + gathered record 40 per instance in, ~one id out
         "l1_ssim_fwd": 20 * 3 * HW,   # --loss l1_ssim only: read image + gt, write three derivative maps
         "l1_ssim_bwd": 24 * 3 * HW,   # read image + gt + three maps, write dL/dimage
@@ -132,8 +132,34 @@ def cpu_baseline(workload, state, max_seconds=12.0):
 
     stages = {"cov3D_python_fwd_bwd_s": round(med(cov_path), 4), "sh_python_fwd_bwd_s": round(med(sh_path), 4),
               "geom_transform_points_s": round(med(project_path), 4), "threads": k0_threads}
+    # the dense pure-PyTorch rasterizer at config 1 (gs_flat, 10 000 Gaussians) as the "pure-PyTorch CPU
+    # raster" reference point.  The dense [pixels x Gaussians] formulation keeps ~0.9 KB per pair for autograd (58 GB at 256x256):
+    # a bounded sample -- 64x64 of the 256x256 pixels -- is timed and the factor to the full image stated.
+    dense = None
+    try:
+        from oracle import dense_torch
+        fs = syn.flat_scene(10000)
+        c1 = syn.orbit_camera(0, width=64, height=64)
+        kw1 = dict(image_height=64, image_width=64, tanfovx=c1.tanfovx, tanfovy=c1.tanfovy, bg=torch.ones(3), viewmatrix=c1.world_view_transform,
+                   projmatrix=c1.full_proj_transform, sh_degree=3, campos=c1.camera_center)
+        leaves = [t.clone().requires_grad_(True) for t in (fs.means3D, fs.opacities, fs.shs, fs.scales, fs.rotations)]
+        t0 = time.time()
+        color, _, _ = dense_torch.rasterize_dense(leaves[0], None, leaves[1], shs=leaves[2], scales=leaves[3], rotations=leaves[4], **kw1)
+        t1 = time.time()
+        ((color - 0.5) ** 2).sum().backward()
+        t2 = time.time()
+        dense = {"fwd_s": round(t1 - t0, 3), "bwd_s": round(t2 - t1, 3), "threads": k0_threads,
+                 "sample": "config 1 Gaussians (gs_flat, 10 000), 64x64 of its 256x256 pixels, float32, autograd backward; "
+                           "full image = 16x the pixels (memory O(P x HW): ~58 GB)", "full_image_factor": 16}
+        del color, leaves
+    except Exception as e:  # noqa: BLE001
+        dense = {"error": repr(e)[:200]}
     t = sorted(times)[len(times) // 2]
-    return {"pytorch_cov_project_path": stages, "value": 1.0 / t, "unit": "iters/s", "cores": oracle_threads, "kind": "port",
+    return {"pytorch_cov_project_path": stages, "dense_torch_raster_c1": dense,
+            "k0_leg": "torch-CPU RESTATEMENT of GaussianMeshModel.update_alpha + prepare_scaling_rot (oracle/mesh_oracle.py, bit-exact against "
+                      "the reference's own classes on tests/golden/k0_*.npz); the reference tree itself is not present on this box, so "
+                      "BASELINE.md section 3 #1 (the imported reference classes) cannot be timed here",
+            "value": 1.0 / t, "unit": "iters/s", "cores": oracle_threads, "kind": "port",
             "sample": f"{len(times)} full fwd+bwd iteration(s) of the same workload ({workload}/{state}, "
                       f"{sc.num_gaussians} Gaussians, {cam.image_width}x{cam.image_height}); C oracle with OpenMP "
                       f"({oracle_threads} threads, fastest of 16/32/64/128) + torch-CPU K0 ({k0_threads} threads), median", "host_cpu_count": os.cpu_count(), "k0_torch_threads": k0_threads, **{k: round(v, 4) for k, v in pieces.items()}}
@@ -149,6 +175,43 @@ def kernel_source_hash():
     finally:
         sys.path.pop(0)
     return srchash.kernel_source_hash()
+
+
+# Stages that take several kernels: priced as ONE unit (sum of the launches' durations against the stage's algorithmic bytes,
+# SURVEY.md 8(d)).  Round 3 booked the forward walk's bytes on its first launch and showed `frac 0.0` for the other two.
+STAGES = {
+    "forward_compositing": (("blend_head", "blend_fwd", "blend_finalize"), lambda P, N, F, HW: 44 * N + 24 * HW),
+    "binning": (("tile_scan", "emit_instances", "tile_sort"), lambda P, N, F, HW: 28 * N),
+    "k0_plus_preprocess_fwd": (("mesh_fwd", "preprocess_fwd"), lambda P, N, F, HW: 36 * F + 56 * P + 308 * P),
+}
+
+def rccl_summary(path):
+    """What this rank's RCCL INIT / GRAPH log says about the communicator (never fails the bench: best effort)."""
+    env = {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "RCCL_MSCCL_ENABLE", "NCCL_P2P_LEVEL",
+                                      "HSA_ENABLE_IPC_MODE_LEGACY") if k in os.environ}
+    out = {"env": env, "algorithm_protocol": "RCCL's tuner per collective and size (NCCL_ALGO / NCCL_PROTO unset)" if "NCCL_ALGO" not in env and "NCCL_PROTO" not in env
+           else f"forced: NCCL_ALGO={env.get('NCCL_ALGO')} NCCL_PROTO={env.get('NCCL_PROTO')}", "log": path}
+    try:
+        if not path or not os.path.exists(path):
+            out["note"] = "no RCCL debug file (NCCL_DEBUG_FILE set elsewhere, or a non-RCCL backend)"
+            return out
+        import re
+        with open(path, errors="replace") as f:
+            lines = f.read().splitlines()
+        txt = "\n".join(lines)
+        m = re.search(r"(RCCL|NCCL) version[^\n]*", txt)
+        out["version"] = m.group(0)[:120] if m else None
+        m = re.search(r"nranks (\d+)", txt)
+        out["nranks"] = int(m.group(1)) if m else None
+        ch = re.findall(r"Channel (\d+)/(\d+)", txt)
+        out["channels"] = int(ch[0][1]) if ch else None
+        out["transports"] = sorted(set(re.findall(r"via (P2P/\w+|SHM\w*|NET/\w+|direct\w*)", txt)))[:8]
+        out["xgmi_mentions"] = len(re.findall(r"XGMI|xgmi", txt))
+        out["rings_trees"] = [ln.split("NCCL INFO", 1)[-1].strip()[:160] for ln in lines if ("Connected all" in ln or "Trees" in ln or "Ring 0" in ln)][:6]
+        out["lines"] = len(lines)
+    except Exception as e:  # noqa: BLE001
+        out["error"] = repr(e)[:200]
+    return out
 
 
 BASELINE_METRIC = "train iters/s (fwd+bwd raster) @800×800, 300k Gaussians; HBM GB/s vs roofline"
@@ -251,6 +314,16 @@ def main():
     # the nccl code path -- communicator creation, async collectives from autograd hooks, stream waits -- without peers)
     force_ddp = world == 1 and os.environ.get("GMS_BENCH_FORCE_DDP") == "1"
     backend = None
+    rccl_log = None
+    if (world > 1 and not shared_gpu) or force_ddp:
+        # self-diagnosing multi-GPU run: RCCL's own INIT / GRAPH log of this rank goes to a file that rank 0 summarises into the JSON
+        # line (version, ranks, channels, transports, the algorithm / protocol environment) -- the first 8-GPU run explains itself
+        rccl_log = f"/tmp/gms_bench_rccl_{os.getpid()}.log"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        if os.environ["NCCL_DEBUG_FILE"] != rccl_log:
+            rccl_log = None
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
@@ -392,20 +465,32 @@ def main():
                     p.grad = None
         return step, reducer
 
-    def timed(step, steps, warmup):
-        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+    rank_spread = {}
+
+    def timed(step, steps, warmup, tag=None):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks.  `tag`: also record
+        every rank's own elapsed time and its time to reach the closing barrier (per-rank spread: a straggler shows here)."""
         for _ in range(warmup):
             step()
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        torch.cuda.synchronize(device)
+        own = time.perf_counter() - t0          # this rank's K steps, before waiting for the others
         sync()
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+            if tag is not None:
+                mine = torch.tensor([own], device=device, dtype=torch.float64)
+                every = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine)
+                ms = [1000.0 * float(x.item()) / steps for x in every]
+                rank_spread[tag] = {"ms_per_step_by_rank": [round(v, 4) for v in ms], "min": round(min(ms), 4), "max": round(max(ms), 4),
+                                    "spread_frac": round((max(ms) - min(ms)) / max(ms), 4) if max(ms) > 0 else 0.0}
         return el
 
     if args.mode == "animate":
@@ -457,7 +542,7 @@ def main():
             for _ in range(10):
                 step()
             torch.cuda.synchronize(device)
-    elapsed = timed(step, args.steps, args.warmup)
+    elapsed = timed(step, args.steps, args.warmup, tag="headline")
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * vps * args.steps / elapsed
     keep_buffers(True)          # one untimed step whose scratch stays referenced: visible count / interactions for the JSON
@@ -471,6 +556,7 @@ def main():
         ones = torch.ones(1, device=device)
         dist.all_reduce(ones)
         extra["ranks_seen"] = int(ones.item())
+        extra["per_rank_step_time"] = rank_spread.get("headline")
         extra["backend"] = backend + ("/shared-gpu (test path: every rank on cuda:0)" if shared_gpu else "/RCCL over xGMI" if backend == "nccl" else "")
         if reducer is not None:
             reducer.remove()
@@ -504,6 +590,9 @@ def main():
         dense_numel = sum(p.numel() for p in params if not (sh_factor and (p is model._features_dc or p is model._features_rest)))
         # per rank per step: all-reduced gradient + gathered factors (packed: everything gathered, W x the small gradients)
         extra["exchange_bytes"] = (4 * dense_numel * world + gather_bytes) if sh_mode_default == "packed" else (4 * dense_numel + gather_bytes)
+        extra["exchange_candidates"] = {"sh_exchange_ms_per_step": sh_exchange_ms or None, "allreduce_algorithms_ms": allreduce_times,
+                                        "chosen": {"sh_exchange": sh_mode_default, "allreduce": algo}}
+        extra["rccl"] = rccl_summary(rccl_log)
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)
@@ -545,14 +634,31 @@ def main():
             lps = n / max(args.profile_steps * vps, 1)       # launches per rendered view
             # a stage that takes several launches per view (tile_sort: presort + merge; blend_head on deep scenes) is priced on
             # the SUM of its launches: its algorithmic bytes are per view, not per launch
-            gbs = ab[name] / (avg_us * max(lps, 1.0) * 1e-6) / 1e9
-            kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
-                             "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
-                             "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": pmc.get(name)}
+            if ab[name] is None:          # one launch of a multi-kernel stage: priced under `stages`, not here
+                kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
+                                 "algorithmic_bytes": None, "achieved_GBps": None, "frac_of_8TBps": None, "traffic": pmc.get(name),
+                                 "priced_with": next(k for k, v in STAGES.items() if name in v[0])}
+            else:
+                gbs = ab[name] / (avg_us * max(lps, 1.0) * 1e-6) / 1e9
+                kernels[name] = {"avg_us": round(avg_us, 2), "launches_per_step": n / max(args.profile_steps, 1),
+                                 "algorithmic_bytes": ab[name], "achieved_GBps": round(gbs, 1),
+                                 "frac_of_8TBps": round(gbs / 8000.0, 4), "traffic": pmc.get(name)}
             if name in sq and sq[name].get("SQ_INSTS_VALU"):
                 lane_ops = sq[name]["SQ_INSTS_VALU"] * 64.0
                 kernels[name]["valu_wave_insts"] = sq[name]["SQ_INSTS_VALU"]
                 kernels[name]["valu_issue_frac"] = round(lane_ops / (avg_us * 1e-6) / 1e12 / VALU_PEAK_TLANEOPS, 4)
+        stages = {}
+        for sname, (members, fn) in STAGES.items():
+            have_k = [m for m in members if m in kernels]
+            if not have_k:
+                continue
+            us = sum(kernels[m]["avg_us"] * kernels[m]["launches_per_step"] for m in have_k) / max(vps, 1)
+            sb = fn(P, N, F, size * size)
+            tr = [kernels[m]["traffic"] for m in have_k]
+            stages[sname] = {"kernels": have_k, "sum_us_per_view": round(us, 2), "algorithmic_bytes": sb,
+                             "achieved_GBps": round(sb / (us * 1e-6) / 1e9, 1) if us > 0 else None,
+                             "frac_of_8TBps": round(sb / (us * 1e-6) / 8e12, 4) if us > 0 else None,
+                             "traffic": sum(tr) if all(t is not None for t in tr) else None}
         if not kernels:     # --profile-steps 0: no per-kernel timing requested
             kernels = {"(not profiled)": {"avg_us": 0.0, "launches_per_step": 0, "algorithmic_bytes": 0, "achieved_GBps": 0.0,
                                           "frac_of_8TBps": 0.0, "traffic": None}}
@@ -565,6 +671,11 @@ def main():
         # the launch stream, measured in this run) against 8 TB/s; `traffic` = HBM bytes from the PMC passes (null when the
         # committed counters belong to another build).  The compositing kernels have no dense contraction and gather 48-byte
         # records out of L2 -- what actually bounds them is VALU issue, reported next to it under `valu`.
+        if kd.get("priced_with"):      # the dominant launch belongs to a multi-kernel stage: the stage is the roofline unit
+            st = stages[kd["priced_with"]]
+            kd = dict(kd, achieved_GBps=st["achieved_GBps"], frac_of_8TBps=st["frac_of_8TBps"], algorithmic_bytes=st["algorithmic_bytes"],
+                      traffic=st["traffic"], avg_us=st["sum_us_per_view"])
+            dom = kd["priced_with"]
         roofline = {"kernel": dom, "avg_launch_us": kd["avg_us"], "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kd["frac_of_8TBps"], "algorithmic_bytes": kd["algorithmic_bytes"],
                     "traffic": kd["traffic"], "pmc": pmc_note}
@@ -598,6 +709,7 @@ def main():
                                + (f" + optimizer.step() [{args.optimizer}]" if args.optimizer != "none" else "")},
             "roofline": roofline,
             "kernels": kernels,
+            "stages": stages,
             "whole_iteration": {"algorithmic_bytes": whole_bytes, "sum_kernel_us": round(sum_kernel_us, 1),
                                 "achieved_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                 "frac_of_8TBps": round(whole_bytes / (ms_per_step * 1e-3) / 8e12, 4)},

@@ -28,6 +28,13 @@ def test_single_gpu_line_has_the_contract_fields():
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["value"] > 0
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and "workload" in d["config"]
     assert abs(d["value"] - 1000.0 / d["ms_per_step"]) / d["value"] < 0.02
+    # multi-kernel stages are priced as ONE unit (round 3 showed `frac 0.0` for two of the three forward-compositing launches)
+    fc = d["stages"]["forward_compositing"]
+    assert fc["frac_of_8TBps"] > 0 and fc["algorithmic_bytes"] > 0 and set(fc["kernels"]) <= {"blend_head", "blend_fwd", "blend_finalize"}
+    assert d["stages"]["binning"]["frac_of_8TBps"] > 0 and d["stages"]["k0_plus_preprocess_fwd"]["frac_of_8TBps"] > 0
+    for name, k in d["kernels"].items():
+        assert k["frac_of_8TBps"] is None or k["frac_of_8TBps"] > 0, name
+        assert (k["frac_of_8TBps"] is None) == ("priced_with" in k), name
 
 
 def test_gpus_flag_starts_the_ranks_itself():
@@ -60,6 +67,12 @@ def test_two_ranks_under_the_drivers_launcher():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["views_per_rank_per_step"] == 1
     assert d["config"]["views_per_step"] == 2 and d["value"] > 0 and d["ranks_seen"] == 2
+    # the self-diagnosing fields of a multi-rank line: per-rank step time, every exchange candidate with its time, the chosen one
+    pr = d["per_rank_step_time"]
+    assert len(pr["ms_per_step_by_rank"]) == 2 and 0 < pr["min"] <= pr["max"]
+    ec = d["exchange_candidates"]
+    assert set(ec["sh_exchange_ms_per_step"]) == {"dense", "factor", "packed"} and ec["chosen"]["sh_exchange"] in ec["sh_exchange_ms_per_step"]
+    assert "algorithm_protocol" in d["rccl"]
 
 
 def test_one_rank_rccl_process_group_runs_the_allreduce_step():
@@ -73,3 +86,5 @@ def test_one_rank_rccl_process_group_runs_the_allreduce_step():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 1 and d["config"]["views_per_rank_per_step"] == 2 and d["value"] > 0
+    # RCCL's own INIT log of the rank is summarised into the line (version, ranks, channels)
+    assert d["rccl"].get("nranks") == 1 and d["rccl"].get("version"), d["rccl"]
