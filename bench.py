@@ -32,7 +32,7 @@ def algorithmic_bytes(P, N, F, W, H):
     HW = W * H
     return {
         "preprocess_fwd": 308 * P,                 # read 236 + write 72 per Gaussian
-        "tile_scan": 8 * ((W + 15) // 16) * ((H + 15) // 16),
+        "tile_scan": None,      # one block, 8 T bytes: a latency kernel; priced with the `binning` stage
         "emit_instances": 12 * N,                  # binning lower bound 28*N = emit 12 + sort 16
         "tile_sort": 16 * N,
         "blend_fwd": None,      # (segments 1.. of the forward walk: priced with the `forward_compositing` stage, see STAGES)
@@ -592,7 +592,6 @@ def main():
         extra["exchange_bytes"] = (4 * dense_numel * world + gather_bytes) if sh_mode_default == "packed" else (4 * dense_numel + gather_bytes)
         extra["exchange_candidates"] = {"sh_exchange_ms_per_step": sh_exchange_ms or None, "allreduce_algorithms_ms": allreduce_times,
                                         "chosen": {"sh_exchange": sh_mode_default, "allreduce": algo}}
-        extra["rccl"] = rccl_summary(rccl_log)
         step, reducer = make_step(vps, True)           # for the profiling pass below
 
     # ---- per-kernel durations: HIP events on the launch stream (separate untimed pass)
@@ -721,10 +720,12 @@ def main():
                 out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
-        final_line = json.dumps(out)
     if distributed:
         dist.destroy_process_group()
     if rank == 0:
+        if distributed:
+            out["rccl"] = rccl_summary(rccl_log)      # (after the communicator is gone: its debug file is complete)
+        final_line = json.dumps(out)
         # RCCL prints its version banner through C stdio (flushed at exit): flush it first so that the JSON is the last line
         try:
             import ctypes

@@ -475,11 +475,15 @@ __global__ void __launch_bounds__(BLOCK) det_corner_fill_kernel(int64_t n_corner
     adj[off[v] + atomicAdd(&cur[v], 1u)] = (uint32_t)c;
 }
 
+constexpr int DET_SMALL_DEGREE = 32;       // up to here one thread sorts-by-selection (O(d^2) loads); above, a wave ranks the list
+constexpr int DET_WAVE_CAP = 2048;         // corners a wave can rank through its LDS slice; beyond: serial selection by one lane
+
 __global__ void __launch_bounds__(BLOCK) det_vertex_gather_kernel(int V, const uint32_t *off, const uint32_t *adj, const float *corner_grad, float *dL_dvertices)
 {
     const int v = blockIdx.x * BLOCK + threadIdx.x;
     if (v >= V) return;
     const uint32_t b = off[v], e = off[v + 1];
+    if (e - b > (uint32_t)DET_SMALL_DEGREE) return;          // det_vertex_gather_wave_kernel's
     float gx = 0.f, gy = 0.f, gz = 0.f;
     int64_t last = -1;
     for (uint32_t n = b; n < e; n++) {
@@ -489,6 +493,44 @@ __global__ void __launch_bounds__(BLOCK) det_vertex_gather_kernel(int V, const u
         last = next;
     }
     dL_dvertices[3 * (size_t)v] = gx; dL_dvertices[3 * (size_t)v + 1] = gy; dL_dvertices[3 * (size_t)v + 2] = gz;
+}
+
+// High-degree vertices (the two poles of a UV sphere touch n_lon faces: 224 at the headline size -- one thread's O(d^2) selection
+// took 4 ms there): one wave per vertex.  Every lane ranks its entries (rank = number of smaller corner indices: the indices of
+// a vertex are distinct), the wave writes the list in rank order into its LDS slice, lane 0 adds the gradients in that order.
+__global__ void __launch_bounds__(BLOCK) det_vertex_gather_wave_kernel(int V, const uint32_t *off, const uint32_t *adj, const float *corner_grad, float *dL_dvertices)
+{
+    __shared__ uint32_t sorted_all[4][DET_WAVE_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = blockIdx.x * (BLOCK / WAVE) + wave;
+    if (v >= V) return;                                       // wave-uniform
+    const uint32_t b = off[v], e = off[v + 1], d = e - b;
+    if (d <= (uint32_t)DET_SMALL_DEGREE) return;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (d <= (uint32_t)DET_WAVE_CAP) {
+        uint32_t *sorted = sorted_all[wave];
+        for (uint32_t i = lane; i < d; i += WAVE) {
+            const uint32_t c = adj[b + i];
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < d; k++) rank += adj[b + k] < c ? 1u : 0u;
+            sorted[rank] = c;
+        }
+        wave_sync();
+        if (lane == 0)
+            for (uint32_t n = 0; n < d; n++) {
+                const size_t c = sorted[n];
+                gx += corner_grad[3 * c]; gy += corner_grad[3 * c + 1]; gz += corner_grad[3 * c + 2];
+            }
+    } else if (lane == 0) {
+        int64_t last = -1;
+        for (uint32_t n = b; n < e; n++) {
+            int64_t next = INT64_MAX;
+            for (uint32_t k = b; k < e; k++) { const int64_t c = adj[k]; if (c > last && c < next) next = c; }
+            gx += corner_grad[3 * next]; gy += corner_grad[3 * next + 1]; gz += corner_grad[3 * next + 2];
+            last = next;
+        }
+    }
+    if (lane == 0) { dL_dvertices[3 * (size_t)v] = gx; dL_dvertices[3 * (size_t)v + 1] = gy; dL_dvertices[3 * (size_t)v + 2] = gz; }
 }
 
 }  // namespace gms
@@ -573,6 +615,7 @@ extern "C" int32_t gms_mesh_to_gaussians_backward(const GmsMeshArgs *A, const fl
             GMS_HIP_CHECK(hipMemsetAsync(off, 0, ((size_t)A->V + 1) * sizeof(uint32_t), stream));
         }
         det_vertex_gather_kernel<<<(unsigned)((A->V + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(A->V, off, adj, corner_grad, dL_dvertices);
+        det_vertex_gather_wave_kernel<<<(unsigned)((A->V + 3) / 4), BLOCK, 0, stream>>>(A->V, off, adj, corner_grad, dL_dvertices);
         GMS_KERNEL_CHECK(0, stream, "mesh_bwd (deterministic)");
         return GMS_OK;
     }
