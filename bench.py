@@ -319,10 +319,12 @@ def main():
         # self-diagnosing multi-GPU run: RCCL's own INIT / GRAPH log of this rank goes to a file that rank 0 summarises into the JSON
         # line (version, ranks, channels, transports, the algorithm / protocol environment) -- the first 8-GPU run explains itself
         rccl_log = f"/tmp/gms_bench_rccl_{os.getpid()}.log"
-        os.environ.setdefault("NCCL_DEBUG", "INFO")
-        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
-        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
-        if os.environ["NCCL_DEBUG_FILE"] != rccl_log:
+        if os.environ.get("GMS_BENCH_RCCL_LOG", "1") != "0":
+            if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+                os.environ["NCCL_DEBUG"] = "INFO"          # (a preset WARN / VERSION level would leave the file empty)
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,ENV")
+            os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        if os.environ.get("NCCL_DEBUG_FILE") != rccl_log:
             rccl_log = None
     if force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -59,6 +59,8 @@ struct PreArgs {
     uint8_t *visible;        // optional: radii > 0 as bytes
     GeomState geom;
     uint32_t *tile_count;
+    uint32_t *zero_cursor;   // [T] emit cursors, cleared here when the frame takes the inline-scan emit (else NULL: tile_scan clears them)
+    int T;
 };
 
 // SH -> RGB (before +0.5/clamp) for one channel from the coefficient row r[k*3+c] held in registers;
@@ -131,6 +133,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < a.P;
+    if (MODE != 2 && a.zero_cursor)
+        for (int q = i; q < a.T; q += (int)gridDim.x * BLOCK) a.zero_cursor[q] = 0u;
 
     // Fast path: every global load of this thread is issued before anything is computed, so the
     // position / scale / rotation / opacity / SH round trips overlap instead of chaining.
@@ -545,61 +549,209 @@ struct FillUnitsArgs {
     uint32_t max_units, max_deep, max_multi;
 };
 
-__device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
+// what fill_units needs to know about one tile: its count, its exclusive prefixes `pre` of the NSCAN scanned quantities and
+// the totals `tot` (tile_scan_kernel's arrays, or the inline scan of the emit launch)
+__device__ __forceinline__ void fill_units_tile(const FillUnitsArgs &f, int t, uint32_t c, uint32_t L, const uint32_t pre[NSCAN], const uint32_t tot[NSCAN])
 {
-    const uint32_t *class_first = f.class_first, *offset = f.offset, *mseg_first = f.mseg_first;
-    uint4 *unit_tile = f.unit_tile;
-    uint2 *deep_tab = f.deep_tab;
-    const int T = f.T, sort_np = f.sort_np;
-    const uint32_t L = f.scan_out[3], max_units = f.max_units, max_deep = f.max_deep;
-    const int t = block * BLOCK + threadIdx.x;
-    if (t >= T) return;
-    const uint32_t c = offset[t + 1] - offset[t], nfull = c / L;      // (the counters were cleared by the scan)
+    const uint32_t nfull = c / L;
     uint32_t q[NSCAN];
-    tile_terms(c, L, q, sort_np);
+    tile_terms(c, L, q, f.sort_np);
     const uint32_t nseg = q[1];                          // units of this tile (>= 1)
-    const uint4 tail = make_uint4(offset[t], offset[t] + c, 0u, 0u);
-    const uint32_t slot0 = mseg_first[t];
+    const uint4 tail = make_uint4(pre[0], pre[0] + c, 0u, 0u);
+    const uint32_t slot0 = pre[2];
     auto put = [&](uint32_t u, uint32_t seg) {
-        if (u < max_units) {
-            unit_tile[2 * (size_t)u] = make_uint4((uint32_t)t, seg, nseg, slot0);
-            unit_tile[2 * (size_t)u + 1] = tail;
+        if (u < f.max_units) {
+            f.unit_tile[2 * (size_t)u] = make_uint4((uint32_t)t, seg, nseg, slot0);
+            f.unit_tile[2 * (size_t)u + 1] = tail;
         }
     };
-    for (uint32_t j = 0, d = class_first[NCLASS * (T + 1) + t]; j < q[9]; j++, d++)
-        if (d < max_deep) deep_tab[d] = make_uint2((uint32_t)t, j);
-    if (q[10]) { const uint32_t d = class_first[(NCLASS + 1) * (T + 1) + t]; if (d < f.max_multi) f.multi_tab[d] = (uint32_t)t; }
-    uint32_t u = class_first[t];
+    for (uint32_t j = 0, d = pre[9]; j < q[9]; j++, d++)
+        if (d < f.max_deep) f.deep_tab[d] = make_uint2((uint32_t)t, j);
+    if (q[10]) { const uint32_t d = pre[10]; if (d < f.max_multi) f.multi_tab[d] = (uint32_t)t; }
+    uint32_t u = pre[3];
     for (uint32_t s = 0; s < nfull; s++, u++) put(u, s);
-    uint32_t base = class_first[T];                     // all full units come first
+    uint32_t base = tot[3];                             // all full units come first
     for (int k = 1; k < NCLASS; k++) {
-        if (q[3 + k]) put(base + class_first[k * (T + 1) + t], k == NCLASS - 1 ? 0u : nfull);
-        base += class_first[k * (T + 1) + T];
+        if (q[3 + k]) put(base + pre[3 + k], k == NCLASS - 1 ? 0u : nfull);
+        base += tot[3 + k];
     }
+}
+
+__device__ __forceinline__ void fill_units(const FillUnitsArgs &f, int block)
+{
+    const int T = f.T;
+    const int t = block * BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t c = f.offset[t + 1] - f.offset[t];      // (the counters were cleared by the scan)
+    uint32_t pre[NSCAN], tot[NSCAN];
+    pre[0] = f.offset[t]; pre[1] = 0u; pre[2] = f.mseg_first[t]; tot[0] = tot[1] = tot[2] = 0u;
+#pragma unroll
+    for (int k = 0; k < NCLASS + 2; k++) { pre[3 + k] = f.class_first[k * (T + 1) + t]; tot[3 + k] = f.class_first[k * (T + 1) + T]; }
+    fill_units_tile(f, t, c, f.scan_out[3], pre, tot);
+}
+
+// ---- the tile scan INSIDE the emit launch (round 4).  tile_scan_kernel is one block whose 13 us sit between preprocess and emit
+// with the rest of the chip idle.  On the capacity-hint path (every frame but the first of a shape) its work is done redundantly
+// instead: every emit block scans the T <= 4096 counters itself (10-16 KB out of L2, ~1.5 us) and keeps the tile offsets in LDS;
+// the launch's spare blocks -- one per 256 tiles, as before -- run the full NSCAN-quantity scan, write the tables later launches
+// read (tile_offset, unit_first, mseg_first, the totals of class_first, scan_out) and their slice of the unit table, and the first
+// of them publishes N to the host.  The counters are cleared by the presort launch, the cursors by preprocess_fwd.
+constexpr int INLINE_SCAN_MAX_T = 4096;
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane)
+{
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)v, d);
+        if (lane >= d) v += x;
+    }
+    return v;
+}
+
+// exclusive scan of count[0..T) into s_off[0..T]; all BLOCK threads
+__device__ __forceinline__ void inline_offsets(const uint32_t *count, int T, uint32_t *s_off, uint32_t *s_wave /* [4] */)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + BLOCK - 1) / BLOCK;
+    const int b = min(T, tid * per), e = min(T, b + per);
+    uint32_t c[16];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { c[k] = (k < per && b + k < e) ? count[b + k] : 0u; sum += c[k]; }
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == WAVE - 1) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t pre = incl - sum;
+    for (int w = 0; w < wave; w++) pre += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < per && b + k < e) { s_off[b + k] = pre; pre += c[k]; }
+    if (tid == BLOCK - 1) s_off[T] = pre;
+    __syncthreads();
+}
+
+struct InlineScanLds {
+    uint32_t chunk[NSCAN][BLOCK];      // exclusive prefix of every thread's chunk of tiles
+    uint32_t wave_tot[NSCAN][BLOCK / WAVE];
+    uint32_t total[NSCAN];
+    uint32_t wave_deep[BLOCK / WAVE];
+    uint32_t deepest;
+};
+
+// the spare blocks' scan of all NSCAN quantities, then tile `t`'s prefixes / totals
+__device__ __forceinline__ void inline_scan_build(const uint32_t *count, int T, uint32_t L, int sort_np, InlineScanLds &S)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (T + BLOCK - 1) / BLOCK;
+    const int b = min(T, tid * per), e = min(T, b + per);
+    uint32_t run[NSCAN];
+    uint32_t deepest = 0;
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) run[k] = 0;
+    for (int t = b; t < e; t++) {
+        uint32_t q[NSCAN];
+        tile_terms(count[t], L, q, sort_np);
+        deepest = max(deepest, q[0]);
+#pragma unroll
+        for (int k = 0; k < NSCAN; k++) run[k] += q[k];
+    }
+    for (int d = 32; d >= 1; d >>= 1) deepest = max(deepest, (uint32_t)__shfl_xor((int)deepest, d));
+    if (lane == 0) S.wave_deep[wave] = deepest;
+    uint32_t incl[NSCAN];
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) {
+        incl[k] = wave_incl_scan_u32(run[k], lane);
+        if (lane == WAVE - 1) S.wave_tot[k][wave] = incl[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NSCAN; k++) {
+        uint32_t pre = incl[k] - run[k];
+        for (int w = 0; w < wave; w++) pre += S.wave_tot[k][w];
+        S.chunk[k][tid] = pre;
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < NSCAN; k++) S.total[k] = S.wave_tot[k][0] + S.wave_tot[k][1] + S.wave_tot[k][2] + S.wave_tot[k][3];
+        S.deepest = max(max(S.wave_deep[0], S.wave_deep[1]), max(S.wave_deep[2], S.wave_deep[3]));
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------ K3
 // The grid's extra blocks (beyond the Gaussians') write the unit table: it only depends on the tile scan, like this
 // kernel, so it rides along instead of costing a launch of its own.
+struct InlineScanArgs {
+    const uint32_t *count;         // [T] per-tile instance counters (preprocess_fwd)
+    uint32_t *offset, *unit_first, *mseg_first, *class_first, *scan_out;
+    uint32_t L;                    // this frame's segment length (forced: the inline path is not taken when the scan has to choose it)
+};
+
+template <bool INLINE>
 __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, int gy, const int *radii, GeomState geom,
                                                                const uint32_t *tile_offset, uint32_t *tile_cursor,
                                                                uint64_t *keys, uint64_t capacity, unsigned emit_blocks, FillUnitsArgs fu,
-                                                               int32_t *host_slot, int32_t seq, const uint32_t *scan_out)
+                                                               int32_t *host_slot, int32_t seq, const uint32_t *scan_out, InlineScanArgs is)
 {
-    if (blockIdx.x >= emit_blocks) {
+    // one LDS buffer: emit blocks = [tile offsets (inline scan) | tile table keys, counts, bases | wave sums]; spare blocks = InlineScanLds
+    constexpr int OFFW = INLINE ? INLINE_SCAN_MAX_T + 4 : 0;
+    __shared__ uint32_t smem[OFFW + 3 * TT_SLOTS + BLOCK / WAVE];
+    static_assert(sizeof(InlineScanLds) <= sizeof(uint32_t) * (INLINE_SCAN_MAX_T + 4 + 3 * TT_SLOTS), "spare blocks alias the emit blocks' LDS");
+    uint32_t *s_off = smem, *s_wave = smem + OFFW + 3 * TT_SLOTS;
+    // INLINE: the spare blocks come FIRST in the grid (the first of them publishes N: the host should not wait for it behind
+    // thousands of emit blocks); otherwise they follow the emit blocks as before
+    const unsigned nspare = gridDim.x - emit_blocks;
+    const bool spare = INLINE ? blockIdx.x < nspare : blockIdx.x >= emit_blocks;
+    const unsigned spare_idx = INLINE ? blockIdx.x : blockIdx.x - emit_blocks;
+    const unsigned emit_idx = INLINE ? blockIdx.x - nspare : blockIdx.x;
+    if (spare) {
+        if (INLINE) {
+            InlineScanLds &S = *reinterpret_cast<InlineScanLds *>(smem);
+            const int T = fu.T;
+            inline_scan_build(is.count, T, is.L, fu.sort_np, S);
+            const int t = (int)spare_idx * BLOCK + (int)threadIdx.x;
+            if (spare_idx == 0 && threadIdx.x == 0) {
+                is.scan_out[0] = S.total[0]; is.scan_out[1] = S.deepest; is.scan_out[2] = S.total[1]; is.scan_out[3] = is.L;
+                if (host_slot) publish_counts(host_slot, seq, S.total[0], S.deepest, S.total[1]);
+                is.offset[T] = S.total[0]; is.unit_first[T] = S.total[1]; is.mseg_first[T] = S.total[2];
+#pragma unroll
+                for (int k = 0; k < NCLASS + 2; k++) is.class_first[k * (T + 1) + T] = S.total[3 + k];
+            }
+            if (t < T) {
+                const int per = (T + BLOCK - 1) / BLOCK;
+                const int c0 = t / per;
+                uint32_t pre[NSCAN], tot[NSCAN];
+#pragma unroll
+                for (int k = 0; k < NSCAN; k++) { pre[k] = S.chunk[k][c0]; tot[k] = S.total[k]; }
+                for (int u = c0 * per; u < t; u++) {
+                    uint32_t q[NSCAN];
+                    tile_terms(is.count[u], is.L, q, fu.sort_np);
+#pragma unroll
+                    for (int k = 0; k < NSCAN; k++) pre[k] += q[k];
+                }
+                is.offset[t] = pre[0]; is.unit_first[t] = pre[1]; is.mseg_first[t] = pre[2];
+#pragma unroll
+                for (int k = 0; k < NCLASS + 2; k++) is.class_first[k * (T + 1) + t] = pre[3 + k];      // (a re-run of the tail reads them)
+                fill_units_tile(fu, t, is.count[t], is.L, pre, tot);
+            }
+            return;
+        }
         // (first spare block: this frame's counts go to the host from here when the scan left that to us)
-        if (blockIdx.x == emit_blocks && threadIdx.x == 0 && host_slot) publish_counts(host_slot, seq, scan_out[0], scan_out[1], scan_out[2]);
-        fill_units(fu, (int)(blockIdx.x - emit_blocks));
+        if (spare_idx == 0 && threadIdx.x == 0 && host_slot) publish_counts(host_slot, seq, scan_out[0], scan_out[1], scan_out[2]);
+        fill_units(fu, (int)spare_idx);
         return;
     }
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (INLINE) { inline_offsets(is.count, fu.T, s_off, s_wave); tile_offset = s_off; }
+    const int i = (int)emit_idx * BLOCK + threadIdx.x;
+    // (the three loads are independent: the pixel centre and the depth of a culled Gaussian are stale words that nothing reads --
+    // loading them only after `r > 0` was known put a second memory round trip into a kernel that waits 85 % of its cycles)
     const int r = i < P ? radii[i] : 0;
+    const float2 pxy = i < P ? *reinterpret_cast<const float2 *>(geom.rec + i) : make_float2(0.f, 0.f);
+    const uint32_t dbits = i < P ? __float_as_uint(geom.depth[i]) : 0u;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     uint64_t key = 0;
     if (r > 0) {
-        const float4 q0 = geom.rec[i].q0;
-        tile_rect(q0.x, q0.y, (float)r, gx, gy, minx, miny, maxx, maxy);
-        key = ((uint64_t)__float_as_uint(geom.depth[i]) << 32) | (uint32_t)i;
+        tile_rect(pxy.x, pxy.y, (float)r, gx, gy, minx, miny, maxx, maxy);
+        key = ((uint64_t)dbits << 32) | (uint32_t)i;
     }
     const int rw = maxx - minx;
     const int area = r > 0 ? rw * (maxy - miny) : 0;
@@ -608,9 +760,8 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
     int cx = minx, cy = miny;
     // footprints up to SMALL_AREA tiles: count per tile in the block's LDS table, fetch one cursor range per
     // distinct tile (one global atomic each, all in flight together), then hand out ranks from LDS
-    __shared__ int tt_key[TT_SLOTS];
-    __shared__ uint32_t tt_cnt[TT_SLOTS];
-    __shared__ uint32_t tt_base[TT_SLOTS];
+    int *tt_key = reinterpret_cast<int *>(smem + OFFW);
+    uint32_t *tt_cnt = smem + OFFW + TT_SLOTS, *tt_base = smem + OFFW + 2 * TT_SLOTS;
     for (int q = threadIdx.x; q < TT_SLOTS; q += BLOCK) { tt_key[q] = -1; tt_cnt[q] = 0; }
     __syncthreads();
     if (small) {
@@ -742,10 +893,13 @@ __device__ __forceinline__ int sort_class(uint64_t n, int passes_launched, int &
 
 __global__ void __launch_bounds__(256) tile_presort_kernel(const uint32_t *tile_offset, const uint32_t *run_total, const uint2 *run_tab,
                                                            uint32_t max_runs, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
-                                                           int passes_launched)
+                                                           int passes_launched, uint32_t *zero_count, int T)
 {
     __shared__ uint64_t s[SORT_RUN];
     const int tid = threadIdx.x;
+    // inline-scan frames: the per-tile counters were read by the emit launch; they are cleared here (all zero between frames)
+    if (zero_count)
+        for (int q = (int)blockIdx.x * 256 + tid; q < T; q += (int)gridDim.x * 256) zero_count[q] = 0u;
     if (blockIdx.x >= run_total[0] || blockIdx.x >= max_runs) return;      // one block per (tile, run) of the run table
     const uint2 tr = run_tab[blockIdx.x];
     const uint64_t beg = tile_offset[tr.x], end64 = tile_offset[tr.x + 1];
@@ -843,11 +997,14 @@ __device__ __forceinline__ void sort_level(uint64_t (&k)[4], int t, uint64_t *ld
 }
 
 __global__ void __launch_bounds__(256) tile_presort_reg_kernel(const uint32_t *tile_offset, const uint32_t *run_total, const uint2 *run_tab,
-                                                               uint32_t max_runs, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
-                                                               int passes_launched)
+                                                           uint32_t max_runs, uint64_t *keys, uint64_t *tmp, uint64_t capacity,
+                                                           int passes_launched, uint32_t *zero_count, int T)
 {
     __shared__ uint64_t s[SORT_RUN];
     const int tid = threadIdx.x;
+    // inline-scan frames: the per-tile counters were read by the emit launch; they are cleared here (all zero between frames)
+    if (zero_count)
+        for (int q = (int)blockIdx.x * 256 + tid; q < T; q += (int)gridDim.x * 256) zero_count[q] = 0u;
     if (blockIdx.x >= run_total[0] || blockIdx.x >= max_runs) return;      // one block per (tile, run) of the run table
     const uint2 tr = run_tab[blockIdx.x];
     const uint64_t beg = tile_offset[tr.x], end64 = tile_offset[tr.x + 1];
@@ -1273,6 +1430,16 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.visible = A->visible; pa.geom = geom; pa.tile_count = img.tile_count;
+    // Inline tile scan (see emit_instances_kernel): on the capacity-hint path, when the segment length is known up front and the
+    // tile table fits the emit blocks' LDS.  GMS_INLINE_SCAN=0 keeps the separate tile_scan launch.
+    static int inline_env = -1;
+    if (inline_env < 0) { const char *e = getenv("GMS_INLINE_SCAN"); inline_env = e ? (atoi(e) != 0) : 1; }
+    const uint32_t frame_L_pre = seg_len_for_frame((uint64_t)A->binning_capacity_hint, T);
+    // (every emit block repeats the scan and holds the offsets in LDS, 29 KB per block instead of 12: it pays while the emit blocks
+    // are one resident round -- headline scene: 2 354 -> 2 434 it/s -- and loses beyond, config-5 size: emit 117 -> 141 us)
+    const bool inline_scan = inline_env && A->binning_capacity_hint > 0 && frame_L_pre != 0 && T <= INLINE_SCAN_MAX_T &&
+                             (P + BLOCK - 1) / BLOCK <= 1536;
+    pa.zero_cursor = inline_scan ? img.tile_cursor : nullptr; pa.T = T;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
     const bool split = A->shs_rest != nullptr;
     const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
@@ -1337,11 +1504,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     static thread_local int32_t seq_counter = 0;
     const int32_t seq = (seq_counter = seq_counter == 0x7fffffff ? 1 : seq_counter + 1);
     const uint32_t frame_L = seg_len_for_frame((uint64_t)A->binning_capacity_hint, T);      // 0: the scan chooses from the depth
-    GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
-                                                                                   img.unit_first, img.mseg_first, img.class_first, T, frame_L,
-                                                                                   slot, seq, sort_np, img.scan_out));
-    GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
-    ctr->dirty = false;
+    if (!inline_scan) {
+        GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
+                                                                                       img.unit_first, img.mseg_first, img.class_first, T, frame_L,
+                                                                                       slot, seq, sort_np, img.scan_out));
+        GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
+        ctr->dirty = false;
+    }
+    bool first_tail = true;          // the first enqueue_tail of an inline-scan frame scans inside its emit launch; a re-run reads the tables it left
 
     BlendFwdOut bo;
     bo.rec = geom.rec; bo.bg = A->background; bo.final_T = img.final_T; bo.n_contrib = img.n_contrib;
@@ -1364,9 +1534,17 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         fu.max_multi = (uint32_t)BinningState::n_multi((size_t)capacity); fu.T = T; fu.sort_np = sort_np; fu.scan_out = img.scan_out; fu.max_units = mu;
         fu.max_deep = (uint32_t)BinningState::n_deep((size_t)capacity, (size_t)T);
         const unsigned fblocks = (unsigned)((T + BLOCK - 1) / BLOCK);
-        GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
-                                                                                                       img.tile_cursor, bin.keys, capacity, pblocks, fu,
-                                                                                                       nullptr, seq, img.scan_out));
+        const bool inl = inline_scan && first_tail;
+        first_tail = false;
+        InlineScanArgs isa{img.tile_count, img.tile_offset, img.unit_first, img.mseg_first, img.class_first, img.scan_out, frame_L};
+        if (inl)
+            GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<true><<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
+                                                                                                                 img.tile_cursor, bin.keys, capacity, pblocks, fu,
+                                                                                                                 slot, seq, img.scan_out, isa));
+        else
+            GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<false><<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
+                                                                                                                  img.tile_cursor, bin.keys, capacity, pblocks, fu,
+                                                                                                                  nullptr, seq, img.scan_out, isa));
         GMS_KERNEL_CHECK(A->debug, stream, "emit_instances");
         uint64_t *sort_tmp = reinterpret_cast<uint64_t *>(bin.seg_state);      // free until compositing
         if ((uint64_t)BinningState::n_slots((size_t)capacity, L) * 7u * TILE_PIX * 4u < capacity * 8u) sort_np = 0;   // (very long segments)
@@ -1378,10 +1556,11 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (presort_lds < 0) { const char *e = getenv("GMS_PRESORT"); presort_lds = (e && e[0] == 'l') ? 1 : 0; }
         if (presort_lds)
             GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
-                                                                                                 sort_tmp, capacity, sort_np));
+                                                                                                 sort_tmp, capacity, sort_np, inl ? img.tile_count : nullptr, T));
         else
             GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_presort_reg_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
-                                                                                                     sort_tmp, capacity, sort_np));
+                                                                                                     sort_tmp, capacity, sort_np, inl ? img.tile_count : nullptr, T));
+        if (inl) ctr->dirty = false;          // the counters are clean again once this launch has run
         for (int pass = 0; pass < sort_np; pass++)
             GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
                                                                                                    sort_tmp, capacity, sort_np, pass));
