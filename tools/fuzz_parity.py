@@ -9,6 +9,11 @@ from games_hip import synthetic as syn
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+# third argument "det": deterministic-reduction mode, judged by the STRICT criterion (K = ADJUDICATE_K_STRICT, zero unexplained entries)
+STRICT = len(sys.argv) > 3 and sys.argv[3] == "det"
+if STRICT:
+    import diff_gaussian_rasterization as dgr
+    dgr.set_deterministic(True)
 bad = 0
 worst, cond_count, cond_q = {}, {}, {}
 t0 = time.time()
@@ -31,16 +36,17 @@ for case in range(n_cases):
             oacc = U.f32_realisations(inputs, kw, gc, gd)
             rows, alt_fn = U.alt_oracles(inputs, kw, gc, gd, o["details"])
             rep = U.grad_report(hg, o["grads"], go64=o64["grads"], go32acc=oacc, excuse=U.excused_rows(o["details"]),
-                                alt_rows=rows if rows.any() else None, alts=alt_fn() if rows.any() else None)
+                                alt_rows=rows if rows.any() else None, alts=alt_fn() if rows.any() else None,
+                                K=U.ADJUDICATE_K_STRICT if STRICT else None)
             for k, v in rep.items():
                 worst[k] = max(worst.get(k, 0.0), v["worst_ratio"])
                 if v.get("ref_outliers"):
                     cond_count[k] = max(cond_count.get(k, 0.0), v["outliers"] / v["ref_outliers"])
                 if v.get("ref_q") and v["q_rel"] > U.GRAD_REL:
                     cond_q[k] = max(cond_q.get(k, 0.0), v["q_rel64"] / v["ref_q"])
-            return {k: (U.grad_fails(v), v["max_rel"], v["q_rel"], v["outliers"], v["unexplained"], round(v["worst_ratio"], 1), v.get("excused", 0),
+            return {k: (U.grad_fails(v, strict=STRICT), v["max_rel"], v["q_rel"], v["outliers"], v["unexplained"], round(v["worst_ratio"], 1), v.get("excused", 0),
                         v.get("alt_explained", 0), v["size"], v.get("ref_outliers"), v.get("ref_q"), v.get("q_rel64"))
-                    for k, v in rep.items() if U.grad_fails(v)}
+                    for k, v in rep.items() if U.grad_fails(v, strict=STRICT)}
 
         for rep_i in range(2):                       # twice: second call takes the capacity-hint path
             h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=gd)
@@ -56,7 +62,7 @@ for case in range(n_cases):
     except Exception:
         bad += 1
         print("ERROR", tag, flush=True); traceback.print_exc()
-print("worst adjudication ratio per tensor (K = %g):" % U.ADJUDICATE_K, {k: round(v, 2) for k, v in worst.items()})
+print("worst adjudication ratio per tensor (K = %g%s):" % ((U.ADJUDICATE_K_STRICT, ", deterministic mode, strict") if STRICT else (U.ADJUDICATE_K, "")), {k: round(v, 2) for k, v in worst.items()})
 print("conditioning-relative caps: worst outliers / ref_outliers per tensor (COND_COUNT = %g):" % U.COND_COUNT, {k: round(v, 2) for k, v in cond_count.items()})
 print("                            worst q_rel64 / ref_q where q_rel > 1e-3 (COND_Q = %g):" % U.COND_Q, {k: round(v, 2) for k, v in cond_q.items()})
 print(f"{n_cases} cases, {bad} bad, {time.time() - t0:.0f} s")
