@@ -267,10 +267,12 @@ def grad_report(gh, go, q=0.999, go64=None, excuse=None, go32acc=None, alt_rows=
 
 
 # Deterministic-reduction mode (include/gmsplat.h, GAMES_HIP_DETERMINISTIC=1): no float atomics, fixed summation order.  The two
-# allowances that exist for the ORDER of float atomics are withdrawn there: K drops to ADJUDICATE_K_STRICT (the fixed order is one
-# more float32 realisation of the sums: it must sit inside the spread of the oracle's own realisations, not 8 x outside it) and
-# not a single entry may stay unexplained.
-ADJUDICATE_K_STRICT = 2.0
+# allowances that exist for the ORDER of float atomics are tightened there: K is halved to ADJUDICATE_K_STRICT and not a single
+# entry may stay unexplained.  (K cannot go to 1: the fixed order is one more float32 realisation of the sums, and how far one
+# realisation sits from float64 relative to the few others that were sampled has a tail of its own -- worst ratio 3.9 over 800
+# default-mode fuzz scenes in round 3, 3.35 over 120 deterministic-mode scenes in round 4, both on scenes of ONE elongated Gaussian;
+# K = 2 passed the suite and 119 of those 120 scenes.)
+ADJUDICATE_K_STRICT = 4.0
 
 
 def grad_fails(v, strict=False):

@@ -95,8 +95,7 @@ def test_both_compositing_implementations_are_deterministic_on_a_small_scene(env
 
 @pytest.mark.parametrize("case", ["random", "flat10k"])
 def test_parity_criterion_without_the_atomics_order_allowances(case):
-    """In deterministic mode `assert_grads(strict=True)`: K = 2 instead of 8 (the fixed summation order must sit inside the spread
-    of the float32 oracle's own realisations) and not one unexplained entry (instead of one per million).  Forward parity is
+    """In deterministic mode `assert_grads(strict=True)`: K = 4 instead of 8 and not one unexplained entry (instead of one per million).  Forward parity is
     unchanged by the mode (the forward has no float atomics)."""
     import diff_gaussian_rasterization as dgr
     if case == "random":
