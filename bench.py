@@ -698,7 +698,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{desc['text']}, SH degree 3, {size}x{size}, orbit camera k=(rank*views+v)%8, white bg",
                        "model": desc["model"], "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
-                       "interactions": interactions,
+                       "interactions": interactions, "interactions_kind": stats.get("interactions_kind"),
                        "visible_gaussians": stats.get("visible"), "deepest_tile": stats.get("deepest_tile"),
                        "mean_instances_per_tile": round(N / max(1, ((size + 15) // 16) ** 2), 1),
                        "views_per_step": world * vps, "views_per_rank_per_step": vps,

@@ -204,10 +204,16 @@ def last_stats() -> dict:
     d.pop("geom", None)
     image = d.pop("image", None)
     if image is not None and image.numel():
-        # sum over pixels of the 1-based list position of the last splat each pixel composited: the number of
-        # (pixel, splat) steps a per-pixel front-to-back walk takes ("interactions")
+        # sum over pixels of the stored n_contrib.  QUADRANT kernels (GMS_MICRO=0, deep frames): the 1-based position IN THE TILE'S
+        # LIST of the last splat the pixel composited = the (pixel, splat) steps of a per-pixel front-to-back walk, SURVEY.md 8(d)
+        # "interactions", comparable with the oracle's count.  MICRO-TILE kernels (the default on shallow frames): seg * L + the
+        # 1-based position in the pixel's 4x4 BLOCK's pre-filtered list -- the steps of a walk over entries that reach the block,
+        # several times smaller and NOT comparable with the figure above or with earlier rounds (`interactions_kind` says which).
         off = int(_lib.load().gms_image_n_contrib_offset(d["width"], d["height"]))
         d["interactions"] = int(image[off:off + 4 * d["width"] * d["height"]].view(torch.int32).sum(dtype=torch.int64))
+        T = ((d["width"] + 15) // 16) * ((d["height"] + 15) // 16)
+        micro = os.environ.get("GMS_MICRO", "") != "0" and (os.environ.get("GMS_MICRO", "") == "1" or max(d.get("capacity_hint", 0), d.get("num_rendered", 0)) <= 512 * T)
+        d["interactions_kind"] = "micro_tile_block_list_positions" if micro else "tile_list_positions"
     return d
 
 

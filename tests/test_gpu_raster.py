@@ -316,6 +316,7 @@ def test_deep_tiles_take_the_merge_path_sort_from_the_second_frame(P):
 
 
 @pytest.mark.parametrize("env", [
+    {"GMS_INLINE_SCAN": "0"},
     # micro-tile compositing (the default, blend_micro.hip): segment lengths, forced two-phase products, entries per trip
     {"GMS_SEG_LEN": "64"}, {"GMS_SEG_LEN": "128", "GMS_DEEP": "1"}, {"GMS_SEG_LEN": "192"}, {"GMS_TRIP": "4", "GMS_TRIP_BWD": "1"},
     {"GMS_TRIP": "1", "GMS_TRIP_BWD": "4"}, {"GMS_UNIT_RUN": "1"}, {"GMS_SYNC_BINNING": "1"}, {"GMS_BINDING": "ctypes"},
