@@ -234,6 +234,9 @@ def parse_args(argv=None):
     ap.add_argument("--mode", default="train", choices=["train", "animate"],
                     help="train: the headline fwd+bwd step; animate: BASELINE config 5 style forward-only renders with per-frame "
                          "vertex animation and on-device re-derivation of scale/rotation (secondary line, not the headline)")
+    ap.add_argument("--graph", action="store_true",
+                    help="--mode animate only: replay the frame as a captured hipGraph (games_hip.animate.GraphedAnimation) instead of "
+                         "enqueuing it from Python every frame")
     ap.add_argument("--loss", default="dense_grad", choices=["dense_grad", "l1_ssim"],
                     help="dense_grad: the headline step of SURVEY 8(d), dL/dcolor = (image-0.5)/(3HW); l1_ssim: the reference's "
                          "training loss (train.py:106-107) through the fused HIP L1+SSIM kernels against a synthetic target")
@@ -502,19 +505,28 @@ def main():
         verts = torch.cat(list(model.vertices)) if isinstance(model.vertices, (list, tuple)) else model.vertices
         faces = model._hip_topology()[0] if isinstance(model.faces, (list, tuple)) else model.faces
 
+        anim = None
+        if args.graph:
+            from games_hip.animate import GraphedAnimation
+            anim = GraphedAnimation(model, cam, pipe, bg)
+
         def animate_step():
             with torch.no_grad():
                 t = 0.05 * frame[0]
                 frame[0] += 1
                 new_v = verts * (1.0 + 0.05 * math.sin(t))           # scripts/render_time_animated.py:68-87 style
-                render_animated(None, new_v[faces], cam, model, pipe, bg)
+                if anim is not None:
+                    anim.render(new_v[faces], check=(frame[0] % 64 == 0))      # the frame's counts are read back every 64th frame
+                else:
+                    render_animated(None, new_v[faces], cam, model, pipe, bg)
         el = timed(animate_step, args.steps, args.warmup)
         if rank == 0:
             print(json.dumps({"metric": "renders/s (fwd only, per-frame vertex animation + fused face->Gaussian + raster)",
                               "value": round(world * args.steps / el, 2), "unit": "renders/s", "n_gpus": world,
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 4),
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{desc['text']}, animate, {size}x{size}"}}), flush=True)
+                              "config": {"workload": f"{desc['text']}, animate, {size}x{size}",
+                                         "graph": ({"captures": anim.captures, **anim.status()} if anim is not None else None)}}), flush=True)
         if distributed:
             dist.destroy_process_group()
         return

@@ -1339,6 +1339,14 @@ extern "C" size_t gms_image_n_contrib_offset(int32_t w, int32_t h)
     ImageState s = ImageState::carve(base, (size_t)w, (size_t)h);
     return (size_t)(reinterpret_cast<char *>(s.n_contrib) - base);
 }
+extern "C" size_t gms_image_counts_offset(int32_t w, int32_t h)
+{
+    char *const base = reinterpret_cast<char *>(uintptr_t(1) << 20);
+    ImageState s = ImageState::carve(base, (size_t)w, (size_t)h);
+    return (size_t)(reinterpret_cast<char *>(s.scan_out) - base);
+}
+static thread_local int64_t t_last_launched_units = 0;
+extern "C" int64_t gms_last_launched_units(void) { return t_last_launched_units; }
 extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 {
     const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
@@ -1585,6 +1593,18 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     };
 
     int64_t N;
+    if (A->no_host_wait) {
+        // capturable form (gmsplat.h): launches only.  The counts stay on the device (img.scan_out); overflow is the caller's to detect.
+        if (A->binning_capacity_hint <= 0) { set_error("no_host_wait needs a binning capacity hint (render the shape once without it first)"); return GMS_ERR_INVALID_ARGUMENT; }
+        const uint64_t cap = (uint64_t)A->binning_capacity_hint;
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L, micro_mode()));
+        if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+        const int32_t rc = enqueue_tail(bin_mem, cap, false);
+        if (rc != GMS_OK) return rc;
+        t_last_launched_units = (int64_t)launched_units;
+        if (A->num_units_out) *A->num_units_out = 0;
+        return (int64_t)cap;
+    }
     if (A->binning_capacity_hint > 0) {
         // optimistic path: enqueue the whole tail before looking at N (no pipeline bubble)
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
@@ -1592,6 +1612,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
         int32_t rc = enqueue_tail(bin_mem, cap, false);
         if (rc != GMS_OK) return rc;
+        t_last_launched_units = (int64_t)launched_units;
         rc = wait_for_count(slot, seq, stream, &N);
         if (rc != GMS_OK) return rc;
         deepest_seen = deepest_tile(slot);

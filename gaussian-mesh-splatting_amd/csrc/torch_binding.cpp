@@ -131,6 +131,13 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
         auto it = g_capacity.find(key);
         if (it != g_capacity.end()) hint = quantize_capacity(it->second + it->second / 4 + 4096);
     }
+    // Stream capture (torch.cuda.graph): the forward must not touch the host.  gms_rasterize_forward is then asked for its
+    // launches-only form; the frame's counts stay on the device (games_hip.animate.GraphedAnimation reads them after a replay).
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing((hipStream_t)stream_of(means3D_), &cap_status) == hipSuccess && cap_status != hipStreamCaptureStatusNone;
+    if (capturing)
+        TORCH_CHECK(hint > 0 && P > 0, "rasterizing inside a stream capture needs the capacity hint of this shape: render it at least once on the "
+                                        "same stream before the capture (not in deterministic mode)");
     Slot geom{Tensor(), dev, false}, binning{Tensor(), dev, false}, image{Tensor(), dev, false};
     int64_t num_units = 0;
     GmsRasterForwardArgs a{};
@@ -146,6 +153,7 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
     a.binning_capacity_hint = hint;
     a.visible = (visible.defined() && visible.numel()) ? static_cast<uint8_t *>(visible.data_ptr()) : nullptr;
     a.num_units_out = &num_units;
+    a.no_host_wait = capturing ? 1 : 0;
     const int64_t n = gms_rasterize_forward(&a, stream_of(means3D));
     TORCH_CHECK(!(geom.failed || binning.failed || image.failed), "scratch allocation failed (out of device memory?)");
     check_rc(n, "gms_rasterize_forward");
@@ -155,7 +163,7 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
     {
         std::lock_guard<std::mutex> lk(g_mu);
         int64_t &c = g_capacity[key];
-        c = std::max(n, (int64_t)(0.97 * (double)c));
+        if (!capturing) c = std::max(n, (int64_t)(0.97 * (double)c));      // (a captured call returns the capacity, not a count)
         g_last.num_rendered = n; g_last.num_units = num_units; g_last.hint = hint; g_last.P = P; g_last.W = (int)W; g_last.H = (int)H;
         if (g_keep_buffers.load()) { g_last.radii = f.radii; g_last.image = f.image; g_last.binning = f.binning; g_last.geom = f.geom; }
     }
@@ -632,4 +640,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("set_capacity", &set_capacity);
     m.def("clear_capacity", &clear_capacity);
     m.def("abi_version", []() { return (int64_t)gms_abi_version(); });
+    m.def("image_counts_offset", [](int64_t w, int64_t h) { return (int64_t)gms_image_counts_offset((int32_t)w, (int32_t)h); });
+    m.def("last_launched_units", []() { return (int64_t)gms_last_launched_units(); });
 }

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
-GMS_ABI_VERSION = 3
+GMS_ABI_VERSION = 4
 GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
 ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
 
@@ -33,7 +33,7 @@ class RasterForwardArgs(C.Structure):
         ("geom_alloc", ALLOC_FN), ("geom_ctx", C.c_void_p),
         ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
         ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
-        ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p), ("num_units_out", C.c_void_p),
+        ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p), ("num_units_out", C.c_void_p), ("no_host_wait", C.c_int32),
     ]
 
 
@@ -98,6 +98,7 @@ EXPORTS = (
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
     "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault", "gms_set_deterministic", "gms_get_deterministic",
+    "gms_image_counts_offset", "gms_last_launched_units",
 )
 K_COUNT = 17
 
@@ -136,6 +137,9 @@ def load():
         lib.gms_geom_bytes.argtypes = [C.c_int32]
         lib.gms_image_bytes.argtypes = [C.c_int32, C.c_int32]
         lib.gms_image_n_contrib_offset.argtypes = [C.c_int32, C.c_int32]
+        lib.gms_image_counts_offset.restype = C.c_size_t
+        lib.gms_image_counts_offset.argtypes = [C.c_int32, C.c_int32]
+        lib.gms_last_launched_units.restype = C.c_int64
         lib.gms_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.gms_knn_workspace_bytes.restype = C.c_size_t
         lib.gms_knn_workspace_bytes.argtypes = [C.c_int32]

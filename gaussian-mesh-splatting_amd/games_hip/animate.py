@@ -105,3 +105,89 @@ def render_flame_animated(gaussians, views: Iterable, pipeline, background: torc
         if out_dir:
             _save(img, os.path.join(out_dir, f"{k:05d}.png"))
     return frames
+
+
+class GraphedAnimation:
+    """The animated render loop of scripts/render_time_animated.py:68-87 as a replayed hipGraph.
+
+    One frame = deformed triangles -> fused face->Gaussian op -> rasterizer forward.  After `warmup` ordinary frames on a private
+    stream (every allocation, capacity hint and library-owned buffer of the shape in place) one frame is CAPTURED with
+    `torch.cuda.graph`; inside the capture the rasterizer runs in its launches-only form (`GmsRasterForwardArgs.no_host_wait`,
+    include/gmsplat.h: no host wait for the instance count).  `render(triangles)` then copies the triangles into the graph's static
+    input, replays the graph and returns the static output image: no Python between the kernels, no host synchronisation.
+
+    A replayed frame keeps the CAPTURED capacity and launch sizes.  `status()` reads the frame's own counts back from the device
+    (one small copy: call it every frame or every few, as the application likes): if a frame had more (Gaussian, tile) instances
+    than the captured binning capacity or more work units than the captured launches it is incomplete -- `render(...,
+    check=True)` re-captures with the frame's counts and renders it again.
+
+        anim = GraphedAnimation(gaussians, view, pipeline, background)
+        for k in range(n_frames):
+            img = anim.render(transform(vertices, t[k])[faces].float(), check=True)
+    """
+
+    def __init__(self, gaussians, view, pipeline, background: torch.Tensor, warmup: int = 3):
+        import diff_gaussian_rasterization as dgr
+        if dgr._C is None:
+            raise NotImplementedError("GraphedAnimation needs the _C extension module")
+        self._dgr = dgr
+        self.pc, self.view, self.pipe, self.bg, self.warmup = gaussians, view, pipeline, background, int(warmup)
+        self.stream = torch.cuda.Stream(device=background.device)
+        self.graph = None
+        self.static_tri = None
+        self.out = None
+        self.captures = 0
+
+    @torch.no_grad()
+    def _capture(self, triangles: torch.Tensor, slack: float = 1.0) -> None:
+        dgr = self._dgr
+        dev = triangles.device
+        self.static_tri = triangles.detach().clone()
+        W, H = int(self.view.image_width), int(self.view.image_height)
+        P = int(self.pc._alpha.shape[0] * self.pc._alpha.shape[1])
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(max(self.warmup, 1)):          # ordinary frames: hints, pools, the library's per-stream buffers
+                render_animated(None, self.static_tri, self.view, self.pc, self.pipe, self.bg)
+            if slack > 1.0:                                # a re-capture after an overflow: leave room above this frame's count
+                n = int(dgr.last_stats()["num_rendered"])
+                dgr.set_capacity_hint(dev.index if dev.index is not None else torch.cuda.current_device(), W, H, P, int(n * slack))
+                render_animated(None, self.static_tri, self.view, self.pc, self.pipe, self.bg)
+            self.stream.synchronize()
+            dgr.keep_buffers(True)                         # the captured frame's image scratch holds its counts: keep the handle
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.out = render_animated(None, self.static_tri, self.view, self.pc, self.pipe, self.bg)["render"]
+            st = dict(dgr._C.last_stats())
+            dgr.keep_buffers(False)
+        self._image_scratch = st["image"]
+        self.capacity = int(st["capacity_hint"])
+        self.launched_units = int(dgr._C.last_launched_units())
+        self._counts_off = int(dgr._C.image_counts_offset(W, H))
+        self.captures += 1
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+
+    def status(self) -> dict:
+        """Counts of the most recent replayed frame (device -> host copy of 16 bytes) and whether it fitted the capture."""
+        c = self._image_scratch[self._counts_off:self._counts_off + 16].view(torch.int32).cpu()
+        n, deepest, units, L = (int(x) & 0xffffffff for x in c)
+        return {"num_rendered": n, "deepest_tile": deepest, "num_units": units, "segment_length": L, "capacity": self.capacity,
+                "launched_units": self.launched_units, "complete": n <= self.capacity and units <= self.launched_units}
+
+    @torch.no_grad()
+    def render(self, triangles: torch.Tensor, check: bool = False) -> torch.Tensor:
+        """The frame for `triangles` [F,3,3].  Returns the graph's STATIC output tensor (overwritten by the next call: clone it to
+        keep it).  `check`: verify the frame fitted the captured sizes and, if it did not, re-capture at 1.5x its count and redo it."""
+        dev = triangles.device
+        if self.graph is None or triangles.shape != self.static_tri.shape:
+            self._capture(triangles)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            self.static_tri.copy_(triangles)
+            self.graph.replay()
+            if check and not self.status()["complete"]:
+                self._capture(triangles, slack=1.5)
+                self.static_tri.copy_(triangles)
+                self.graph.replay()
+        torch.cuda.current_stream(dev).wait_stream(self.stream)
+        return self.out

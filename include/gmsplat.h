@@ -46,7 +46,8 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 3   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17 */
+#define GMS_ABI_VERSION 4   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
+                             4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset */
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -106,10 +107,22 @@ typedef struct GmsRasterForwardArgs {
     /* Optional HOST pointer: receives the number of (tile, segment) work units of this frame; pass it back to
      * gms_rasterize_backward (num_units) so its launch is sized exactly.  NULL = not wanted. */
     int64_t *num_units_out;
+    /* 1: the call only ENQUEUES -- no host wait for the instance count, no overflow re-run, nothing but kernel launches (and one
+     * host-visible store from a kernel) on `stream` -- so that it can be captured into a hipGraph (the
+     * animated render loops of scripts/render_time_animated.py:68-87 replayed without host work).  Needs binning_capacity_hint > 0
+     * and every library-owned buffer of this (thread, device, stream, shape) in place, i.e. at least one ordinary call on the same
+     * stream first.  The return value is then the CAPACITY (an upper bound of the instance count unless the frame overflowed); the
+     * frame's true counts stay on the device: four uint32 {instances, deepest tile, work units, segment length} at byte offset
+     * gms_image_counts_offset() of the image scratch buffer.  A frame with more instances than the capacity, or more work units than
+     * the launch was sized for, is INCOMPLETE and the caller must detect it from those counts (games_hip.animate.GraphedAnimation
+     * does).  Pass the returned value as num_rendered and binning_capacity, and num_units = 0, to a backward call. */
+    int32_t no_host_wait;
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */
 int64_t gms_rasterize_forward(const GmsRasterForwardArgs *args, void *stream);
+/* Blocks (work units) the compositing launches of the calling thread's most recent gms_rasterize_forward were sized for. */
+int64_t gms_last_launched_units(void);
 
 typedef struct GmsRasterBackwardArgs {
     int32_t P, D, M, width, height;
@@ -323,6 +336,8 @@ size_t gms_image_bytes(int32_t width, int32_t height);
 /* Byte offset, inside the image scratch buffer, of n_contrib [H*W] uint32 (1-based list position of the last splat each
  * pixel composited): lets a caller sum the per-pixel walk lengths ("interactions") after a forward. */
 size_t gms_image_n_contrib_offset(int32_t width, int32_t height);
+/* Byte offset, inside the image scratch buffer, of the frame's counts: uint32[4] = {instances N, deepest tile, work units, segment length}. */
+size_t gms_image_counts_offset(int32_t width, int32_t height);
 size_t gms_binning_bytes(int64_t num_instances, int32_t width, int32_t height);
 
 /* ---- deterministic-reduction mode (SURVEY.md section 5 "race detection", section 7 hard part 1) ---------------------------
