@@ -15,6 +15,9 @@ python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_lik
 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_1m --mode animate > gpurun_out/${T}_bench_c5_1m_animate.json.log 2>&1
 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_500k --profile-steps 10 > gpurun_out/${T}_bench_c5_500k.json.log 2>&1
 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_500k --mode animate > gpurun_out/${T}_bench_c5_500k_animate.json.log 2>&1
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload small --mode animate > gpurun_out/${T}_bench_small_animate.json.log 2>&1
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload small --mode animate --graph > gpurun_out/${T}_bench_small_animate_graph.json.log 2>&1
+python bench.py --steps 60 --warmup 10 --no-cpu-baseline --workload c5_flame_like_500k --mode animate --graph > gpurun_out/${T}_bench_c5_500k_animate_graph.json.log 2>&1
 GMS_BENCH_FORCE_DDP=1 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --workload c4_ficus_like --profile-steps 0 > gpurun_out/${T}_bench_one_rank_rccl.json.log 2>&1
 python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --profile-steps 0 > gpurun_out/${T}_bench_gpus2_shared.json.log 2>&1
 GAMES_HIP_DETERMINISTIC=1 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --profile-steps 10 > gpurun_out/${T}_bench_deterministic.json.log 2>&1
@@ -29,3 +32,4 @@ python tools/fuzz_parity.py ${FUZZ_DET_N:-120} 23000 det > gpurun_out/${T}_fuzz_
 rm -f gpurun_out/parity_report.jsonl
 python -m pytest tests -m gpu -q 2>&1 | tail -15 > gpurun_out/${T}_pytest_gpu.log
 tail -3 gpurun_out/${T}_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${T}_smoke.log 2>&1; tail -2 gpurun_out/${T}_smoke.log
