@@ -153,3 +153,100 @@ def test_reference_animated_renderer_with_the_installed_mixin(monkeypatch):
     finally:
         hip_model.uninstall(games, out)
         ref_import.drop_reference_stubs()
+
+
+def test_reference_points_animated_renderer_runs_on_the_drop_in_surface(monkeypatch):
+    """renderer/gaussian_points_animated_renderer/__init__.py:21-114 (scripts/render_points_time_animated.py,
+    scripts/render_from_object.py), the fourth `render()` variant of SURVEY 8(a) a7, with the reference's own
+    `PointsGaussianModel` (games/flat_splatting/scene/points_gaussian_model.py: pseudo-mesh faces from flat Gaussians, scale /
+    rotation re-derived in PyTorch from the deformed faces): centres = first triangle vertex, flat first scale axis 1e-8.
+    Image == the oracle rendering of exactly those Gaussians; gradients reach the model."""
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import diff_gaussian_rasterization as dgr
+    import games
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", _oracle_rasterize)
+    pts_render = importlib.import_module("renderer.gaussian_points_animated_renderer").render
+    try:
+        sc = syn.flat_scene(400, seed=3)
+        with ref_import.cuda_literals_on_cpu():
+            m = games.gaussianModelRender["gs_points"](3)
+            m._xyz = torch.nn.Parameter(sc.means3D.clone())
+            m._scaling = torch.nn.Parameter(torch.log(sc.scales[:, 1:].clone()))          # the model keeps the two in-plane axes
+            m._rotation = torch.nn.Parameter(sc.rotations.clone())
+            m._opacity = torch.nn.Parameter(torch.logit(sc.opacities.clone()))
+            m._features_dc = torch.nn.Parameter(sc.shs[:, :1].clone())
+            m._features_rest = torch.nn.Parameter(sc.shs[:, 1:].clone())
+            m.active_sh_degree = 3
+            with torch.no_grad():
+                m.prepare_vertices()                                                   # pseudo-mesh faces of the flat Gaussians
+            tri = (m.triangles * torch.tensor([1.0, 1.05, 0.95]) + torch.tensor([0.02, 0.0, -0.01])).detach().requires_grad_(True)
+            cam = syn.orbit_camera(3, width=72, height=56)
+            bg = torch.tensor([0.0, 0.0, 0.0])
+            pkg = pts_render(tri, cam, m, _Pipe(), bg)
+            image = pkg["render"]
+            assert image.shape == (3, 56, 72) and pkg["radii"].dtype == torch.int32
+            ((image - 0.3) ** 2).mean().backward()
+            assert tri.grad is not None and float(tri.grad.abs().max()) > 0          # through prepare_scaling_rot(triangles) and the centres
+            assert m._opacity.grad is not None and m._features_dc.grad is not None
+            with torch.no_grad():
+                xa, sa, ra, oa = tri[:, 0].detach(), m.get_scaling, m.get_rotation, m.get_opacity
+                shs = m.get_features
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=56, image_width=72,
+                                tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, viewmatrix=cam.world_view_transform,
+                                projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center)
+        assert float(np.abs(image.detach().numpy() - o.color).max()) <= 1e-5 and int((o.radii > 0).sum()) > 50
+    finally:
+        ref_import.drop_reference_stubs()
+
+
+def test_reference_flame_renderer_with_the_installed_mixin(monkeypatch):
+    """renderer/flame_gaussian_renderer/__init__.py:20-116 (scripts/render_flame.py drives it), the third `render()` variant: the
+    centres follow `pc.alpha @ vertices[pc.faces]` for the vertices the caller passes, scale / rotation stay what the model holds
+    (SURVEY appendix C.1).  `pc` is the reference's GaussianFlameModel with the installed HIP mixin (K0 op served by the
+    restatement here); image == the oracle rendering of those Gaussians."""
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import diff_gaussian_rasterization as dgr
+    import games
+    from games_hip import model as hip_model
+    from oracle import mesh_oracle
+    import test_abi
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", _oracle_rasterize)
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", test_abi._cpu_op)
+    flame_render = importlib.import_module("renderer.flame_gaussian_renderer").flame_render
+    out = hip_model.install(games)
+    try:
+        scene = syn.mesh_scene("tiny")
+        new_v = scene.vertices * torch.tensor([0.95, 1.1, 1.0]) + torch.tensor([0.01, 0.0, 0.02])
+        with ref_import.cuda_literals_on_cpu(), torch.no_grad():
+            m = games.gaussianModelRender["gs_flame"](3)
+            par = lambda t: torch.nn.Parameter(t.clone())
+            m.point_cloud = hip_model._FlameCloud(hip_model._SyntheticFlameLayer(scene.vertices.clone()), hip_model._squeeze_and_enlarge)
+            m.faces = scene.faces
+            m._flame_shape, m._flame_exp, m._flame_pose = par(torch.zeros(1, 4)), par(torch.zeros(1, 4)), par(torch.zeros(1, 6))
+            m._flame_neck_pose, m._flame_trans = par(torch.zeros(1, 3)), par(torch.zeros(1, 3))
+            m._vertices_enlargement = par(torch.ones_like(scene.vertices))
+            m._alpha, m._scales, m._opacity = par(scene._alpha), par(scene._scale), par(scene._opacity)
+            m._features_dc, m._features_rest = par(scene._features_dc), par(scene._features_rest)
+            m.active_sh_degree = 3
+            m.update_alpha()                    # FLAME layer (synthetic here) -> vertices -> softmax alphas, xyz  (the mixin)
+            m.prepare_scaling_rot()
+            cam = syn.orbit_camera(6, width=64, height=64)
+            bg = torch.ones(3)
+            img = flame_render(cam, m, _Pipe(), bg, vertices=new_v)["render"]
+            # what the renderer fed the rasterizer: centres from the NEW vertices, scale / rotation from the model (rest pose)
+            al, _, _, scaling, rot = mesh_oracle.mesh_to_gaussians(scene.vertices, scene.faces, scene._alpha, scene._scale, "softmax")
+            xyz = torch.matmul(al, new_v[scene.faces]).reshape(-1, 3)
+            xa, sa, ra, oa, shs = mesh_oracle.activated(xyz, scaling, rot, scene._opacity, scene._features_dc, scene._features_rest)
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=64, image_width=64,
+                                tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, viewmatrix=cam.world_view_transform,
+                                projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center)
+        assert float(np.abs(img.numpy() - o.color).max()) <= 1e-5
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
