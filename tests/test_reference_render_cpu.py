@@ -4,6 +4,8 @@ own `GaussianMeshModel` run unmodified on top of the drop-in package's Python su
 with `screenspace_points.grad` -- with only the innermost kernel call replaced by the CPU oracle (there is no GPU here and
 no reference tree on the GPU box, so this is the one place where the reference's glue and the drop-in meet in a test).
 With `install()`: the mixin model (K0 op replaced by the restatement) renders the same image as the reference class."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -250,3 +252,64 @@ def test_reference_flame_renderer_with_the_installed_mixin(monkeypatch):
     finally:
         hip_model.uninstall(games, out)
         ref_import.drop_reference_stubs()
+
+
+def test_reference_render_time_animated_loop_equals_the_driver(monkeypatch, tmp_path):
+    """scripts/render_time_animated.py:68-87: the reference's own `render_set` loop (its `transform_hotdog_fly`, its animated
+    renderer, its `torchvision.utils.save_image` calls) runs UNMODIFIED on the drop-in with the installed mesh mixin, and
+    `games_hip.animate.render_time_animated` -- the driver the GPU box uses -- produces the same frames bit for bit."""
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import sys
+    import types
+    import diff_gaussian_rasterization as dgr
+    import games
+    from games_hip import animate, model as hip_model
+    from games_hip.render import PipelineParams
+    import test_abi
+    monkeypatch.setattr(dgr, "_rasterize_gaussians", _oracle_rasterize)
+    monkeypatch.setattr(hip_model, "mesh_to_gaussians", test_abi._cpu_op)
+
+    def cpu_tri_op(triangles, _alpha, _scale, alpha_mode="relu", fused_activations=False):
+        F = triangles.shape[0]
+        return test_abi._cpu_op(triangles.reshape(3 * F, 3), torch.arange(3 * F).reshape(F, 3), _alpha, _scale, alpha_mode,
+                                fused_activations=fused_activations)
+    monkeypatch.setattr(hip_model, "triangles_to_gaussians", cpu_tri_op)
+    import games_hip.render as hip_render_mod
+    monkeypatch.setattr(hip_render_mod, "triangles_to_gaussians", cpu_tri_op, raising=False)
+    import games_hip.mesh_op as mesh_op_mod
+    monkeypatch.setattr(mesh_op_mod, "triangles_to_gaussians", cpu_tri_op)
+    saved = []
+    tv = types.ModuleType("torchvision")
+    tv.utils = types.SimpleNamespace(save_image=lambda t, path: saved.append((os.path.basename(os.path.dirname(path)), t.detach().clone())))
+    monkeypatch.setitem(sys.modules, "torchvision", tv)
+    script = importlib.import_module("scripts.render_time_animated")          # the reference's script module (its __main__ part is guarded)
+    out = hip_model.install(games)
+    try:
+        scene = syn.mesh_scene("tiny")
+        with ref_import.cuda_literals_on_cpu(), torch.no_grad():
+            m = games.gaussianModelRender["gs_mesh"](3)
+            m.vertices, m.faces = scene.vertices.clone(), scene.faces
+            m._alpha, m._scale, m._opacity = scene._alpha.clone(), scene._scale.clone(), scene._opacity.clone()
+            m._features_dc, m._features_rest = scene._features_dc.clone(), scene._features_rest.clone()
+            m.active_sh_degree = 3
+            m.update_alpha(); m.prepare_scaling_rot()
+            views = []
+            for k in range(3):
+                c = syn.orbit_camera(k, width=48, height=40)
+                c.original_image = torch.zeros(3, 40, 48)
+                views.append(c)
+            bg = torch.ones(3)
+            script.render_set(None, str(tmp_path), "test", 7, views, m, _Pipe(), bg)          # the reference's loop, unmodified
+            ref_frames = [t for where, t in saved if where == "time_animated"]
+            assert len(ref_frames) == 3 and os.path.isdir(tmp_path / "test" / "ours_7" / "time_animated")
+            ours = animate.render_time_animated(m, views, PipelineParams(), bg, transform=animate.transform_hotdog_fly)
+        for a, b in zip(ref_frames, ours):
+            assert torch.equal(a, b)
+        assert not torch.equal(ours[0], ours[2])                      # the frames differ: the deformation was applied
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
+        sys.modules.pop("scripts.render_time_animated", None)
