@@ -84,8 +84,15 @@ def _cpu_op(vertices, faces, _alpha, _scale, alpha_mode="relu", face_splat_offse
     """Test-only stand-in for the HIP op (same return tuple), built on the CPU restatement: lets the reference's own
     create_from_pcd / save_ply / load_ply drive the mixins in this GPU-less container."""
     from oracle import mesh_oracle
-    assert face_splat_offset is None
-    alpha, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vertices, faces, _alpha, _scale, alpha_mode)
+    if face_splat_offset is None:
+        alpha, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(vertices, faces, _alpha, _scale, alpha_mode)
+    else:
+        # CSR call (gs_multi_mesh: `_alpha` [P,3], `splat_face` [P]): every splat gets a private copy of its face, S = 1
+        tri = vertices[faces.long()[splat_face.long()]]                         # [P,3,3], differentiable back to `vertices`
+        P = tri.shape[0]
+        alpha, _, xyz, scaling, rot = mesh_oracle.mesh_to_gaussians(tri.reshape(-1, 3), torch.arange(3 * P).reshape(P, 3),
+                                                                    _alpha.reshape(P, 1, 3), _scale, alpha_mode)
+        alpha = alpha.reshape(P, 3)
     out = (alpha, xyz, scaling, rot)
     if fused_activations:
         out += (torch.exp(scaling), torch.nn.functional.normalize(rot))

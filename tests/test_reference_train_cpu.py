@@ -171,3 +171,118 @@ class _null:
 
     def __exit__(self, *a):
         return False
+
+
+def _multi_point_clouds(MultiMeshPointCloud):
+    scenes = syn.multi_mesh_scenes("multi_tiny", state="init")
+    pcds = []
+    for sc in scenes:
+        tri = sc.vertices[sc.faces]
+        P = sc.num_gaussians
+        pcds.append(MultiMeshPointCloud(alpha=sc._alpha, points=torch.matmul(sc._alpha, tri).reshape(-1, 3), colors=np.full((P, 3), 0.5),
+                                        normals=np.zeros((P, 3)), vertices=sc.vertices.numpy(), faces=sc.faces.numpy(), triangles=tri))
+    return pcds, scenes
+
+
+def _multi_targets(cams, device):
+    from oracle import gs_oracle, mesh_oracle
+    scenes = syn.multi_mesh_scenes("multi_tiny", state="trained")
+    with torch.no_grad():
+        xyz, scaling, rot = mesh_oracle.multi_mesh_to_gaussians([s.vertices for s in scenes], [s.faces for s in scenes],
+                                                                [s._alpha for s in scenes], [s._scale for s in scenes])
+        xa, sa, ra, oa, shs = mesh_oracle.activated(xyz, scaling, rot, torch.cat([s._opacity for s in scenes]),
+                                                    torch.cat([s._features_dc for s in scenes]), torch.cat([s._features_rest for s in scenes]))
+    for c in cams:
+        o = gs_oracle.rasterize(means3D=xa, opacities=oa, shs=shs, scales=sa, rotations=ra, image_height=c.image_height,
+                                image_width=c.image_width, tanfovx=c.tanfovx, tanfovy=c.tanfovy, bg=torch.ones(3),
+                                viewmatrix=c.world_view_transform.cpu(), projmatrix=c.full_proj_transform.cpu(), sh_degree=3,
+                                campos=c.camera_center.cpu())
+        c.original_image = torch.from_numpy(o.color.copy()).to(device)
+
+
+def test_reference_training_loop_on_the_multi_mesh_model(monkeypatch, tmp_path):
+    """BASELINE config 4's model on the reference's loop: `train.training("gs_multi_mesh", ...)` unmodified, its GaussianMultiMeshModel
+    with the installed mixin (ONE CSR launch for the two meshes instead of the per-mesh python loop), its per-mesh optimizer groups
+    and its list-valued model_params.pt; the stand-alone HipGaussianMultiMeshModel + games_hip.train walks the same trajectory."""
+    if not ref_import.available():
+        pytest.skip("reference tree not present")
+    ref_import.import_reference()
+    import importlib
+    import games
+    from games.multi_mesh_splatting.utils.graphics_utils import MultiMeshPointCloud
+    from games_hip import model as hip_model
+    from games_hip import train as hip_train
+    from games_hip.render import PipelineParams, render as hip_render
+    from games_hip.synthetic import RGB2SH, inverse_sigmoid
+    from oracle import loss_oracle
+    train = importlib.import_module("train")
+    on_cpu = DEVICE == "cpu"
+    if on_cpu:
+        _patch_kernels(monkeypatch)
+    real_load = torch.load
+    monkeypatch.setattr(torch, "load", lambda *a, **k: real_load(*a, **{"weights_only": False, **k}))
+    cams = [_Cam(k, 48, DEVICE) for k in range(4)]
+    _multi_targets(cams, DEVICE)
+    made = {}
+
+    class SyntheticScene:
+        def __init__(self, args, gaussians, *a, **k):
+            self.model_path, self.gaussians, self.cameras_extent = args.model_path, gaussians, 1.0
+            pcds, _ = _multi_point_clouds(MultiMeshPointCloud)
+            gaussians.create_from_pcd(pcds, self.cameras_extent)
+            made["gaussians"] = gaussians
+
+        def getTrainCameras(self, scale=1.0):
+            return cams
+
+        def getTestCameras(self, scale=1.0):
+            return cams[:1]
+
+        def save(self, iteration):
+            self.gaussians.save_ply(os.path.join(self.model_path, f"point_cloud/iteration_{iteration}", "point_cloud.ply"))
+
+    monkeypatch.setattr(train, "Scene", SyntheticScene)
+    monkeypatch.setattr(train, "TENSORBOARD_FOUND", False)
+    monkeypatch.setattr(train, "args", argparse.Namespace(gs_type="gs_multi_mesh"), raising=False)
+    dataset = argparse.Namespace(sh_degree=3, model_path=str(tmp_path / "out"), white_background=True, source_path="", images="images",
+                                 eval=False, gs_type="gs_multi_mesh", num_splats=[2, 3], meshes=["a", "b"])
+    opt = argparse.Namespace(**vars(hip_train.OptimizationParamsMesh(iterations=ITERS, vertices_lr=0.00016)))
+    pipe = types.SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False, antialiasing=False)
+    out = hip_model.install(games)
+    try:
+        random.seed(0); np.random.seed(0); torch.manual_seed(0)
+        ctx = ref_import.cuda_literals_on_cpu() if on_cpu else _null()
+        with ctx:
+            train.training("gs_multi_mesh", dataset, opt, pipe, [ITERS], [ITERS], [], None, -1, False)
+        ref_model = made["gaussians"]
+        assert isinstance(ref_model, hip_model.HipMultiMeshMixin)
+        saved = torch.load(os.path.join(dataset.model_path, f"point_cloud/iteration_{ITERS}", "model_params.pt"))
+        assert [a.shape[1] for a in saved["_alpha"]] == [2, 3] and len(saved["vertices"]) == 2        # the reference's list layout
+        ref_params = {n: [t.detach().clone() for t in getattr(ref_model, n)] for n in ("vertices", "_alpha", "_scale")}
+        ref_params.update({n: [getattr(ref_model, n).detach().clone()] for n in ("_features_dc", "_features_rest", "_opacity")})
+    finally:
+        hip_model.uninstall(games, out)
+        ref_import.drop_reference_stubs()
+
+    _, scenes = _multi_point_clouds(MultiMeshPointCloud)
+    for sc in scenes:
+        P = sc.num_gaussians
+        sc._scale = torch.ones(P, 1); sc._opacity = torch.full((P, 1), inverse_sigmoid(0.1))
+        sc._features_dc = RGB2SH(torch.full((P, 1, 3), 0.5)); sc._features_rest = torch.zeros(P, 15, 3)
+    v1_start = scenes[1].vertices.clone()                 # (from_scenes on CPU aliases the scene's storage)
+    m = hip_model.HipGaussianMultiMeshModel.from_scenes(scenes, DEVICE)
+    m.active_sh_degree = 0
+    m.training_setup(vertices_lr=opt.vertices_lr, alpha_lr=opt.alpha_lr, feature_lr=opt.feature_lr, opacity_lr=opt.opacity_lr,
+                     scaling_lr=opt.scaling_lr, fused=not on_cpu)
+    random.seed(0); np.random.seed(0); torch.manual_seed(0)
+    losses = hip_train.training(m, cams, hip_train.OptimizationParamsMesh(**vars(opt)), PipelineParams(), torch.ones(3, device=DEVICE),
+                                render=hip_render, loss_fn=loss_oracle.l1_ssim_loss if on_cpu else None, report_iterations=[1, ITERS])
+    assert len(losses) == 2 and all(np.isfinite(losses))         # (different cameras at iterations 1 and 14: no ordering claim)
+    for n, wants in ref_params.items():
+        gots = getattr(m, n)
+        gots = list(gots) if isinstance(gots, (list, tuple)) else [gots]
+        assert len(gots) == len(wants), n
+        for got, want in zip(gots, wants):
+            scale = float(want.abs().max()) + 1e-12
+            assert float((got.detach() - want).abs().max()) <= (2e-5 if on_cpu else 2e-3) * scale, n
+    assert float((m.vertices[1].detach().cpu() - v1_start).abs().max()) > 1e-5        # the second mesh's vertices moved too
