@@ -50,7 +50,7 @@ def test_kernel_source_hash_ignores_comments_but_not_code(tmp_path):
 
 def test_committed_pmc_counters_belong_to_the_committed_kernels():
     """profiles/pmc_traffic.json is only reported by bench.py when its `_source_hash` equals the hash of the sources being run
-    (regenerate with tools/r03_final.sh + make_pmc_traffic.py after a kernel change); a stale pair shows up here as a SKIP."""
+    (regenerate with tools/r04_final.sh (collect_profiles.sh + make_pmc_traffic.py) after a kernel change); a stale pair shows up here as a SKIP."""
     import json
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:

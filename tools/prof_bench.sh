@@ -1,4 +1,4 @@
-# kernel-trace profile of bench.py under an environment: bash tools/r04_prof.sh TAG "ENV=..." [bench args]
+# kernel-trace profile of bench.py under an environment: bash tools/prof_bench.sh TAG "ENV=..." [bench args]
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=$1; ENVS=$2; shift 2
 rm -rf /tmp/prof_$TAG; mkdir -p /tmp/prof_$TAG $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
