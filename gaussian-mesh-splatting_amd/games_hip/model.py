@@ -474,6 +474,25 @@ class HipGaussianFlameModel(HipFlameMixin, _StandaloneBase):
         return [self._flame_exp, self._flame_pose, self._flame_trans, self._vertices_enlargement, self._alpha,
                 self._features_dc, self._features_rest, self._opacity, self._scales]
 
+    def training_setup(self, flame_shape_lr=0.01, flame_exp_lr=0.001, flame_pose_lr=0.001, flame_neck_pose_lr=0.001,
+                       flame_trans_lr=0.001, vertices_enlargement_lr=0.0002, alpha_lr=0.001, feature_lr=0.0025, opacity_lr=0.05,
+                       scaling_lr=0.005, fused=True):
+        """Parameter groups of gaussian_flame_model.py:209-228, in its order, with the defaults of `OptimizationParamsFlame`
+        (arguments_games/__init__.py:30-47)."""
+        self._make_optimizer([
+            {"params": [self._flame_shape], "lr": flame_shape_lr, "name": "shape"},
+            {"params": [self._flame_exp], "lr": flame_exp_lr, "name": "expression"},
+            {"params": [self._flame_pose], "lr": flame_pose_lr, "name": "pose"},
+            {"params": [self._flame_neck_pose], "lr": flame_neck_pose_lr, "name": "neck_pose"},
+            {"params": [self._flame_trans], "lr": flame_trans_lr, "name": "transl"},
+            {"params": [self._vertices_enlargement], "lr": vertices_enlargement_lr, "name": "vertices_enlargement"},
+            {"params": [self._alpha], "lr": alpha_lr, "name": "alpha"},
+            {"params": [self._features_dc], "lr": feature_lr, "name": "f_dc"},
+            {"params": [self._features_rest], "lr": feature_lr / 20.0, "name": "f_rest"},
+            {"params": [self._opacity], "lr": opacity_lr, "name": "opacity"},
+            {"params": [self._scales], "lr": scaling_lr, "name": "scaling"},
+        ], fused)
+
     # ---- checkpoints: point_cloud.ply + flame_params.pt (games/flame_splatting/scene/gaussian_flame_model.py:232-265)
     FLAME_ATTRS = ("_flame_shape", "_flame_exp", "_flame_pose", "_flame_neck_pose", "_flame_trans", "_vertices_enlargement",
                    "faces", "alpha", "point_cloud")                 # the reference's `flame_additional_attrs` (:238-244), same order
