@@ -484,7 +484,19 @@ __global__ void __launch_bounds__(WPB * WAVE) blend_bwd_kernel(BlendGrid g, Blen
 
 // ------------------------------------------------------------------------------------ host
 static unsigned long long *g_dbg_buf = nullptr;
-constexpr size_t DBG_BYTES = 4 * 8ull * 65536ull * 8;     // 4 waves x 65536 blocks x {start,end}
+constexpr size_t DBG_BYTES = 4 * 8ull * 65536ull * 8;     // 4 waves x 65536 blocks x 8 words ({start, end} or phase stamps)
+// make EXPERIMENTS=1 builds only: GMS_DBG into g.dbg, and the stamp buffer (cleared) when any of `buf_bits` is set
+void experiment_switches(BlendGrid &g, uint32_t buf_bits, hipStream_t stream)
+{
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("GMS_DBG"); dbg = (GMS_EXPERIMENTS && e) ? atoi(e) : 0; }
+    g.dbg = (uint32_t)dbg;
+    g.dbg_buf = nullptr;
+    if ((uint32_t)dbg & buf_bits) {
+        if (!g_dbg_buf) (void)hipMalloc((void **)&g_dbg_buf, DBG_BYTES);
+        if (g_dbg_buf) { (void)hipMemsetAsync(g_dbg_buf, 0, DBG_BYTES, stream); g.dbg_buf = g_dbg_buf; }
+    }
+}
 int32_t launch_blend_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
     // two-phase transmittance products pay off when tiles are deep on average (> 2 segments per tile over the

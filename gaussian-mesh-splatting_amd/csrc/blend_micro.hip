@@ -384,6 +384,21 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
 }
 
 // ------------------------------------------------------------------------------------ bwd
+// Phase stamps of one wave (make EXPERIMENTS=1, GMS_DBG & 1024; tools/micro_phases.py): wall clock (100 MHz) at
+// start / after the staging / before the walk / after the walk / after the block barrier / at the end, and the wave's trips.
+struct Phases {
+    unsigned long long *buf; bool on;
+    __device__ __forceinline__ Phases(const BlendGrid &g) : buf(nullptr), on(false)
+    {
+        if (dbg_on(g, 1024u) && g.dbg_buf) {
+            buf = g.dbg_buf + 8ull * 65536ull * (threadIdx.x >> 6) + 8ull * (blockIdx.x & 65535u);
+            on = (threadIdx.x & 63) == 0;
+        }
+    }
+    __device__ __forceinline__ void mark(int k) { if (on) buf[k] = wall_clock64(); }
+    __device__ __forceinline__ void value(int k, unsigned long long v) { if (on) buf[k] = v; }
+};
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
 {
@@ -424,11 +439,14 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     __shared__ uint32_t eid_all[4][QSLOTS];            // entry index (within the unit) of every queue slot
     __shared__ float table_all[(DET ? 4 : 1) * LMAX * 10];
     __shared__ UnitShared S;
+    Phases ph(g);
+    ph.mark(0);
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
     for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     unit_setup<false>(g, u, S, a.rec);                  // (its barrier also orders the table clear)
+    ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     float *const table = table_all + (DET ? q * LMAX * 10 : 0);
     SplatRec *recs = recs_all[q];
@@ -455,6 +473,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     top = max(top, (uint32_t)__shfl_xor((int)top, 8)); top = max(top, (uint32_t)__shfl_xor((int)top, 4));
     top = max(top, (uint32_t)__shfl_xor((int)top, 2)); top = max(top, (uint32_t)__shfl_xor((int)top, 1));
     const uint32_t maxtop = max4rows(top);
+    ph.value(6, maxtop);
 
     if (maxtop > 0) {          // (wave-uniform; a wave with nothing to walk goes straight to the flush barrier)
     BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
@@ -507,6 +526,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     queue_clear(recs);
     eid[lane] = 0u;
     if (lane < QSLOTS - WAVE) eid[WAVE + lane] = 0u;
+    ph.mark(2);
 
     // back to front: global trip t0 handles entry top - 1 - t0 of every row's list (the rows are aligned at their tops)
     for (uint32_t g0 = 0; g0 < maxtop; g0 += 16) {
@@ -554,7 +574,9 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         }
     }
     }
+    ph.mark(3);
     __syncthreads();
+    ph.mark(4);
     // flush: sixteen entries per step, ten lanes per entry on the ten fields of its 64-byte record (one cache line)
     {
         const int f = threadIdx.x & 15;
@@ -566,14 +588,390 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
                 a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] = y;
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];
-                if (FAULT == 9) { if (y == 123.456f) a.accum[0] = y; }                  // (timing experiment: no global atomics)
-                else if (y != 0.f) unsafeAtomicAdd(a.accum + (size_t)S.uid[e] * GRAD_STRIDE + f, y);
+                if (y != 0.f) unsafeAtomicAdd(a.accum + (size_t)S.uid[e] * GRAD_STRIDE + f, y);
             }
         }
     }
+    ph.mark(5);
+}
+
+// ==================================================================================== resident-unit kernels (round 5)
+// The same micro-tile scheme with the unit's splat records RESIDENT in LDS.  The queue kernels above re-gather a record from
+// L2 once per 4x4 block that lists it (2.15 gathers per instance) through a dependent chain -- list byte (global) -> Gaussian id
+// (LDS) -> 48-byte record (global) -> LDS queue, two wave_syncs -- every 16 trips of every row.  Here the block's 256 threads
+// gather the unit's <= 256 records ONCE, coalesced by entry, into LDS (40 bytes each: the extents are only needed by the
+// filter), the sixteen byte lists are rebuilt in LDS from a 16-bit block mask per instance (computed by the launch that first
+// touches the unit, 2 bytes per instance in global memory instead of the 16-byte-per-instance list area), and a row's trip reads
+// `list[block][pos]` -> `record[entry]` straight from LDS: no queue, no refill, no global access inside the walks.
+struct UnitRecs {
+    float4 ra[LMAX];           // pix.x, pix.y, conic A, conic B
+    float4 rb[LMAX];           // conic C, opacity', r, g
+    float2 rc[LMAX];           // b, 1/depth
+    uint8_t list[16][LMAX];    // per 4x4 block: the entries that reach it, in list (depth) order
+    uint32_t order[16], ocnt[16];
+    uint32_t wcnt[4][16];
+};
+
+template <int NE> __device__ __forceinline__ uint32_t list_load(const uint8_t *lst, uint32_t pos);
+template <> __device__ __forceinline__ uint32_t list_load<1>(const uint8_t *lst, uint32_t pos) { return lst[pos]; }
+template <> __device__ __forceinline__ uint32_t list_load<2>(const uint8_t *lst, uint32_t pos) { return *reinterpret_cast<const uint16_t *>(lst + pos); }
+template <> __device__ __forceinline__ uint32_t list_load<4>(const uint8_t *lst, uint32_t pos) { return *reinterpret_cast<const uint32_t *>(lst + pos); }
+
+// Staging.  FILTER = this launch is the first to touch the unit: the thread of an entry computes the entry's block mask from the
+// record it has just gathered and leaves it in global memory (g.mlist as uint16[instances]) for the later launches, which read
+// it back instead -- every launch therefore builds IDENTICAL lists (n_contrib holds positions in them).
+template <bool FILTER>
+__device__ __forceinline__ void unit_stage(const BlendGrid &g, const Unit &u, UnitRecs &S, const SplatRec *rec, uint32_t *uid)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t cn = u.end - u.beg;
+    uint16_t *mm = reinterpret_cast<uint16_t *>(g.mlist);
+    uint32_t mask = 0;
+    if ((uint32_t)tid < cn) {
+        const uint32_t id = reinterpret_cast<const uint32_t *>(g.keys)[2 * (size_t)(u.beg + tid)];      // low word of the (depth, id) key
+        if (!FILTER) mask = mm[u.beg + tid];
+        const SplatRec r = rec[id];
+        if (FILTER) { mask = block_mask(r, (float)(u.tx * TILE), (float)(u.ty * TILE)); mm[u.beg + tid] = (uint16_t)mask; }
+        S.ra[tid] = r.q0; S.rb[tid] = r.q1; S.rc[tid] = make_float2(r.q2.x, r.q2.y);
+        if (uid) uid[tid] = id;
+    } else {
+        // a row that idles behind the end of its list reads whatever byte lies there: every record it can name must be finite
+        S.ra[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rb[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rc[tid] = make_float2(0.f, 0.f);
+    }
+    uint32_t mycnt = 0;                        // lane b < 16: hits of block b among this wave's 64 entries
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((mask >> b) & 1u));
+        if (lane == b) mycnt = n;
+    }
+    if (lane < 16) S.wcnt[wave][lane] = mycnt;
+    __syncthreads();
+    const uint64_t lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        const uint64_t bal = __ballot((mask >> b) & 1u);
+        if ((mask >> b) & 1u) {
+            uint32_t base = 0;
+            for (int w = 0; w < wave; w++) base += S.wcnt[w][b];
+            S.list[b][base + (uint32_t)__builtin_popcountll(bal & lt)] = (uint8_t)tid;
+        }
+    }
+    if (tid < 16) {
+        const uint32_t c = S.wcnt[0][tid] + S.wcnt[1][tid] + S.wcnt[2][tid] + S.wcnt[3][tid];
+        uint32_t rank = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0++) {
+            const uint32_t cs = (uint32_t)__shfl((int)c, s0);
+            rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
+        }
+        S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
+    }
+    __syncthreads();
+}
+
+template <int NE>
+__device__ __forceinline__ void ru_tloc_unit(const BlendGrid &g, const Unit &u, const UnitRecs &S, int phase, int q)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
+    float *dst = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *lst = S.list[p.b];
+    const uint32_t maxcnt = max4rows(cnt);
+    float Tl = 1.f;
+    (void)phase;
+    for (uint32_t t = 0; t < maxcnt; t += NE) {
+        // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
+        if (__all(Tl < T_MIN || !p.inside || t >= cnt)) break;
+        const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
+        float al[NE], pw[NE]; bool val[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const uint32_t ent = (ep >> (8 * e)) & 0xffu;
+            const float4 r0 = S.ra[ent];
+            const float2 r1 = *reinterpret_cast<const float2 *>(&S.rb[ent]);
+            const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+            val[e] = t + e < cnt;
+            pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
+            al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < NE; e++)
+            if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
+    }
+    *dst = Tl;
+}
+
+template <int NE>
+__device__ __forceinline__ void ru_fwd_unit(const BlendGrid &g, const BlendFwdOut &o, const Unit &u, const UnitRecs &S, int q)
+{
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *lst = S.list[p.b];
+    const uint32_t maxcnt = max4rows(cnt);
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
+
+    float T = 1.f;
+    {
+        // prefix product of the segments in front, four independent loads per step (same left-to-right order)
+        const float *tl = g.seg_state + (size_t)u.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
+        int k = 0;
+        for (; k + 4 <= u.seg; k += 4) {
+            const float t0 = tl[(size_t)k * SEG_FLOATS], t1 = tl[(size_t)(k + 1) * SEG_FLOATS];
+            const float t2 = tl[(size_t)(k + 2) * SEG_FLOATS], t3 = tl[(size_t)(k + 3) * SEG_FLOATS];
+            T = T * t0 * t1 * t2 * t3;
+        }
+        for (; k < u.seg; k++) T *= tl[(size_t)k * SEG_FLOATS];
+    }
+    const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !p.inside || dead_on_entry;
+
+    for (uint32_t t = 0; t < maxcnt; t += NE) {
+        if (__all(done || t >= cnt)) break;
+        // NE entries of every row per trip: independent alpha evaluations, sequential compositing
+        const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
+        float al[NE], pw[NE]; bool val[NE]; float2 cg[NE], cb[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const uint32_t ent = (ep >> (8 * e)) & 0xffu;
+            const float4 r0 = S.ra[ent], r1 = S.rb[ent];
+            cb[e] = S.rc[ent];
+            cg[e] = make_float2(r1.z, r1.w);
+            const float dx = r0.x - p.xf, dy = r0.y - p.yf;
+            val[e] = t + e < cnt;
+            pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
+            al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
+            const float testT = T * (1.f - al[e]);
+            if (act && testT < T_MIN) { done = true; act = false; }
+            if (act) {
+                const float w = al[e] * T;
+                C0 += cg[e].x * w; C1 += cg[e].y * w; C2 += cb[e].x * w;
+                Dp += cb[e].y * w;
+                T = testT;
+                last = posbase + t + (uint32_t)e + 1u;
+            }
+        }
+    }
+    if (u.nseg == 1) {
+        if (p.inside) {
+            const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
+            o.final_T[pid] = T;
+            o.n_contrib[pid] = last;
+            o.out_color[pid] = C0 + T * o.bg[0];
+            o.out_color[HW + pid] = C1 + T * o.bg[1];
+            o.out_color[2 * HW + pid] = C2 + T * o.bg[2];
+            o.out_invdepth[pid] = Dp;
+        }
+    } else {
+        float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        st[SEG_C0 * TILE_PIX + p.tid] = C0; st[SEG_C1 * TILE_PIX + p.tid] = C1; st[SEG_C2 * TILE_PIX + p.tid] = C2;
+        st[SEG_D * TILE_PIX + p.tid] = Dp;
+        st[SEG_TEND * TILE_PIX + p.tid] = dead_on_entry ? -1.f : T;
+        st[SEG_LAST * TILE_PIX + p.tid] = __uint_as_float(last);
+        // the first segment's exact walk doubles as its transmittance product (see blend.hip)
+        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + p.tid] = done ? 0.f : T;
+    }
+}
+
+template <int NE>
+__global__ void __launch_bounds__(BLOCK) ru_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
+{
+    __shared__ UnitRecs S;
+    Unit u;
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
+    const bool walk = u.seg == 0 ? phase <= 0
+                                 : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
+    if (!walk) return;
+    if (u.seg > 0 && phase == 1 && g.tile_dead[u.tile]) {          // products of a dead tile: nothing to walk, empty lists on record
+        if (threadIdx.x < u.end - u.beg) reinterpret_cast<uint16_t *>(g.mlist)[u.beg + threadIdx.x] = 0;
+        g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + threadIdx.x] = 0.f;
+        return;
+    }
+    unit_stage<true>(g, u, S, o.rec, nullptr);
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
+    if (u.seg == 0) ru_fwd_unit<NE>(g, o, u, S, q);
+    else ru_tloc_unit<NE>(g, u, S, phase, q);
+}
+
+template <int NE>
+__global__ void __launch_bounds__(BLOCK) ru_fwd_kernel(BlendGrid g, BlendFwdOut o)
+{
+    __shared__ UnitRecs S;
+    Unit u;
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
+    if (u.seg == 0) return;
+    if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, nullptr);       // last segments are first touched here
+    else unit_stage<false>(g, u, S, o.rec, nullptr);                          // middle segments: filtered by the first launch
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
+    ru_fwd_unit<NE>(g, o, u, S, q);
+}
+
+// Backward.  The rows of a wave are aligned at the BOTTOM of their lists: global trip position `pos` is the same list index
+// for every row (rows whose list ends below it idle), so a trip's entry bytes are one aligned LDS read per NE entries.
+template <bool INVD, int NE, int FAULT, bool DET = false>
+__global__ void __launch_bounds__(BLOCK) ru_bwd_kernel(BlendGrid g, BlendBwdArgs a)
+{
+    __shared__ UnitRecs S;
+    __shared__ uint32_t uid[LMAX];
+    __shared__ float table_all[(DET ? 4 : 1) * LMAX * 10];
+    Phases ph(g);
+    ph.mark(0);
+    Unit u;
+    if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
+    if (u.end <= u.beg) return;
+    for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
+    unit_stage<false>(g, u, S, a.rec, uid);                  // (its barriers also order the table clear)
+    ph.mark(1);
+    const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
+    float *const table = table_all + (DET ? q * LMAX * 10 : 0);
+    const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
+    const size_t HW = (size_t)g.W * g.H;
+    const size_t pid = (size_t)p.yi * g.W + p.xi;
+    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
+    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
+    if (p.inside) {
+        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
+        if (INVD) dinvd = a.dL_dinvd[pid];
+    }
+    const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
+    const uint32_t posbase = (uint32_t)u.seg * u.L;
+    const uint32_t cn = u.end - u.beg;
+    const uint32_t cnt = S.ocnt[4 * q + row];
+    const uint8_t *lst = S.list[p.b];
+    // entries [0, lrel) of this block's list of this segment were composited by this pixel
+    const uint32_t lrel = last > posbase ? min(last - posbase, cnt) : 0u;
+    uint32_t top = lrel;                                    // furthest entry any pixel of the wave composited
+    top = max(top, (uint32_t)__shfl_xor((int)top, 8)); top = max(top, (uint32_t)__shfl_xor((int)top, 4));
+    top = max(top, (uint32_t)__shfl_xor((int)top, 2)); top = max(top, (uint32_t)__shfl_xor((int)top, 1));
+    const uint32_t maxtop = max4rows(top);
+    ph.value(6, maxtop);
+
+    if (maxtop > 0) {          // (wave-uniform; a wave with nothing to walk goes straight to the flush barrier)
+    BwdState st8 = {Tfinal, 0.f, 0.f, 0.f, 0.f};
+    if (u.nseg > 1) {
+        const float *st = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS;
+        const float te = st[SEG_TEND * TILE_PIX + p.tid];
+        if (te > 0.f) {
+            // restart of the recurrence at the segment boundary: T after this segment's last applied splat and the colour
+            // composited behind it (sum of the live partials of the later segments) divided by that T
+            st8.T = te;
+            float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
+            bool stop = false;
+            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += 4) {
+                float tk[4], c0[4], c1[4], c2[4], dd[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float *sk = g.seg_state + (size_t)(u.slot0 + min(k0 + j, u.nseg - 1)) * SEG_FLOATS;
+                    tk[j] = sk[SEG_TEND * TILE_PIX + p.tid]; c0[j] = sk[SEG_C0 * TILE_PIX + p.tid];
+                    c1[j] = sk[SEG_C1 * TILE_PIX + p.tid]; c2[j] = sk[SEG_C2 * TILE_PIX + p.tid];
+                    dd[j] = INVD ? sk[SEG_D * TILE_PIX + p.tid] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (k0 + j >= u.nseg || tk[j] < 0.f) stop = true;
+                    if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
+                }
+                if (__all(stop)) break;
+            }
+            const float inv = FAULT == 2 ? 0.f : 1.f / te;
+            st8.acc0 = S0 * inv; st8.acc1 = S1 * inv; st8.acc2 = S2 * inv; st8.accd = SD * inv;
+        }
+    }
+    ph.mark(2);
+
+    // lane -> field of the 64-byte gradient record (the layout row_reduce10 leaves)
+    const bool b3 = (li & 8) != 0, b2 = (li & 4) != 0, b1 = (li & 2) != 0, b0 = (li & 1) != 0;
+    int afield;
+    switch (li) {
+    case 0: afield = GRAD_MX; break;
+    case 8: afield = GRAD_OP; break;
+    case 4: afield = GRAD_CB; break;
+    case 12: afield = GRAD_B; break;
+    case 2: afield = GRAD_MY; break;
+    case 10: afield = GRAD_R; break;
+    case 6: afield = GRAD_CC; break;
+    case 14: afield = GRAD_ID; break;
+    case 1: afield = GRAD_CA; break;
+    default: afield = GRAD_G; break;       // lane 9
+    }
+    const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
+
+    // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
+    for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
+        const uint32_t ep = list_load<NE>(lst, (uint32_t)g0);
+        bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE]; float2 r2[NE]; uint32_t se[NE];
+        bool anyact = false;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            const uint32_t pos = (uint32_t)g0 + (uint32_t)(NE - 1 - e);          // descending within the trip
+            se[e] = (ep >> (8 * (NE - 1 - e))) & 0xffu;
+            const float4 r0 = S.ra[se[e]];
+            r1[e] = S.rb[se[e]]; r2[e] = S.rc[se[e]];
+            dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
+            const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
+            G[e] = __expf(pw);
+            al[e] = fminf(ALPHA_MAX, r1[e].y * G[e]);
+            // composited by this pixel iff it lies below lrel (lrel <= the length of the row's list)
+            act[e] = pos < lrel && pw <= 0.f && al[e] >= ALPHA_MIN;
+            anyact = anyact || act[e];
+        }
+        if (!__any(anyact)) continue;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            float v[10];
+            const float4 q2 = make_float4(r2[e].x, r2[e].y, 0.f, 0.f);
+            bwd_step<INVD>(st8, act[e], r1[e], q2, dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
+            const float y = row_reduce10(v, b3, b2, b1, b0);
+            // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
+            if (DET) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (row == r && alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
+                    asm volatile("" ::: "memory");          // four separate LDS instructions, in row order
+                }
+            } else if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
+        }
+    }
+    }
+    ph.mark(3);
+    __syncthreads();
+    ph.mark(4);
+    // flush: sixteen entries per step, ten lanes per entry on the ten fields of its 64-byte record (one cache line)
+    {
+        const int f = threadIdx.x & 15;
+        for (uint32_t e = threadIdx.x >> 4; e < cn; e += BLOCK / 16) {
+            if (DET) {
+                // every instance of the unit gets its record (zeros included: the buffer is not cleared between frames)
+                const uint32_t k = e * 10u + (uint32_t)f;
+                const float y = f < 10 ? ((table_all[k] + table_all[LMAX * 10 + k]) + table_all[2 * LMAX * 10 + k]) + table_all[3 * LMAX * 10 + k] : 0.f;
+                a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] = y;
+            } else if (f < 10) {
+                const float y = table[e * 10u + (uint32_t)f];
+                if (y != 0.f) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, y);
+            }
+        }
+    }
+    ph.mark(5);
 }
 
 // ------------------------------------------------------------------------------------ host
+// GMS_MICRO_RU: 1 (default) = the resident-unit kernels, 0 = the row-queue kernels
+static bool resident_units()
+{
+    static int ru = -1;
+    if (ru < 0) { const char *e = getenv("GMS_MICRO_RU"); ru = e ? (atoi(e) != 0) : 1; }
+    return ru != 0;
+}
+
 int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
     static int deep_env = -2;
@@ -582,8 +980,11 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP"); trip = e ? atoi(e) : 4; }      // (forward: 4 entries per trip; 2: -1.3 % it/s)
-    auto head = trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>);
-    auto fwd2 = trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>);
+    const bool ru = resident_units();
+    auto head = ru ? (trip == 4 ? ru_head_kernel<4> : (trip == 1 ? ru_head_kernel<1> : ru_head_kernel<2>))
+                   : (trip == 4 ? micro_head_kernel<4> : (trip == 1 ? micro_head_kernel<1> : micro_head_kernel<2>));
+    auto fwd2 = ru ? (trip == 4 ? ru_fwd_kernel<4> : (trip == 1 ? ru_fwd_kernel<1> : ru_fwd_kernel<2>))
+                   : (trip == 4 ? micro_fwd_kernel<4> : (trip == 1 ? micro_fwd_kernel<1> : micro_fwd_kernel<2>));
     if (deep) {     // deep scene: head segments, tile-dead check, then the tail segments of the tiles still alive
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, head<<<blocks, BLOCK, 0, stream>>>(g, o, 0));
         GMS_LAUNCH(GMS_K_BLEND_HEAD, stream, micro_tloc_check_kernel<<<(unsigned)g.T, BLOCK, 0, stream>>>(g));
@@ -599,19 +1000,31 @@ int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t 
     return GMS_OK;
 }
 
-int32_t launch_micro_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    BlendGrid g = g_in;
+    experiment_switches(g, 1024u, stream);          // (make EXPERIMENTS=1 only: GMS_DBG & 1024 = per-wave phase stamps)
     const unsigned blocks = blend_grid_units(max_units);
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
+    const bool ru = resident_units();
     if (a.part) {                           // deterministic mode (gmsplat.h): per-wave tables, ordered adds, per-instance partial records
-        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
-        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        if (ru) {
+            if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (ru_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+            else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (ru_bwd_kernel<false, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        } else {
+            if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+            else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        }
     } else if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
-    } else if (fault_mode() == 9 && !invd) {      // timing experiment (wrong results): no atomics
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 9><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        if (ru) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (ru_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
+    } else if (ru) {
+        auto kern = trip == 1 ? (invd ? ru_bwd_kernel<true, 1, 0> : ru_bwd_kernel<false, 1, 0>)
+                  : trip == 4 ? (invd ? ru_bwd_kernel<true, 4, 0> : ru_bwd_kernel<false, 4, 0>)
+                              : (invd ? ru_bwd_kernel<true, 2, 0> : ru_bwd_kernel<false, 2, 0>);
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)

@@ -312,6 +312,7 @@ struct Stamp {
 // units covered by the grid the blend launches use for `max_units` (the XCD run mapping pads to 8 * UNIT_RUN_MAX blocks)
 inline uint32_t blend_grid_units(uint32_t max_units) { return 8u * UNIT_RUN_MAX * ((max_units + 8u * UNIT_RUN_MAX - 1u) / (8u * UNIT_RUN_MAX)); }
 
+void experiment_switches(BlendGrid &g, uint32_t buf_bits, hipStream_t stream);     // blend.hip; a no-op outside make EXPERIMENTS=1
 int32_t launch_blend_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream);
 int32_t launch_blend_backward(const BlendGrid &g, const BlendBwdArgs &a, uint32_t max_units, bool debug, hipStream_t stream);
 int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream);
