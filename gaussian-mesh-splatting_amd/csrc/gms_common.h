@@ -349,6 +349,8 @@ int fault_mode();
 // Deterministic-reduction mode (gmsplat.h, gms_set_deterministic / env GAMES_HIP_DETERMINISTIC=1): every floating-point sum
 // of the backward passes runs in a fixed order -- no float atomics anywhere -- so two runs give bit-identical gradients.
 int det_mode();
+// upstream-quirk switch (gmsplat.h, gms_set_upstream_scale_mod_grad / env GMS_UPSTREAM_SCALE_MOD_GRAD=1): dL/dscale without the scale_modifier factor
+int upstream_scale_mod_grad();
 // library-owned device scratch of the deterministic mode, one growing buffer per (device, stream, slot); nullptr on failure
 void *det_scratch(int slot, size_t bytes, hipStream_t stream);
 

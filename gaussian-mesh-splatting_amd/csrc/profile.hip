@@ -73,14 +73,26 @@ int det_mode()
     return g_det;
 }
 
+// ---- upstream-quirk switch (gmsplat.h)
+static int g_scale_mod_quirk = -1;          // -1: not yet read from the environment
+int upstream_scale_mod_grad()
+{
+    if (g_scale_mod_quirk < 0) { const char *e = getenv("GMS_UPSTREAM_SCALE_MOD_GRAD"); g_scale_mod_quirk = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_scale_mod_quirk;
+}
+
 namespace {
 struct DetBuf { int device; hipStream_t stream; int slot; void *p; size_t cap; };
 std::mutex g_det_mu;
 std::vector<DetBuf> g_det_bufs;
 }  // namespace
 
+// (Buffers are keyed by (device, stream, slot), not by host thread, and live until the process ends: two host threads that drive
+// the deterministic mode on ONE stream share them -- as they share the stream's order, which already serialises their kernels.
+// A request of 0 bytes -- an empty mesh, no instances -- gets a valid minimal buffer, not nullptr.)
 void *det_scratch(int slot, size_t bytes, hipStream_t stream)
 {
+    if (bytes == 0) bytes = 256;
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(g_det_mu);
@@ -180,5 +192,7 @@ extern "C" const char *gms_profile_kernel_name(int32_t kid)
 
 extern "C" void gms_set_deterministic(int32_t on) { gms::g_det = on ? 1 : 0; }
 extern "C" int32_t gms_get_deterministic(void) { return gms::det_mode(); }
-extern "C" void gms_set_fault(int32_t fault) { gms::g_fault = fault > 0 ? fault : 0; }
+extern "C" void gms_set_fault(int32_t fault) { gms::g_fault = (fault >= 1 && fault <= 5) ? fault : 0; }      // the five documented defects, nothing else
 extern "C" int32_t gms_get_fault(void) { return gms::fault_mode(); }
+extern "C" void gms_set_upstream_scale_mod_grad(int32_t on) { gms::g_scale_mod_quirk = on ? 1 : 0; }
+extern "C" int32_t gms_get_upstream_scale_mod_grad(void) { return gms::upstream_scale_mod_grad(); }

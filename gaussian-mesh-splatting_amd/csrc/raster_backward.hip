@@ -29,6 +29,7 @@ struct PreBwdArgs {
     int P, D, M, W, H;
     const float *means3D, *shs, *shs_rest, *colors, *opac, *scales, *rots, *cov3Dp, *view, *proj, *campos;
     float mod, tanx, tany;
+    float scale_grad_mod;   // factor of dL/dscale: `mod` (the derivative of cov3D = R diag(mod s)^2 R^T), or 1 under the upstream-quirk switch
     int aa;
     const int *radii;
     const uint8_t *clamped;
@@ -319,7 +320,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
                     accs += R[a1][j] * dLm;
                     dR[a1][j] = dLm * s[j];
                 }
-                dscale[j] = accs * mod;
+                dscale[j] = accs * a.scale_grad_mod;
             }
             drot[0] = 2.f * (-z * dR[0][1] + y * dR[0][2] + z * dR[1][0] - x * dR[1][2] - y * dR[2][0] + x * dR[2][1]);
             drot[1] = 2.f * (y * dR[0][1] + z * dR[0][2] + y * dR[1][0] - 2.f * x * dR[1][1] - r * dR[1][2] + z * dR[2][0] + r * dR[2][1] - 2.f * x * dR[2][2]);
@@ -583,7 +584,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;
     p.means3D = A->means3D; p.shs = A->shs; p.shs_rest = A->shs_rest; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
-    p.mod = A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
+    p.mod = A->scale_modifier; p.scale_grad_mod = upstream_scale_mod_grad() ? 1.f : A->scale_modifier; p.tanx = A->tan_fovx; p.tany = A->tan_fovy; p.aa = A->antialiasing; p.radii = A->radii;
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = fault_mode() == 3 ? 0 : A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
     p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = (A->shs && A->sh_factor_mode) ? A->dL_dcolors : nullptr; p.campos_row = A->factor_campos_row; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;

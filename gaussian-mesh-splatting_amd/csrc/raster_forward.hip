@@ -125,11 +125,18 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
 // coefficient reads that only the compositing needs: runs on a second stream beside scan / emit / sort / filter).  The two
 // write disjoint bytes of the 48-byte record.
 // (cull_extents -- the noise-aware half extents stored in record words 10, 11 -- lives in gms_blend.h)
-template <int SHDEG, bool SPLIT, int MODE = 0>
+// DMA (round 5; split storage, degree 3, MODE 0): the wave's coefficient block goes global -> LDS with `global_load_lds_dwordx4`
+// (1 KiB per wave instruction, no staging VGPRs, no ds_write pass).  The LDS destination of that instruction is lane-linear, and
+// so is the source here: the 64 rows of `_features_rest` a wave owns are 11 520 contiguous, 16-byte aligned bytes, copied as they
+// lie (row pitch 45 dwords: odd, so the per-lane ds_read_b32 of a row are conflict-free), the 768 bytes of `_features_dc` behind
+// them.  Before, the same block went through 12 float4 registers per lane and 48 scalar ds_write_b32 with a division by 45 each.
+template <int SHDEG, bool SPLIT, int MODE = 0, bool DMA = false>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float sh_lds[MODE == 1 ? 2 * TT_SLOTS : 4 * WAVE * SH_PITCH];
+    static_assert(!DMA || (SHDEG == 3 && SPLIT && MODE == 0), "the LDS-DMA staging exists for split degree-3 storage");
+    constexpr int DMA_WAVE_FLOATS = WAVE * 48;        // 64 x 45 REST floats, then 64 x 3 DC floats
+    __shared__ __attribute__((aligned(16))) float sh_lds[MODE == 1 ? 2 * TT_SLOTS : (DMA ? 4 * DMA_WAVE_FLOATS : 4 * WAVE * SH_PITCH)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * BLOCK + tid;
     const bool valid = i < a.P;
@@ -150,6 +157,21 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         const int g0 = blockIdx.x * BLOCK + wave * WAVE;
         const int rows = min(WAVE, a.P - g0);
         if (MODE == 1) {
+        } else if (DMA) {
+            float *wl = sh_lds + wave * DMA_WAVE_FLOATS;
+            const float *sp = a.shs_rest + (size_t)g0 * RESTF;       // g0 % 64 == 0: 16-byte aligned
+            const int nfl = rows * RESTF;
+#pragma unroll
+            for (int j = 0; j < NQ; j++) {
+                const int e4 = (lane + WAVE * j) * 4;                // (a chunk that straddles the end of the array is copied below)
+                if (e4 + 3 < nfl)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + e4),
+                                                     (__attribute__((address_space(3))) void *)(wl + WAVE * 4 * j), 16, 0, 0);
+            }
+            const float *dp = a.shs + (size_t)g0 * 3;
+            if (lane * 4 + 3 < rows * 3)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dp + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)(wl + WAVE * RESTF), 16, 0, 0);
         } else if (!SPLIT) {
             const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
 #pragma unroll
@@ -243,6 +265,33 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     float rgb[3] = {0, 0, 0};
     unsigned clampbits = 0;
     if (MODE == 1) {
+    } else if (DMA) {
+        float *wl = sh_lds + wave * DMA_WAVE_FLOATS;
+        const int g0 = blockIdx.x * BLOCK + wave * WAVE;
+        const int rows = max(0, min(WAVE, a.P - g0));          // (the last block's later waves may own no row at all)
+        if (rows < WAVE) {          // last wave of the array: the (at most one) 16-byte chunk of each block that straddles its end
+            const int nfl = rows * RESTF, nd = rows * 3;
+            for (int e = (nfl & ~3) + lane; e < nfl; e += WAVE) wl[e] = a.shs_rest[(size_t)g0 * RESTF + e];
+            for (int e = (nd & ~3) + lane; e < nd; e += WAVE) wl[WAVE * RESTF + e] = a.shs[(size_t)g0 * 3 + e];
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the LDS-DMA copies have landed
+        wave_sync();                               // the rows are this wave's own
+        if (vis) {
+            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            float r[48];
+#pragma unroll
+            for (int c = 0; c < 3; c++) r[c] = wl[WAVE * RESTF + lane * 3 + c];
+#pragma unroll
+            for (int m = 0; m < RESTF; m++) r[3 + m] = wl[lane * RESTF + m];
+            const float x = dx * inv, y = dy * inv, z = dz * inv;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                float v = sh_eval_channel<3>(r, c, x, y, z) + 0.5f;
+                if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
+                rgb[c] = v;
+            }
+        }
     } else if (SHDEG >= 0) {
         float *wl = sh_lds + wave * (WAVE * SH_PITCH);
         if (!SPLIT) {
@@ -1347,6 +1396,8 @@ extern "C" size_t gms_image_counts_offset(int32_t w, int32_t h)
 }
 static thread_local int64_t t_last_launched_units = 0;
 extern "C" int64_t gms_last_launched_units(void) { return t_last_launched_units; }
+static thread_local int32_t t_last_used_micro = 0;
+extern "C" int32_t gms_last_used_micro(void) { return t_last_used_micro; }
 extern "C" size_t gms_binning_bytes(int64_t n, int32_t w, int32_t h)
 {
     const size_t T = (size_t)((w + TILE - 1) / TILE) * (size_t)((h + TILE - 1) / TILE);
@@ -1475,6 +1526,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
             t_aux.push_back(x); aux = &t_aux.back();
         }
     }
+    static int pre_dma = -1;          // GMS_PRE_DMA=0: the register-staged SH rows instead of LDS-DMA (split degree-3 storage)
+    if (pre_dma < 0) { const char *e = getenv("GMS_PRE_DMA"); pre_dma = e ? (atoi(e) != 0) : 1; }
 #define GMS_PRE_M(DEG, SP, MODE, STR) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, STR, (preprocess_fwd_kernel<DEG, SP, MODE><<<pblocks, BLOCK, 0, STR>>>(pa)))
 #define GMS_PRE(DEG, SP)                                                              \
     do {                                                                              \
@@ -1496,7 +1549,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     case 4: GMS_PRE(2, false); break;
     case 5: GMS_PRE(2, true); break;
     case 6: GMS_PRE(3, false); break;
-    case 7: GMS_PRE(3, true); break;
+    case 7:
+        if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        else GMS_PRE(3, true);
+        break;
     default: GMS_PRE_M(-1, false, 0, stream); break;
     }
 #undef GMS_PRE
@@ -1505,6 +1561,9 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const uint32_t L = seg_len_min();         // sizes and carving; the frame's own L is chosen by the scan (scan_out[3])
     int32_t *slot = pinned_slot();
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
+    // The launches-only form never reads the slot: its launches publish nothing, so a captured graph does not hold this thread's
+    // slot and a stale sequence number (a replay would otherwise overwrite a count an eager call on another stream has just received).
+    int32_t *const pub_slot = A->no_host_wait ? nullptr : slot;
     // merge-path passes for tiles deeper than SORT_BIG_CHUNK keys: as many as the deepest tile of the previous frame
     // (+25 %) needs; a deeper tile than that falls back to the one-block sort and raises the count for the next frame
     int sort_np = 0;
@@ -1515,7 +1574,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     if (!inline_scan) {
         GMS_LAUNCH(GMS_K_TILE_SCAN, stream, tile_scan_kernel<<<1, SCAN_THREADS, 0, stream>>>(img.tile_count, img.tile_offset, img.tile_cursor,
                                                                                        img.unit_first, img.mseg_first, img.class_first, T, frame_L,
-                                                                                       slot, seq, sort_np, img.scan_out));
+                                                                                       pub_slot, seq, sort_np, img.scan_out));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_scan");
         ctr->dirty = false;
     }
@@ -1548,7 +1607,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (inl)
             GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<true><<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                                                  img.tile_cursor, bin.keys, capacity, pblocks, fu,
-                                                                                                                 slot, seq, img.scan_out, isa));
+                                                                                                                 pub_slot, seq, img.scan_out, isa));
         else
             GMS_LAUNCH(GMS_K_EMIT, stream, emit_instances_kernel<false><<<pblocks + fblocks, BLOCK, 0, stream>>>(P, gx, gy, A->radii, geom, img.tile_offset,
                                                                                                                   img.tile_cursor, bin.keys, capacity, pblocks, fu,
@@ -1581,6 +1640,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
         g.mlist = bin.mlist; g.mcount = bin.mcount;
         if (aux) GMS_HIP_CHECK(hipStreamWaitEvent(stream, aux->join, 0));      // the colours (second stream) before the compositing
+        t_last_used_micro = use_micro(capacity, T) ? 1 : 0;
         if (use_micro(capacity, T)) {
             // the micro-tile kernels index a unit's entries with one byte: never launch them on a frame whose L they cannot hold
             if (frame_L == 0 || frame_L > SEG_LEN_MICRO) {

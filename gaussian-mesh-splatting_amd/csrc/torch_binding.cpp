@@ -436,6 +436,7 @@ py::dict last_stats()
     py::dict d;
     d["num_rendered"] = g_last.num_rendered; d["num_units"] = g_last.num_units; d["capacity_hint"] = g_last.hint;
     d["P"] = g_last.P; d["width"] = g_last.W; d["height"] = g_last.H; d["deepest_tile"] = gms_last_deepest_tile();
+    d["used_micro"] = (int)gms_last_used_micro();
     if (g_last.radii.defined()) { d["radii"] = g_last.radii; d["image"] = g_last.image; d["binning"] = g_last.binning; d["geom"] = g_last.geom; }
     return d;
 }

@@ -125,6 +125,13 @@ def clear_capacity_hints() -> None:
     _capacity_cache.clear()
 
 
+def set_upstream_scale_mod_grad(on: bool) -> None:
+    """Upstream-quirk switch (include/gmsplat.h): with it on, dL/dscale comes back WITHOUT the scale_modifier factor -- what the
+    public upstream CUDA backward is believed to return (unverifiable here: the submodule is absent).  Inert at scale_modifier = 1.0,
+    which is what every render() of the reference passes.  Also: GMS_UPSTREAM_SCALE_MOD_GRAD=1 in the environment."""
+    _lib.load().gms_set_upstream_scale_mod_grad(1 if on else 0)
+
+
 def set_deterministic(on: bool) -> None:
     """Deterministic-reduction mode (include/gmsplat.h, gms_set_deterministic): the backward passes of the rasterizer and of the
     mesh op sum in a fixed order with no float atomics -- two runs on the same inputs give bit-identical gradients.  Slower;
@@ -211,8 +218,7 @@ def last_stats() -> dict:
         # several times smaller and NOT comparable with the figure above or with earlier rounds (`interactions_kind` says which).
         off = int(_lib.load().gms_image_n_contrib_offset(d["width"], d["height"]))
         d["interactions"] = int(image[off:off + 4 * d["width"] * d["height"]].view(torch.int32).sum(dtype=torch.int64))
-        T = ((d["width"] + 15) // 16) * ((d["height"] + 15) // 16)
-        micro = os.environ.get("GMS_MICRO", "") != "0" and (os.environ.get("GMS_MICRO", "") == "1" or max(d.get("capacity_hint", 0), d.get("num_rendered", 0)) <= 512 * T)
+        micro = bool(d.get("used_micro", int(_lib.load().gms_last_used_micro())))      # the library's own decision for that frame
         d["interactions_kind"] = "micro_tile_block_list_positions" if micro else "tile_list_positions"
     return d
 
@@ -380,7 +386,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(num_rendered, "gms_rasterize_forward")
         _capacity_cache[key] = max(int(num_rendered), int(0.97 * _capacity_cache.get(key, 0)))
         _last_stats.update(num_rendered=int(num_rendered), num_units=int(num_units.value), capacity_hint=hint, P=P, width=W, height=H,
-                           deepest_tile=int(lib.gms_last_deepest_tile()))
+                           deepest_tile=int(lib.gms_last_deepest_tile()), used_micro=int(lib.gms_last_used_micro()))
         if _keep_buffers:
             _last_stats.update(radii=radii, image=scratch.tensors.get("image"), binning=scratch.tensors.get("binning"),
                                geom=scratch.tensors.get("geom"))

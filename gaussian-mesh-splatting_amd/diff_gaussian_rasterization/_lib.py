@@ -98,7 +98,8 @@ EXPORTS = (
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
     "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault", "gms_set_deterministic", "gms_get_deterministic",
-    "gms_image_counts_offset", "gms_last_launched_units",
+    "gms_image_counts_offset", "gms_last_launched_units", "gms_last_used_micro",
+    "gms_set_upstream_scale_mod_grad", "gms_get_upstream_scale_mod_grad",
 )
 K_COUNT = 17
 
@@ -140,6 +141,7 @@ def load():
         lib.gms_image_counts_offset.restype = C.c_size_t
         lib.gms_image_counts_offset.argtypes = [C.c_int32, C.c_int32]
         lib.gms_last_launched_units.restype = C.c_int64
+        lib.gms_last_used_micro.restype = C.c_int32
         lib.gms_binning_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
         lib.gms_knn_workspace_bytes.restype = C.c_size_t
         lib.gms_knn_workspace_bytes.argtypes = [C.c_int32]
@@ -168,6 +170,9 @@ def load():
         lib.gms_set_fault.argtypes = [C.c_int32]
         lib.gms_set_fault.restype = None
         lib.gms_get_fault.restype = C.c_int32
+        lib.gms_set_upstream_scale_mod_grad.argtypes = [C.c_int32]
+        lib.gms_set_upstream_scale_mod_grad.restype = None
+        lib.gms_get_upstream_scale_mod_grad.restype = C.c_int32
         lib.gms_set_deterministic.argtypes = [C.c_int32]
         lib.gms_set_deterministic.restype = None
         lib.gms_get_deterministic.restype = C.c_int32

@@ -137,6 +137,7 @@ class GraphedAnimation:
         self.static_tri = None
         self.out = None
         self.captures = 0
+        self._image_scratch, self._counts_off, self.capacity, self.launched_units = None, 0, 0, 0
 
     @torch.no_grad()
     def _capture(self, triangles: torch.Tensor, slack: float = 1.0) -> None:
@@ -154,12 +155,14 @@ class GraphedAnimation:
                 dgr.set_capacity_hint(dev.index if dev.index is not None else torch.cuda.current_device(), W, H, P, int(n * slack))
                 render_animated(None, self.static_tri, self.view, self.pc, self.pipe, self.bg)
             self.stream.synchronize()
+            kept = bool(getattr(dgr, "_keep_buffers", False))      # (the caller's own setting is restored below)
             dgr.keep_buffers(True)                         # the captured frame's image scratch holds its counts: keep the handle
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.out = render_animated(None, self.static_tri, self.view, self.pc, self.pipe, self.bg)["render"]
             st = dict(dgr._C.last_stats())
-            dgr.keep_buffers(False)
+            if not kept:
+                dgr.keep_buffers(False)
         self._image_scratch = st["image"]
         self.capacity = int(st["capacity_hint"])
         self.launched_units = int(dgr._C.last_launched_units())
@@ -169,15 +172,20 @@ class GraphedAnimation:
 
     def status(self) -> dict:
         """Counts of the most recent replayed frame (device -> host copy of 16 bytes) and whether it fitted the capture."""
+        if self._image_scratch is None:          # nothing captured yet
+            return {"num_rendered": 0, "deepest_tile": 0, "num_units": 0, "segment_length": 0, "capacity": 0, "launched_units": 0,
+                    "complete": True}
         c = self._image_scratch[self._counts_off:self._counts_off + 16].view(torch.int32).cpu()
         n, deepest, units, L = (int(x) & 0xffffffff for x in c)
         return {"num_rendered": n, "deepest_tile": deepest, "num_units": units, "segment_length": L, "capacity": self.capacity,
                 "launched_units": self.launched_units, "complete": n <= self.capacity and units <= self.launched_units}
 
     @torch.no_grad()
-    def render(self, triangles: torch.Tensor, check: bool = False) -> torch.Tensor:
+    def render(self, triangles: torch.Tensor, check: bool = True) -> torch.Tensor:
         """The frame for `triangles` [F,3,3].  Returns the graph's STATIC output tensor (overwritten by the next call: clone it to
-        keep it).  `check`: verify the frame fitted the captured sizes and, if it did not, re-capture at 1.5x its count and redo it."""
+        keep it).  `check` (default True: a frame that outgrew the capture would otherwise come back silently incomplete): verify the
+        frame fitted the captured sizes -- a 16-byte read-back, i.e. one stream synchronisation -- and, if it did not, re-capture at
+        1.5x its count and redo it.  Pass False and poll `status()` every few frames where the synchronisation matters."""
         dev = triangles.device
         if self.graph is None or triangles.shape != self.static_tri.shape:
             self._capture(triangles)

@@ -207,6 +207,9 @@ class ShFactorExchange:
         self._set_mode, self._take, self._expand = ops
         self.f_dc, self.f_rest = features_dc, features_rest
         self.world, self.group, self.average = int(world), group, bool(average)
+        if self.world > 1 and not dist.is_initialized():
+            # (round-4 advisor finding: the 1/world of `average` used to be applied although nothing was gathered)
+            raise RuntimeError(f"ShFactorExchange(world={self.world}) needs an initialised torch.distributed process group")
         self._comm = (self.world > 1 or force) and dist.is_initialized()
         self._work, self._gathered, self._local = None, None, None
         self._views_checked = None
@@ -246,10 +249,11 @@ class ShFactorExchange:
             self._gathered, self._work = local.contiguous(), None
 
     def finish(self, means3D: torch.Tensor, sh_degree: int, scale: float = None) -> None:
-        """Wait for the gather and write the SH gradients.  `scale` multiplies the sum over all views of all ranks; None =
-        1/world if `average` else 1."""
+        """Wait for the gather and write the SH gradients.  `scale` multiplies the sum over all views of all ranks; None (the
+        default since round 4; it was 1.0 = a plain sum before) = 1/world if `average` and the factors were gathered over the
+        ranks, else 1.  Pass `scale=1.0` (or `average=False`) for the old plain-sum behaviour."""
         if scale is None:
-            scale = 1.0 / self.world if (self.average and self.world > 1) else 1.0
+            scale = 1.0 / self.world if (self.average and self._comm and self.world > 1) else 1.0
         if self._gathered is None:
             self.start()
         if self._work is not None:
@@ -305,6 +309,8 @@ class PackedGradExchange:
         self.f_dc, self.f_rest = features_dc, features_rest
         self.small = [p for p in params if p is not features_dc and p is not features_rest]
         self.world, self.group, self.average = int(world), group, bool(average)
+        if self.world > 1 and not dist.is_initialized():
+            raise RuntimeError(f"PackedGradExchange(world={self.world}) needs an initialised torch.distributed process group")
         self._comm = (self.world > 1 or force) and dist.is_initialized()
         self._views_checked = None
 
@@ -332,7 +338,7 @@ class PackedGradExchange:
             gathered = send
         G = gathered.view(W, n)
         flat = G[:, :n - nf].sum(dim=0) if W > 1 else G[0, :n - nf]
-        inv = 1.0 / self.world if (self.average and self.world > 1) else 1.0
+        inv = 1.0 / self.world if (self.average and self._comm and self.world > 1) else 1.0
         if inv != 1.0:
             flat = flat * inv
         off = 0

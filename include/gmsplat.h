@@ -123,6 +123,11 @@ typedef struct GmsRasterForwardArgs {
 int64_t gms_rasterize_forward(const GmsRasterForwardArgs *args, void *stream);
 /* Blocks (work units) the compositing launches of the calling thread's most recent gms_rasterize_forward were sized for. */
 int64_t gms_last_launched_units(void);
+/* Which compositing implementation the calling thread's most recent gms_rasterize_forward launched: 1 = the micro-tile kernels
+ * (blend_micro.hip: n_contrib holds positions in a 4x4 block's pre-filtered list), 0 = the quadrant kernels (blend.hip: positions
+ * in the tile's list).  The decision is the library's (GMS_MICRO, the frame's binning capacity -- the instance count itself on an
+ * overflow re-run); bindings report it instead of re-deriving it. */
+int32_t gms_last_used_micro(void);
 
 typedef struct GmsRasterBackwardArgs {
     int32_t P, D, M, width, height;
@@ -371,9 +376,21 @@ int32_t gms_get_deterministic(void);
  *      stream, P) adds the previous frame's moments to its own
  *   4  preprocess_bwd: dL/dscale of every 1000th Gaussian is scaled by 1 + 2e-3
  *   5  preprocess_bwd: dL/dscale (all three components) of every 100th Gaussian is scaled by 1 + 1.3e-3 -- a defect between the
- *      1e-3 tolerance and the 2e-3 of faults 1 / 4, on 1 % of the rows */
+ *      1e-3 tolerance and the 2e-3 of faults 1 / 4, on 1 % of the rows
+ * These five are ALL the library contains; any other value means 0.  (Until round 4 a sixth value, 9, selected a wrong-results
+ * timing experiment of the micro-tile backward; it no longer exists in any build.) */
 void gms_set_fault(int32_t fault);
 int32_t gms_get_fault(void);
+
+/* ---- upstream-quirk switch (parity hygiene; DESIGN.md section 2 "unverifiable") --------------------
+ * cov3D = R diag(mod s)^2 R^T, so the derivative with respect to the scale carries the factor mod = scale_modifier, and that is
+ * what this library returns by default.  The public upstream CUDA backward (computeCov3D: `dL_dscale = dot(Rt[k], dL_dMt[k])` with
+ * s = mod * scale) is believed to leave that factor out; the module is absent from the reference tree
+ * (submodules/diff-gaussian-rasterization, .gitmodules:4-6), so it cannot be checked here.  With the switch on -- this call, or
+ * GMS_UPSTREAM_SCALE_MOD_GRAD=1 in the environment at first use -- dL/dscale is returned WITHOUT the factor.  Inert in GaMeS:
+ * every render() of the reference passes scale_modifier = 1.0 (renderer/gaussian_renderer/__init__.py:25). */
+void gms_set_upstream_scale_mod_grad(int32_t on);
+int32_t gms_get_upstream_scale_mod_grad(void);
 
 #ifdef __cplusplus
 }

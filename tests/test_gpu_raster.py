@@ -61,6 +61,30 @@ def test_forward_backward_parity(case):
     _check(_inputs(sc), kw, cam.image_width, cam.image_height)
 
 
+def test_upstream_scale_modifier_quirk_switch():
+    """include/gmsplat.h, gms_set_upstream_scale_mod_grad: with the switch on dL/dscale loses the scale_modifier factor (what the
+    public upstream backward is believed to return) and nothing else changes; at scale_modifier = 1 -- every render() of the
+    reference -- the two settings agree."""
+    import diff_gaussian_rasterization as dgr
+    sc, cam = syn.random_scene(2000, seed=6), syn.orbit_camera(6, width=128, height=128, radius=3.0)
+    inputs = _inputs(sc)
+    try:
+        for mod in (1.7, 1.0):
+            kw = U.settings_kwargs(cam, torch.tensor([0.2, 0.4, 0.6]), scale_modifier=mod)
+            gc = syn.upstream_grad(torch.from_numpy(U.hip_render(inputs, kw, need_grad=False)["color"])).numpy() * 1000.0
+            dgr.set_upstream_scale_mod_grad(False)
+            off = U.hip_render(inputs, kw, grad_color=gc)["grads"]
+            dgr.set_upstream_scale_mod_grad(True)
+            on = U.hip_render(inputs, kw, grad_color=gc)["grads"]
+            for k in ("means3D", "means2D", "shs", "opacities", "rotations", "scales"):
+                want = off[k] / mod if k == "scales" else off[k]
+                tol = 2e-5 * np.abs(want).max() + 1e-12          # two runs differ by the order of the float atomics
+                assert np.abs(on[k] - want).max() <= tol, (mod, k, np.abs(on[k] - want).max(), tol)
+            assert np.abs(off["scales"]).max() > 0
+    finally:
+        dgr.set_upstream_scale_mod_grad(False)
+
+
 def test_precomputed_colors_and_cov3d_inputs():
     from oracle import dense_torch
     sc = syn.random_scene(3000, seed=7, scale_lo=0.01, scale_hi=0.12)
