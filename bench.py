@@ -499,7 +499,8 @@ def main():
         return el
 
     if args.mode == "animate":
-        from games_hip.render import render_animated
+        from games_hip.render import _fused_frame_ok, render_animated
+        from games_hip.animate import render_frame
         cam = all_cams[rank % 8]
         frame = [0]
         verts = torch.cat(list(model.vertices)) if isinstance(model.vertices, (list, tuple)) else model.vertices
@@ -510,6 +511,9 @@ def main():
             from games_hip.animate import GraphedAnimation
             anim = GraphedAnimation(model, cam, pipe, bg)
 
+        with torch.no_grad():
+            fused_k0 = (not isinstance(model.faces, (list, tuple))) and _fused_frame_ok(model, pipe, None)
+
         def animate_step():
             with torch.no_grad():
                 t = 0.05 * frame[0]
@@ -517,6 +521,8 @@ def main():
                 new_v = verts * (1.0 + 0.05 * math.sin(t))           # scripts/render_time_animated.py:68-87 style
                 if anim is not None:
                     anim.render(new_v[faces], check=(frame[0] % 64 == 0))      # the frame's counts are read back every 64th frame
+                elif fused_k0:
+                    render_frame(new_v, faces, cam, model, pipe, bg)         # mesh -> image: K0 inside the preprocess thread
                 else:
                     render_animated(None, new_v[faces], cam, model, pipe, bg)
         el = timed(animate_step, args.steps, args.warmup)
@@ -526,6 +532,8 @@ def main():
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * el / args.steps, 4),
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": f"{desc['text']}, animate, {size}x{size}",
+                                         "k0": ("inside preprocess_fwd (GmsRasterForwardArgs.mesh): no K0 launch, no vertices[faces] gather"
+                                                if (fused_k0 and anim is None) else ("inside preprocess_fwd, frame replayed as a hipGraph" if fused_k0 else "separate launch")),
                                          "graph": ({"captures": anim.captures, **anim.status()} if anim is not None else None)}}), flush=True)
         if distributed:
             dist.destroy_process_group()
@@ -617,6 +625,12 @@ def main():
     torch.cuda.synchronize(device)
     lib.gms_profile_enable(0)
     ktimes = _lib.kernel_times()
+    # what the bracketing event pair itself adds to every launch it times (round-4 review: without this the small kernels read up
+    # to 32 % long and the table sums to more than the step): measured here, on this stream, subtracted below
+    event_overhead_us = 0.0
+    if args.profile_steps > 0:
+        import ctypes as _C
+        event_overhead_us = max(0.0, float(lib.gms_profile_event_overhead_us(_C.c_void_p(torch.cuda.current_stream(device).cuda_stream), 40)))
 
     if rank == 0:
         P, F = desc["gaussians"], desc["faces"]
@@ -643,7 +657,8 @@ def main():
         for name, (ms, n) in ktimes.items():
             if n == 0:
                 continue
-            avg_us = 1000.0 * ms / n
+            raw_us = 1000.0 * ms / n
+            avg_us = max(raw_us - event_overhead_us, 0.25 * raw_us)      # (the floor only guards a launch shorter than the overhead)
             lps = n / max(args.profile_steps * vps, 1)       # launches per rendered view
             # a stage that takes several launches per view (tile_sort: presort + merge; blend_head on deep scenes) is priced on
             # the SUM of its launches: its algorithmic bytes are per view, not per launch
@@ -723,6 +738,9 @@ def main():
             "roofline": roofline,
             "kernels": kernels,
             "stages": stages,
+            "kernel_timing": {"method": "HIP events on the launch stream around every launch of a separate untimed pass, minus the event "
+                                        "pair's own overhead (gms_profile_event_overhead_us: a kernel that times itself by the device wall clock)",
+                              "event_overhead_us": round(event_overhead_us, 2)},
             "whole_iteration": {"algorithmic_bytes": whole_bytes, "sum_kernel_us": round(sum_kernel_us, 1),
                                 "achieved_GBps": round(whole_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                                 "frac_of_8TBps": round(whole_bytes / (ms_per_step * 1e-3) / 8e12, 4)},

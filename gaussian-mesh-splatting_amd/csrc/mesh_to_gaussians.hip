@@ -15,123 +15,9 @@
 // Operation order follows the reference line by line; contraction is off so the discrete
 // argmax in the quaternion conversion sees the same values as a float32 CPU evaluation.
 #include "gms_common.h"
+#include "gms_mesh.h"
 
 namespace gms {
-
-constexpr float EPS = 1e-8f;
-
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
-__device__ __forceinline__ float dot(V3 a, V3 b)
-{
-#pragma clang fp contract(off)
-    return a.x * b.x + a.y * b.y + a.z * b.z;
-}
-__device__ __forceinline__ V3 cross(V3 a, V3 b)
-{
-#pragma clang fp contract(off)
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
-__device__ __forceinline__ float norm(V3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V3 ldv(const float *p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
-
-struct Frame {
-    V3 t0, t1, t2;
-    V3 N;  float nN;          // cross product and its norm
-    V3 v0, v1, v2;
-    V3 u1; float n1, v1n;     // t1 - mean, |u1|, |u1| + eps
-    V3 v2i, w; float nw;      // t2 - mean, Gram-Schmidt residual and its norm
-    float s1, s2;
-};
-
-__device__ __forceinline__ void face_frame(V3 t0, V3 t1, V3 t2, Frame &f)
-{
-#pragma clang fp contract(off)
-    f.t0 = t0; f.t1 = t1; f.t2 = t2;
-    f.N = cross(t1 - t0, t2 - t0);
-    f.nN = norm(f.N);
-    f.v0 = {f.N.x / (f.nN + EPS), f.N.y / (f.nN + EPS), f.N.z / (f.nN + EPS)};
-    V3 sum = (t0 + t1) + t2;
-    V3 mean = {sum.x / 3.f, sum.y / 3.f, sum.z / 3.f};
-    f.u1 = t1 - mean;
-    f.n1 = norm(f.u1);
-    f.v1n = f.n1 + EPS;
-    f.v1 = {f.u1.x / f.v1n, f.u1.y / f.v1n, f.u1.z / f.v1n};
-    f.v2i = t2 - mean;
-    float c0 = dot(f.v2i, f.v0), c1 = dot(f.v2i, f.v1);
-    f.w = (f.v2i - c0 * f.v0) - c1 * f.v1;
-    f.nw = norm(f.w);
-    f.v2 = {f.w.x / (f.nw + EPS), f.w.y / (f.nw + EPS), f.w.z / (f.nw + EPS)};
-    f.s1 = f.v1n / 2.f;
-    f.s2 = dot(f.v2i, f.v2) / 2.f;
-}
-
-// rotation matrix with columns (v0,v1,v2) -> quaternion; also reports the selected candidate
-struct QuatSel { int sel; float a; float sign; float cand[4]; float xsel; };   // xsel = argument of the selected sqrt
-
-__device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel *qs)
-{
-#pragma clang fp contract(off)
-    const float m00 = f.v0.x, m01 = f.v1.x, m02 = f.v2.x;
-    const float m10 = f.v0.y, m11 = f.v1.y, m12 = f.v2.y;
-    const float m20 = f.v0.z, m21 = f.v1.z, m22 = f.v2.z;
-    float x[4] = {1.0f + m00 + m11 + m22, 1.0f + m00 - m11 - m22, 1.0f - m00 + m11 - m22, 1.0f - m00 - m11 + m22};
-    float qa[4];
-    int sel = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) qa[k] = x[k] > 0.f ? sqrtf(x[k]) : 0.f;
-#pragma unroll
-    for (int k = 1; k < 4; k++)
-        if (qa[k] > qa[sel]) sel = k;          // first maximum wins, as torch.argmax
-    // select without dynamic register-array indexing (that would be demoted to LDS/scratch)
-    const float a = sel == 0 ? qa[0] : sel == 1 ? qa[1] : sel == 2 ? qa[2] : qa[3];
-    const float xsel = sel == 0 ? x[0] : sel == 1 ? x[1] : sel == 2 ? x[2] : x[3];
-    float c[4];
-    const float a2 = a * a;
-    if (sel == 0) { c[0] = a2; c[1] = m21 - m12; c[2] = m02 - m20; c[3] = m10 - m01; }
-    else if (sel == 1) { c[0] = m21 - m12; c[1] = a2; c[2] = m10 + m01; c[3] = m02 + m20; }
-    else if (sel == 2) { c[0] = m02 - m20; c[1] = m10 + m01; c[2] = a2; c[3] = m12 + m21; }
-    else { c[0] = m10 - m01; c[1] = m20 + m02; c[2] = m21 + m12; c[3] = a2; }
-    const float den = 2.0f * fmaxf(a, 0.1f);
-    float o[4] = {c[0] / den, c[1] / den, c[2] / den, c[3] / den};
-    const float sign = o[0] < 0.f ? -1.f : 1.f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = o[0] < 0.f ? -o[k] : o[k];
-    if (qs) {
-        qs->sel = sel; qs->a = a; qs->sign = sign;
-#pragma unroll
-        for (int k = 0; k < 4; k++) qs->cand[k] = c[k];
-        qs->xsel = xsel;
-    }
-}
-
-__device__ __forceinline__ int splat_to_face(const GmsMeshArgs &a, int64_t p)
-{
-    return a.splats_per_face > 0 ? (int)(p / a.splats_per_face) : a.splat_face[p];
-}
-
-__device__ __forceinline__ void load_face(const GmsMeshArgs &a, int f, V3 &t0, V3 &t1, V3 &t2)
-{
-    const int64_t i0 = a.faces[3 * (size_t)f], i1 = a.faces[3 * (size_t)f + 1], i2 = a.faces[3 * (size_t)f + 2];
-    t0 = ldv(a.vertices, (size_t)i0); t1 = ldv(a.vertices, (size_t)i1); t2 = ldv(a.vertices, (size_t)i2);
-}
-
-__device__ __forceinline__ void barycentric(int mode, const float *raw, float al[3], float &rsum)
-{
-#pragma clang fp contract(off)
-    if (mode == GMS_ALPHA_RELU) {
-        float r0 = fmaxf(raw[0], 0.f) + 1e-8f, r1 = fmaxf(raw[1], 0.f) + 1e-8f, r2 = fmaxf(raw[2], 0.f) + 1e-8f;
-        rsum = (r0 + r1) + r2;
-        al[0] = r0 / rsum; al[1] = r1 / rsum; al[2] = r2 / rsum;
-    } else {
-        float mx = fmaxf(raw[0], fmaxf(raw[1], raw[2]));
-        float e0 = expf(raw[0] - mx), e1 = expf(raw[1] - mx), e2 = expf(raw[2] - mx);
-        rsum = (e0 + e1) + e2;
-        al[0] = e0 / rsum; al[1] = e1 / rsum; al[2] = e2 / rsum;
-    }
-}
 
 __global__ void __launch_bounds__(BLOCK) mesh_fwd_kernel(GmsMeshArgs a, float *alpha_out, float *xyz, float *scaling,
                                                          float *rotation, float *scaling_act, float *rotation_unit,

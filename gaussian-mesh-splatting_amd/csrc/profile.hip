@@ -168,6 +168,44 @@ static const char *const k_names[GMS_K_COUNT] = {
 
 extern "C" void gms_profile_enable(int32_t on) { gms::g_profile_on = on != 0; }
 
+// What a bracketing event pair adds to a launch's duration (gmsplat.h).  One wave spins for ~10 us by the 100 MHz wall clock and
+// reports the time it measured itself; the pair around the launch measures more, and the difference is the overhead.
+namespace gms {
+__global__ void profile_calibration_kernel(unsigned long long *out, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned long long t1 = t0;
+    while (t1 - t0 < ticks) { __builtin_amdgcn_s_sleep(8); t1 = wall_clock64(); }
+    if (threadIdx.x == 0) out[0] = t1 - t0;
+}
+}  // namespace gms
+extern "C" double gms_profile_event_overhead_us(void *stream_, int32_t reps)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (reps < 1) reps = 1;
+    if (reps > 1000) reps = 1000;
+    unsigned long long *d = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMalloc((void **)&d, 8) != hipSuccess) return -1.0;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(d); return -1.0; }
+    double sum = 0.0;
+    int n = 0;
+    for (int r = -3; r < reps; r++) {          // (three warm-up rounds)
+        // a kernel in front, as in a profiled step, so that the first event is recorded behind running work and not on an idle queue
+        gms::profile_calibration_kernel<<<1, 64, 0, stream>>>(d, 300ull);
+        (void)hipEventRecord(e0, stream);
+        gms::profile_calibration_kernel<<<1, 64, 0, stream>>>(d, 1000ull);          // 10 us
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) break;
+        float ms = 0.f;
+        unsigned long long inner = 0;
+        if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess || hipMemcpy(&inner, d, 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+        if (r >= 0) { sum += (double)ms * 1e3 - (double)inner * 0.01; n++; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(d);
+    return n > 0 ? sum / n : -1.0;
+}
+
 extern "C" void gms_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(gms::g_mu);

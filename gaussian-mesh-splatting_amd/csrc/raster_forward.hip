@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "gms_blend.h"
+#include "gms_mesh.h"
 #include <atomic>
 #include <vector>
 #include <chrono>
@@ -61,6 +62,7 @@ struct PreArgs {
     uint32_t *tile_count;
     uint32_t *zero_cursor;   // [T] emit cursors, cleared here when the frame takes the inline-scan emit (else NULL: tile_scan clears them)
     int T;
+    GmsMeshArgs mesh;        // K0 instantiation only: centre / scale / rotation / opacity are derived from the mesh in the thread
 };
 
 // SH -> RGB (before +0.5/clamp) for one channel from the coefficient row r[k*3+c] held in registers;
@@ -130,11 +132,16 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
 // so is the source here: the 64 rows of `_features_rest` a wave owns are 11 520 contiguous, 16-byte aligned bytes, copied as they
 // lie (row pitch 45 dwords: odd, so the per-lane ds_read_b32 of a row are conflict-free), the 768 bytes of `_features_dc` behind
 // them.  Before, the same block went through 12 float4 registers per lane and 48 scalar ds_write_b32 with a division by 45 each.
-template <int SHDEG, bool SPLIT, int MODE = 0, bool DMA = false>
+// K0 (round 5; forward-only frames of the animated render drivers, scripts/render_time_animated.py:68-87): the thread derives its
+// Gaussian from the mesh -- barycentric centre, face frame -> activated scale and unit quaternion, sigmoid opacity, the statements
+// of mesh_fwd_kernel (gms_mesh.h::splat_from_face) -- instead of loading means3D / scales / rotations / opacities: those four
+// tensors (44 bytes per Gaussian written by K0 and read back here, plus K0's raw copies) never reach HBM and the K0 launch is gone.
+template <int SHDEG, bool SPLIT, int MODE = 0, bool DMA = false, bool K0 = false>
 __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
 {
 #pragma clang fp contract(off)
     static_assert(!DMA || (SHDEG == 3 && SPLIT && MODE == 0), "the LDS-DMA staging exists for split degree-3 storage");
+    static_assert(!K0 || DMA, "the fused mesh input rides on the LDS-DMA instantiation");
     constexpr int DMA_WAVE_FLOATS = WAVE * 48;        // 64 x 45 REST floats, then 64 x 3 DC floats
     __shared__ __attribute__((aligned(16))) float sh_lds[MODE == 1 ? 2 * TT_SLOTS : (DMA ? 4 * DMA_WAVE_FLOATS : 4 * WAVE * SH_PITCH)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
                 }
             }
         }
-        if (valid && MODE != 2) {
+        if (valid && MODE != 2 && !K0) {
             op_in = a.opac[i];
             if (!a.cov3Dp) {
                 s_in[0] = a.scales[3 * (size_t)i]; s_in[1] = a.scales[3 * (size_t)i + 1]; s_in[2] = a.scales[3 * (size_t)i + 2];
@@ -215,7 +222,17 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     bool vis = false;
     float pix = 0, piy = 0, cA = 0, cB = 0, cC = 0, opp = 0, a_d = 0, c_d = 0, rad = 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    if (valid) {
+    if (K0) {
+        if (valid) {
+            SplatParams sp;
+            splat_from_face(a.mesh, (int64_t)i, sp);
+            px = sp.xyz[0]; py = sp.xyz[1]; pz = sp.xyz[2];
+            s_in[0] = sp.scale[0]; s_in[1] = sp.scale[1]; s_in[2] = sp.scale[2];
+            q_in = make_float4(sp.q[0], sp.q[1], sp.q[2], sp.q[3]);
+            op_in = sp.opacity;
+            view_transform(a.view, px, py, pz, vx, vy, vz); vis = vz > NEAR_Z;
+        }
+    } else if (valid) {
         px = a.means3D[3 * (size_t)i]; py = a.means3D[3 * (size_t)i + 1]; pz = a.means3D[3 * (size_t)i + 2];
         if (MODE == 2) vis = a.radii[i] > 0;                          // (decided by the geometry launch)
         else { view_transform(a.view, px, py, pz, vx, vy, vz); vis = vz > NEAR_Z; }
@@ -1415,7 +1432,20 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     }
     const int P = A->P, W = A->width, H = A->height;
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
-    if (P > 0) {
+    const GmsMeshArgs *mesh = A->mesh;          // forward-only frame straight from a mesh (gmsplat.h): K0 runs inside the preprocess thread
+    if (P > 0 && mesh) {
+        if (mesh->P != (int64_t)P || !mesh->vertices || !mesh->faces || !mesh->_alpha || !mesh->_scale || !mesh->_opacity ||
+            (mesh->splats_per_face <= 0 && !mesh->splat_face) || !A->shs || !A->shs_rest || A->M != 16 || A->D != 3 || A->colors_precomp ||
+            A->cov3D_precomp || (((uintptr_t)A->shs) & 15u) || (((uintptr_t)A->shs_rest) & 15u)) {
+            set_error("gms_rasterize_forward: the fused mesh input needs a complete GmsMeshArgs (P equal, _opacity set), split degree-3 SH "
+                      "storage (shs + shs_rest, M = 16, D = 3, 16-byte aligned) and no precomputed colours / covariances");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+        if (!A->viewmatrix || !A->projmatrix || !A->campos || !A->radii || !A->geom_alloc || !A->binning_alloc || !A->image_alloc) {
+            set_error("gms_rasterize_forward: null input pointer or callback");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+    } else if (P > 0) {
         if ((A->shs == nullptr) == (A->colors_precomp == nullptr)) {
             set_error("provide exactly one of shs / colors_precomp");
             return GMS_ERR_INVALID_ARGUMENT;
@@ -1489,6 +1519,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.visible = A->visible; pa.geom = geom; pa.tile_count = img.tile_count;
+    if (mesh) { pa.mesh = *mesh; pa.means3D = nullptr; pa.opac = nullptr; pa.scales = nullptr; pa.rots = nullptr; pa.cov3Dp = nullptr; }
     // Inline tile scan (see emit_instances_kernel): on the capacity-hint path, when the segment length is known up front and the
     // tile table fits the emit blocks' LDS.  GMS_INLINE_SCAN=0 keeps the separate tile_scan launch.
     static int inline_env = -1;
@@ -1502,7 +1533,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
     const bool split = A->shs_rest != nullptr;
     const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
-                         (A->cov3D_precomp || (((uintptr_t)A->rotations) & 15u) == 0);
+                         (mesh || A->cov3D_precomp || (((uintptr_t)A->rotations) & 15u) == 0);
     if (split && !sh_fast) {
         set_error("split SH storage (shs_rest) needs M == 16 and 16-byte aligned pointers");
         return GMS_ERR_INVALID_ARGUMENT;
@@ -1515,7 +1546,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     struct Aux { int device; hipStream_t s; hipEvent_t fork, join; };
     static thread_local std::vector<Aux> t_aux;
     Aux *aux = nullptr;
-    const bool two_stream = sh_stream_env && sh_fast && A->D > 0;
+    const bool two_stream = sh_stream_env && sh_fast && A->D > 0 && !mesh;
     if (two_stream) {
         for (auto &x : t_aux) if (x.device == device) aux = &x;
         if (!aux) {
@@ -1550,7 +1581,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     case 5: GMS_PRE(2, true); break;
     case 6: GMS_PRE(3, false); break;
     case 7:
-        if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        if (mesh) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        else if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
         else GMS_PRE(3, true);
         break;
     default: GMS_PRE_M(-1, false, 0, stream); break;

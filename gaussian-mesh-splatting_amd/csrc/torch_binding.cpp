@@ -100,10 +100,11 @@ struct Forward {
 Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh_, const Tensor &sh_rest_, const Tensor &colors_,
                      const Tensor &opac_, const Tensor &scales_, const Tensor &rots_, const Tensor &cov_, const Tensor &view_,
                      const Tensor &proj_, const Tensor &campos_, int64_t H, int64_t W, double tanx, double tany, double mod, int64_t D,
-                     bool prefiltered, bool aa, bool debug, const Tensor &visible, bool use_hint)
+                     bool prefiltered, bool aa, bool debug, const Tensor &visible, bool use_hint, const GmsMeshArgs *mesh = nullptr)
 {
+    // (`mesh`: the forward-only frame straight from a mesh, gmsplat.h; `means3D_` then only carries the device and P -- the SH DC tensor)
     require_gpu(means3D_); require_gpu(bg_); require_gpu(view_); require_gpu(proj_); require_gpu(campos_);
-    TORCH_CHECK(means3D_.dim() == 2 && means3D_.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+    TORCH_CHECK(mesh || (means3D_.dim() == 2 && means3D_.size(1) == 3), "means3D must have dimensions (num_points, 3)");
     const auto dev = means3D_.device();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
     const int64_t P = means3D_.size(0);
@@ -154,6 +155,8 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
     a.visible = (visible.defined() && visible.numel()) ? static_cast<uint8_t *>(visible.data_ptr()) : nullptr;
     a.num_units_out = &num_units;
     a.no_host_wait = capturing ? 1 : 0;
+    a.mesh = mesh;
+    if (mesh) { a.means3D = nullptr; a.opacities = nullptr; a.scales = nullptr; a.rotations = nullptr; }
     const int64_t n = gms_rasterize_forward(&a, stream_of(means3D));
     TORCH_CHECK(!(geom.failed || binning.failed || image.failed), "scratch allocation failed (out of device memory?)");
     check_rc(n, "gms_rasterize_forward");
@@ -462,6 +465,28 @@ GmsMeshArgs mesh_args(const Tensor &vertices, const Tensor &faces, const Tensor 
     return a;
 }
 
+// Forward-only frame of the animated render drivers (games_hip.animate): mesh -> image in the rasterizer's own launches, K0 inside
+// the preprocess thread (GmsRasterForwardArgs.mesh).  Returns (image, radii, inverse depth).
+std::tuple<Tensor, Tensor, Tensor> render_mesh_forward(const Tensor &vertices, const Tensor &faces, const Tensor &_alpha, const Tensor &_scale,
+                                                       const Tensor &_opacity, int64_t mode, int64_t spf, const Tensor &splat_face,
+                                                       const Tensor &sh_dc, const Tensor &sh_rest, const Tensor &bg, const Tensor &view,
+                                                       const Tensor &proj, const Tensor &campos, int64_t H, int64_t W, double tanx, double tany,
+                                                       double mod, bool aa, bool debug)
+{
+    require_gpu(vertices); require_gpu(_alpha); require_gpu(_scale); require_gpu(_opacity); require_gpu(sh_dc); require_gpu(sh_rest);
+    TORCH_CHECK(faces.scalar_type() == torch::kInt64 && faces.is_contiguous() && faces.is_cuda(), "faces must be a contiguous int64 device tensor");
+    Tensor v = f32c(vertices), al = f32c(_alpha), sc = f32c(_scale), op = f32c(_opacity);
+    const int64_t P = sc.numel();
+    TORCH_CHECK(al.numel() == 3 * P && op.numel() == P && sh_dc.size(0) == P && sh_rest.size(0) == P, "render_mesh_forward: P mismatch");
+    TORCH_CHECK(sh_dc.dim() == 3 && sh_dc.size(1) == 1 && sh_rest.dim() == 3 && sh_rest.size(1) == 15, "render_mesh_forward needs split degree-3 SH storage ([P,1,3] + [P,15,3])");
+    GmsMeshArgs m = mesh_args(v, faces, al, sc, mode, spf, Tensor(), splat_face, true, op);
+    // (P stands in for means3D: forward_core reads the device and the count from its first tensor argument)
+    Tensor stand_in = sh_dc.view({P, 3});
+    Forward f = forward_core(bg, stand_in, sh_dc, sh_rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
+                             3, false, aa, debug, Tensor(), true, &m);
+    return std::make_tuple(f.color, f.radii, f.invdepth);
+}
+
 class MeshFn : public torch::autograd::Function<MeshFn> {
 public:
     static variable_list forward(AutogradContext *ctx, Tensor vertices_, Tensor faces_, Tensor alpha_, Tensor scale_, int64_t mode,
@@ -629,6 +654,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mark_visible", &mark_visible, nogil());
     m.def("rasterize", &rasterize, "differentiable rasterization (autograd node in C++)", nogil());
     m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization", nogil());
+    m.def("render_mesh_forward", &render_mesh_forward, "forward-only frame straight from a mesh (K0 inside the preprocess thread)", nogil());
     m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]", nogil());
     m.def("adam_step", &adam_step, nogil());
     m.def("set_keep_buffers", &set_keep_buffers, "keep references to the last forward's scratch tensors (diagnostics only)");

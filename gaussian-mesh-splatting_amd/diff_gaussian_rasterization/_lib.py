@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
-GMS_ABI_VERSION = 4
+GMS_ABI_VERSION = 5
 GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
 ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
 
@@ -34,6 +34,7 @@ class RasterForwardArgs(C.Structure):
         ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
         ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
         ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p), ("num_units_out", C.c_void_p), ("no_host_wait", C.c_int32),
+        ("mesh", C.c_void_p),          # ABI 5: const GmsMeshArgs * (forward-only frame straight from a mesh) or NULL
     ]
 
 
@@ -99,7 +100,7 @@ EXPORTS = (
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",
     "gms_sh_grad_expand", "gms_set_fault", "gms_get_fault", "gms_set_deterministic", "gms_get_deterministic",
     "gms_image_counts_offset", "gms_last_launched_units", "gms_last_used_micro",
-    "gms_set_upstream_scale_mod_grad", "gms_get_upstream_scale_mod_grad",
+    "gms_set_upstream_scale_mod_grad", "gms_get_upstream_scale_mod_grad", "gms_profile_event_overhead_us",
 )
 K_COUNT = 17
 
@@ -170,6 +171,8 @@ def load():
         lib.gms_set_fault.argtypes = [C.c_int32]
         lib.gms_set_fault.restype = None
         lib.gms_get_fault.restype = C.c_int32
+        lib.gms_profile_event_overhead_us.argtypes = [C.c_void_p, C.c_int32]
+        lib.gms_profile_event_overhead_us.restype = C.c_double
         lib.gms_set_upstream_scale_mod_grad.argtypes = [C.c_int32]
         lib.gms_set_upstream_scale_mod_grad.restype = None
         lib.gms_get_upstream_scale_mod_grad.restype = C.c_int32

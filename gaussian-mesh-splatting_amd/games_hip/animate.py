@@ -20,7 +20,7 @@ from typing import Callable, Iterable, List, Optional
 
 import torch
 
-from .render import render, render_animated
+from .render import _fused_frame_ok, render, render_animated, render_mesh_frame
 
 
 def _sel(idxs):
@@ -66,6 +66,15 @@ def _save(image: torch.Tensor, path: str) -> None:
     Image.fromarray(a).save(path)
 
 
+def render_frame(vertices: torch.Tensor, faces: torch.Tensor, view, gaussians, pipeline, background: torch.Tensor):
+    """One animated frame from deformed vertices.  Forward-only frames of a model the fused path supports go mesh -> image in the
+    rasterizer's own launches (`render_mesh_frame`: no `vertices[faces]` gather, no K0 launch, no xyz / scale / rotation tensors);
+    anything else takes the reference's route, `render_animated(None, vertices[faces], ...)`.  Same image bit for bit."""
+    if _fused_frame_ok(gaussians, pipeline, None):
+        return render_mesh_frame(vertices, faces, view, gaussians, pipeline, background)
+    return render_animated(None, vertices[faces].float(), view, gaussians, pipeline, background)
+
+
 @torch.no_grad()
 def render_time_animated(gaussians, views: Iterable, pipeline, background: torch.Tensor,
                          transform: Callable = transform_hotdog_fly, idxs=None, out_dir: Optional[str] = None,
@@ -80,8 +89,7 @@ def render_time_animated(gaussians, views: Iterable, pipeline, background: torch
     frames = []
     for k, view in enumerate(views):
         new_vertices = transform(vertices, ts[k], idxs)
-        triangles = new_vertices[faces].float()
-        img = render_animated(idxs, triangles, view, gaussians, pipeline, background)["render"]
+        img = render_frame(new_vertices, faces, view, gaussians, pipeline, background)["render"]
         frames.append(img)
         if out_dir:
             _save(img, os.path.join(out_dir, f"{k:05d}.png"))

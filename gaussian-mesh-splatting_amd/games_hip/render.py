@@ -115,13 +115,60 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
             "radii": radii, "depth": depth_image}
 
 
+def _fused_frame_ok(pc, pipe, override_color) -> bool:
+    """Can this forward-only frame take the fused mesh -> image path (GmsRasterForwardArgs.mesh)?  Uniform splats per face, split
+    degree-3 SH storage at full degree, the rasterizer's native SH / cov3D stages, nothing to differentiate."""
+    import os
+    import diff_gaussian_rasterization as dgr
+    if dgr._C is None or not hasattr(dgr._C, "render_mesh_forward") or os.environ.get("GMS_ANIMATE_FUSED", "1") == "0":
+        return False
+    if torch.is_grad_enabled() or override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
+        return False
+    a, fr, op = getattr(pc, "_alpha", None), getattr(pc, "_features_rest", None), getattr(pc, "_opacity", None)
+    if not (torch.is_tensor(a) and a.dim() == 3 and a.is_cuda and torch.is_tensor(fr) and fr.dim() == 3 and fr.shape[1] == 15):
+        return False
+    P = int(a.shape[0] * a.shape[1])
+    sc = getattr(pc, getattr(pc, "_hip_scale_attr", "_scale"), None)
+    # the unfused frame reads get_opacity: the kernel's sigmoid while the model's cache of it is current (else torch.sigmoid, which
+    # this path does not reproduce bit for bit)
+    cached = pc.__dict__.get("_hip_opacity") if hasattr(pc, "__dict__") else None
+    cache_ok = cached is not None and cached[0] is op and cached[1] == op._version
+    return (int(pc.active_sh_degree) == 3 and torch.is_tensor(op) and op.numel() == P and torch.is_tensor(sc) and sc.numel() == P
+            and cache_ok and pc._features_dc.is_contiguous() and fr.is_contiguous())
+
+
+def render_mesh_frame(vertices: torch.Tensor, faces: torch.Tensor, viewpoint_camera, pc, pipe, bg_color: torch.Tensor,
+                      scaling_modifier=1.0):
+    """One forward-only frame straight from a (deformed) mesh: vertices [V,3] + faces [F,3] -> image, with the face -> Gaussian
+    parameterization computed inside the rasterizer's preprocess thread (no K0 launch, no xyz / scale / rotation tensors; SURVEY.md
+    section 7 step 9).  Same image, bit for bit, as `render_animated(None, vertices[faces], ...)`; callers check `_fused_frame_ok`."""
+    import diff_gaussian_rasterization as dgr
+    from .mesh_op import ALPHA_MODES
+    H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    color, radii, invdepth = dgr._C.render_mesh_forward(
+        vertices.float(), faces, pc._alpha, getattr(pc, getattr(pc, "_hip_scale_attr", "_scale")), pc._opacity, ALPHA_MODES[getattr(pc, "alpha_mode", "relu")], int(pc._alpha.shape[1]),
+        dgr._empty(vertices.device), pc._features_dc, pc._features_rest, bg_color, viewpoint_camera.world_view_transform,
+        viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, H, W, math.tan(viewpoint_camera.FoVx * 0.5),
+        math.tan(viewpoint_camera.FoVy * 0.5), float(scaling_modifier), bool(pipe.antialiasing), bool(pipe.debug))
+    return {"render": color, "viewspace_points": None, "visibility_filter": radii > 0, "radii": radii, "depth": invdepth}
+
+
 def render_animated(idxs, triangles, viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,
                     override_color=None):
     """renderer/gaussian_animated_renderer/__init__.py:21-121: the mesh is deformed per frame, centres follow
     `pc.alpha @ triangles` (:61-67) and scale / rotation are re-derived from the deformed triangles (:72-73).
     With the fused op that is one kernel: assigning `pc.triangles` and calling `prepare_scaling_rot()` runs
     the op on the explicit triangles; its xyz output is `alpha @ triangles`."""
-    from .mesh_op import triangles_to_gaussians
+    from .mesh_op import triangles_to_gaussians, _identity_faces
+    if _fused_frame_ok(pc, pipe, override_color):
+        # forward-only frame (the animated drivers run under no_grad): K0 inside the preprocess thread, explicit triangles as an
+        # identity-indexed mesh.  (The cached kernel sigmoid is what the unfused frame would read from get_opacity.)
+        F_ = int(triangles.shape[0])
+        key = (triangles.device, F_)
+        if key not in _identity_faces:
+            _identity_faces[key] = torch.arange(3 * F_, device=triangles.device, dtype=torch.int64).reshape(F_, 3)
+        pc.triangles = triangles
+        return render_mesh_frame(triangles.reshape(3 * F_, 3), _identity_faces[key], viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     pc.triangles = triangles
     _, xyz, scaling, rotation, scaling_act, rotation_unit = triangles_to_gaussians(
         triangles, pc._alpha, pc._scale, getattr(pc, "alpha_mode", "relu"), fused_activations=True)

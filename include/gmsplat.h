@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 4   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
+#define GMS_ABI_VERSION 5   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
                              4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset */
 
 /* error codes (negative return values) */
@@ -62,6 +62,7 @@ extern "C" {
  * state) so the caller's caching allocator owns all scratch. */
 typedef void *(*gms_alloc_fn)(void *ctx, size_t bytes);
 
+struct GmsMeshArgs;
 typedef struct GmsRasterForwardArgs {
     /* sizes */
     int32_t P;          /* number of Gaussians */
@@ -117,6 +118,14 @@ typedef struct GmsRasterForwardArgs {
      * the launch was sized for, is INCOMPLETE and the caller must detect it from those counts (games_hip.animate.GraphedAnimation
      * does).  Pass the returned value as num_rendered and binning_capacity, and num_units = 0, to a backward call. */
     int32_t no_host_wait;
+    /* Optional (ABI 5): a forward-only frame rendered straight from a mesh -- the animated render loops of
+     * scripts/render_time_animated.py:68-87 / scripts/render_flame.py:29-60, where every frame moves the vertices and nothing is
+     * differentiated.  When non-NULL the preprocess thread derives its Gaussian from the mesh (barycentric centre, face frame ->
+     * activated scale and unit quaternion, sigmoid opacity: the arithmetic of gms_mesh_to_gaussians_forward with fused_activations,
+     * bit for bit) and `means3D`, `opacities`, `scales`, `rotations` are ignored (may be NULL): the K0 launch and the 84 bytes per
+     * Gaussian it writes disappear.  Needs mesh->P == P, mesh->_opacity, split degree-3 SH storage (shs + shs_rest, M = 16, D = 3)
+     * and no precomputed colours / covariances.  A frame rendered this way cannot be handed to gms_rasterize_backward. */
+    const struct GmsMeshArgs *mesh;
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */
@@ -325,6 +334,11 @@ void gms_profile_enable(int32_t on);
 void gms_profile_reset(void);
 int32_t gms_profile_read(int32_t kernel_id, double *total_ms, int64_t *launches);
 const char *gms_profile_kernel_name(int32_t kernel_id);
+/* Microseconds a bracketing event pair adds to a launch it times (measured on `stream` with a kernel that times itself by the
+ * device's wall clock, averaged over `reps` launches; < 0 on failure).  A launch's own ramp-up and drain are part of that figure,
+ * so durations corrected by it are a lower bound: bench.py subtracts it from every per-kernel average (without it the small kernels
+ * read up to 32 % long and the table sums to more than the step). */
+double gms_profile_event_overhead_us(void *stream, int32_t reps);
 
 /* ---- introspection --------------------------------------------------------------------- */
 /* Host time gms_rasterize_forward spent waiting for the instance count N since the last reset (the one place the
