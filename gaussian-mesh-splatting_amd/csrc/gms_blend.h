@@ -26,8 +26,7 @@ struct BlendGrid {
     uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)
     uint32_t unit_run;             // consecutive units dealt to one XCD (power of two <= 64)
     unsigned long long *dbg_buf;   // GMS_DBG&16: per block {start, end} wall clock (100 MHz), else NULL
-    uint32_t *mlist;               // micro mode: [16 capacity] bytes: entry indices per (unit, 4x4 block), see BinningState
-    uint32_t *mcount;              // micro mode: [units][16]
+    uint16_t *mmask;               // micro mode: [capacity] block masks per instance, see BinningState
 };
 
 struct BlendFwdOut {
@@ -259,7 +258,7 @@ struct Unit {
     uint32_t beg, end;     // this unit's entries [beg, end)
     uint32_t slot0;        // first segment-state slot of the tile (multi-segment tiles)
     uint32_t L;            // this frame's segment length
-    uint32_t idx;          // index of the unit in the unit table (micro mode: row of mcount)
+    uint32_t idx;          // index of the unit in the unit table
 };
 
 // Block -> unit.  The unit table lists full segments (seg_len entries) first, then the tiles' partial last

@@ -103,12 +103,10 @@ struct BinningState {
     float *seg_state;      // [2N/L + 2][7][256]
     uint2 *deep_tab;       // [N/1024 + T + 2] (tile, run): every 1024-key sort run / merge chunk of every tile with >= 2 keys
     uint32_t *multi_tab;   // [N/1024 + 2] tiles with more than one run (they need merging)
-    // micro-tile compositing (blend_micro.hip): per (unit, 4x4 pixel block) the unit's entries whose {alpha >= 1/255} ellipse
-    // touches the block, in list (depth) order, as entry indices within the unit (one byte each: L <= 256).  Block b of the
-    // unit whose entries are [beg, beg + cn) starts at byte 16 beg + b cn: worst-case capacity (every entry in every block) at
-    // a fixed address, no scan; only the lines actually written (~2.3 bytes per entry on mesh scenes) ever move.
-    uint32_t *mlist;       // [16 N] bytes
-    uint32_t *mcount;      // [units][16] entries per (unit, block)
+    // micro-tile compositing (blend_micro.hip): per instance (position in the sorted list) the 16-bit mask of the tile's 4x4 pixel
+    // blocks its {alpha >= 1/255} ellipse touches -- written by the launch that first touches the instance's unit, read by the later
+    // ones, so that every launch builds identical per-block lists.  (Until round 5: 16 bytes of list area per instance + counts.)
+    uint16_t *mmask;       // [N]
     static __host__ __device__ size_t n_units(size_t N, size_t T, size_t L) { return T + N / L + 1; }
     static __host__ __device__ size_t n_slots(size_t N, size_t L) { return 2 * (N / L) + 2; }
     static __host__ __device__ size_t n_deep(size_t N, size_t T) { return N / 1024 + T + 2; }
@@ -117,7 +115,7 @@ struct BinningState {
     {
         return align_up((N > 0 ? N : 1) * 8, 256) + align_up(n_units(N, T, L) * 32, 256) +
                align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256) + align_up(n_deep(N, T) * 8, 256) + align_up(n_multi(N) * 4, 256) +
-               (micro ? align_up((N > 0 ? N : 1) * 16, 256) + align_up(n_units(N, T, L) * 64, 256) : 0);
+               (micro ? align_up((N > 0 ? N : 1) * 2, 256) : 0);
     }
     static __host__ __device__ BinningState carve(void *base, size_t N, size_t T, size_t L)
     {
@@ -128,8 +126,7 @@ struct BinningState {
         b.seg_state = (float *)p;    p += align_up(n_slots(N, L) * 7 * TILE_PIX * 4, 256);
         b.deep_tab = (uint2 *)p;     p += align_up(n_deep(N, T) * 8, 256);
         b.multi_tab = (uint32_t *)p; p += align_up(n_multi(N) * 4, 256);
-        b.mlist = (uint32_t *)p;     p += align_up((N > 0 ? N : 1) * 16, 256);       // (this and the next: present only in micro mode)
-        b.mcount = (uint32_t *)p;
+        b.mmask = (uint16_t *)p;      // (present only in micro mode)
         return b;
     }
 };

@@ -10,9 +10,23 @@ namespace gms {
 constexpr float EPS = 1e-8f;
 
 struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+// (the pragma is lexical: an operator without it would hand its multiply / subtract to the caller WITH the `contract` flag, and
+// `(v - c0 * a) - c1 * b` could then become FMAs in one kernel and not in another)
+__device__ __forceinline__ V3 operator+(V3 a, V3 b)
+{
+#pragma clang fp contract(off)
+    return {a.x + b.x, a.y + b.y, a.z + b.z};
+}
+__device__ __forceinline__ V3 operator-(V3 a, V3 b)
+{
+#pragma clang fp contract(off)
+    return {a.x - b.x, a.y - b.y, a.z - b.z};
+}
+__device__ __forceinline__ V3 operator*(float s, V3 a)
+{
+#pragma clang fp contract(off)
+    return {s * a.x, s * a.y, s * a.z};
+}
 __device__ __forceinline__ float dot(V3 a, V3 b)
 {
 #pragma clang fp contract(off)

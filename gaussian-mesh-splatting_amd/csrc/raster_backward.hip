@@ -551,7 +551,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = cap;
         g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
-        g.mlist = bin.mlist; g.mcount = bin.mcount;
+        g.mmask = bin.mmask;
         BlendBwdArgs b;
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;
         b.dL_dpix = A->dL_dout_color; b.dL_dinvd = A->dL_dout_invdepth; b.accum = A->grad_accum;

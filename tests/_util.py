@@ -317,6 +317,42 @@ def assert_grads(gh, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_f
     return rep
 
 
+def _memo(fn):
+    """Evaluate a lazy oracle (float64 run, float32 realisations, alternate outcomes) at most once across the two legs below."""
+    if fn is None:
+        return None
+    box = []
+
+    def get():
+        if not box:
+            box.append(fn())
+        return box[0]
+    return get
+
+
+def assert_grads_both_modes(run_hip, go, go64_fn=None, q=0.999, where="", excuse=None, go32acc_fn=None, alt=None):
+    """The suite's gradient gate since round 5.  PRIMARY: the kernels in deterministic-reduction mode
+    (no float atomic, fixed summation order) under the STRICT criterion -- K = ADJUDICATE_K_STRICT, not one unexplained entry.
+    SECONDARY: the default mode (float atomics, as the reference's CUDA kernels) under the default criterion, whose two allowances
+    (K = 8, one unexplained entry per million) exist for the atomics' summation order alone.  `run_hip()` renders + differentiates
+    with the current mode and returns a dict with "grads" (it is called once per leg).  Returns (default-mode output, its report)."""
+    import diff_gaussian_rasterization as dgr
+    go64_fn, go32acc_fn = _memo(go64_fn), _memo(go32acc_fn)
+    if alt is not None:
+        alt = (alt[0], _memo(alt[1]))
+    was = dgr.deterministic()
+    dgr.set_deterministic(True)
+    try:
+        h_det = run_hip()
+    finally:
+        dgr.set_deterministic(was)
+    assert_grads(h_det["grads"], go, go64_fn, q=q, where=where + " [deterministic, strict]", excuse=excuse, go32acc_fn=go32acc_fn, alt=alt,
+                 strict=True)
+    h = run_hip()
+    rep = assert_grads(h["grads"], go, go64_fn, q=q, where=where + " [atomics]", excuse=excuse, go32acc_fn=go32acc_fn, alt=alt)
+    return h, rep
+
+
 def _log_parity(where, rep):
     """Append the per-tensor maxima to gpurun_out/parity_report.jsonl (merged back from the GPU box): the numbers
     DESIGN.md quotes for max_rel come from here."""

@@ -23,17 +23,18 @@ def _check(inputs, kw, W, H, gd=True, q=0.999):
     gc = syn.upstream_grad(torch.from_numpy(o["color"])).numpy() * 1000.0
     gdm = np.full((1, H, W), 1e-3, np.float32) if gd else None
     o = U.oracle_render(inputs, kw, gc, gdm)
-    h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=gdm)
+    # gradients: deterministic mode under the strict criterion first, then the default (float atomics) mode under the default one
+    h, g = U.assert_grads_both_modes(lambda: U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=gdm), o["grads"],
+                                     lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f64")["grads"], q=q,
+                                     where=f"P={inputs['means3D'].shape[0]} {W}x{H}", excuse=U.excused_rows(o["details"]),
+                                     go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, gdm),
+                                     alt=U.alt_oracles(inputs, kw, gc, gdm, o["details"]))
     rep = U.forward_report(h, o, W, H)
     assert rep["radii_unexplained"] == 0, rep
     assert rep["amb_frac"] < 0.01, rep
     assert rep["max_clean"] <= RGB_TOL, rep
     assert rep["max_invdepth_clean"] <= RGB_TOL, rep
     assert rep["max_amb"] <= 0.02, rep          # a flipped alpha>=1/255 decision moves a pixel by < 1/255 * max colour
-    g = U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f64")["grads"], q=q,
-                       where=f"P={inputs['means3D'].shape[0]} {W}x{H}", excuse=U.excused_rows(o["details"]),
-                       go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, gdm),
-                       alt=U.alt_oracles(inputs, kw, gc, gdm, o["details"]))
     return h, o, rep, g
 
 
@@ -218,16 +219,16 @@ def test_full_size_parity_with_oracle_through_the_mesh_op():
     loss.backward()
     # ---- HIP
     model = HipGaussianMeshModel.from_scene(scene, "cuda")
-    pkg = render(cam_cpu.to("cuda"), model, PipelineParams(), torch.ones(3, device="cuda"))
-    (pkg["render"] * gc.cuda()).sum().backward()
-    h = dict(color=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(), invdepth=pkg["depth"].detach().cpu().numpy())
-    ora = dict(color=o.color, radii=o.radii, invdepth=o.invdepth, details=o.state.details())
-    # each side ran its own float32 mesh->Gaussian stage: the rasterizer inputs differ by rounding (input_rounding=True)
-    rep = U.forward_report(h, ora, 800, 800, input_rounding=True)
-    assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.02, rep
-    assert rep["psnr"] > 60.0, rep
-    gh = dict(vertices=model.vertices.grad, _alpha=model._alpha.grad, _scale=model._scale.grad, _opacity=model._opacity.grad,
-              f_dc=model._features_dc.grad, f_rest=model._features_rest.grad)
+
+    def run_hip():
+        for p_ in (model.vertices, model._alpha, model._scale, model._opacity, model._features_dc, model._features_rest):
+            p_.grad = None
+        model.update_alpha(); model.prepare_scaling_rot()
+        pkg_ = render(cam_cpu.to("cuda"), model, PipelineParams(), torch.ones(3, device="cuda"))
+        (pkg_["render"] * gc.cuda()).sum().backward()
+        grads = dict(vertices=model.vertices.grad, _alpha=model._alpha.grad, _scale=model._scale.grad, _opacity=model._opacity.grad,
+                     f_dc=model._features_dc.grad, f_rest=model._features_rest.grad)
+        return dict(pkg=pkg_, grads={k: t.detach().cpu().numpy() for k, t in grads.items()})
     go = dict(vertices=v.grad, _alpha=a.grad, _scale=s.grad, _opacity=op_raw.grad, f_dc=fdc.grad, f_rest=frest.grad)
     def f64_chain():
         """the same chain in double precision (float64 K0 restatement + float64 C rasterizer oracle)"""
@@ -242,8 +243,14 @@ def test_full_size_parity_with_oracle_through_the_mesh_op():
          + (sh6 * torch.from_numpy(g6["sh"])).sum()).backward()
         return dict(vertices=v6.grad.numpy(), _alpha=a6.grad.numpy(), _scale=s6.grad.numpy(), _opacity=op6.grad.numpy(),
                     f_dc=fdc6.grad.numpy(), f_rest=frest6.grad.numpy())
-    U.assert_grads({k: t.cpu().numpy() for k, t in gh.items()}, {k: t.numpy() for k, t in go.items()}, f64_chain,
-                   where="c2_hotdog_like 800x800 through K0")
+    hres, _ = U.assert_grads_both_modes(run_hip, {k: t.numpy() for k, t in go.items()}, f64_chain, where="c2_hotdog_like 800x800 through K0")
+    pkg = hres["pkg"]
+    h = dict(color=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(), invdepth=pkg["depth"].detach().cpu().numpy())
+    ora = dict(color=o.color, radii=o.radii, invdepth=o.invdepth, details=o.state.details())
+    # each side ran its own float32 mesh->Gaussian stage: the rasterizer inputs differ by rounding (input_rounding=True)
+    rep = U.forward_report(h, ora, 800, 800, input_rounding=True)
+    assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.02, rep
+    assert rep["psnr"] > 60.0, rep
 
 
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
@@ -590,15 +597,28 @@ def test_config5_size_parity_deep_tiles_two_phase_products():
     det = o["details"]
     depth = int((det["ranges"][:, 1] - det["ranges"][:, 0]).max())
     assert det["N"] > 2 * 256 * (size // 16) ** 2 and depth > 2 * 8192, (det["N"], depth)       # deep path + >= 2 merge-path passes
+    lazy = dict(go64=U._memo(lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"]),
+                go32=U._memo(lambda: U.f32_realisations(inputs, kw, gc, None)))
+    alt = U.alt_oracles(inputs, kw, gc, None, det)
+    alt = (alt[0], U._memo(alt[1]))
+    # PRIMARY gate: deterministic-reduction mode (quadrant kernels, per-(instance, quadrant) partial records), strict criterion
+    import diff_gaussian_rasterization as dgr
+    dgr.set_deterministic(True)
+    try:
+        h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
+    finally:
+        dgr.set_deterministic(False)
+    U.assert_grads(h["grads"], o["grads"], lazy["go64"], where=f"c5_flame_like_1m {size}x{size} [deterministic, strict]", excuse=U.excused_rows(det),
+                   go32acc_fn=lazy["go32"], alt=alt, strict=True)
+    # SECONDARY: the float-atomics mode, three frames (no history / hints / hints)
     for frame in range(3):
         h = U.hip_render(inputs, kw, grad_color=gc, grad_invdepth=None)
         rep = U.forward_report(h, o, size, size)
         assert rep["radii_unexplained"] == 0 and rep["max_clean"] <= RGB_TOL and rep["amb_frac"] < 0.01 and rep["max_amb"] <= 0.02, (frame, rep)
         assert last_stats()["num_rendered"] == det["N"]
-        U.assert_grads(h["grads"], o["grads"], lambda: U.oracle_render(inputs, kw, gc, None, precision="f64")["grads"],
-                       where=f"c5_flame_like_1m {size}x{size} frame {frame}", excuse=U.excused_rows(det),
-                       go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, None),
-                       alt=U.alt_oracles(inputs, kw, gc, None, det))
+        U.assert_grads(h["grads"], o["grads"], lazy["go64"],
+                       where=f"c5_flame_like_1m {size}x{size} frame {frame} [atomics]", excuse=U.excused_rows(det),
+                       go32acc_fn=lazy["go32"], alt=alt)
         assert float(U.excused_rows(det).mean()) < 0.02
     # (3) K0 backward at this size, upstream = the oracle's rasterizer gradients
     og = o["grads"]

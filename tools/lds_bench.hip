@@ -45,6 +45,9 @@ __global__ void __launch_bounds__(256) bench(float *out, unsigned long long *cyc
         if (MODE == 10) { if (alane) { const float o = table[e * 10 + field]; table[e * 10 + field] = o + y; } }  // read-add-write without atomicity
         if (MODE == 11) { if (li < 10) atomicAdd(&table[e * 10 + li], y); }                                    // 40 lanes, consecutive fields (lanes 0-9 of a row)
         if (MODE == 12) { if (li < 10) atomicAdd(&table[e * 16 + li], y); }                                    // ... 64-byte entries (would need 16 KB)
+        if (MODE == 13) { if (alane) atomicAdd(reinterpret_cast<unsigned int *>(table) + e * 10 + field, (unsigned int)li + 1u); }        // ds_add_u32, 40 lanes
+        if (MODE == 14) { if (alane) atomicAdd(reinterpret_cast<unsigned long long *>(table) + (e & 127u) * 10 + field, (unsigned long long)li + 1ull); }   // ds_add_u64, 40 lanes
+        if (MODE == 15) { if (alane) atomicMax(reinterpret_cast<int *>(table) + e * 10 + field, (int)li + it); }                         // ds_max_i32, 40 lanes
     }
     const unsigned long long t1 = clock64();
     if (lane == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
@@ -92,5 +95,8 @@ int main()
     run<10>("10 ds_read + add + ds_write (no atomicity)", out, cyc, blocks);
     run<11>("11 ds_add_f32, lanes 0-9 of each row on consecutive fields", out, cyc, blocks);
     run<12>("12 ... with 64-byte table entries", out, cyc, blocks);
+    run<13>("13 ds_add_u32, 4 rows x 10 lanes", out, cyc, blocks);
+    run<14>("14 ds_add_u64, 4 rows x 10 lanes", out, cyc, blocks);
+    run<15>("15 ds_max_i32, 4 rows x 10 lanes", out, cyc, blocks);
     return 0;
 }
