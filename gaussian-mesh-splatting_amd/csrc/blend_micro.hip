@@ -518,6 +518,8 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
                     if (row == r && alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
                     asm volatile("" ::: "memory");          // four separate LDS instructions, in row order
                 }
+            } else if (dbg_on(g, 2048u)) {        // (timing experiment, wrong results: an INTEGER LDS atomic in place of the float one)
+                if (alane && y != 0.f) atomicAdd(reinterpret_cast<unsigned int *>(table) + se[e] * 10u + (uint32_t)afield, __float_as_uint(y));
             } else if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
         }
     }
@@ -586,7 +588,9 @@ int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);
-        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
+        static int lds_pad = -1;            // (make EXPERIMENTS=1 only) GMS_LDS_PAD: bytes of unused dynamic LDS per block, to time other occupancies
+        if (lds_pad < 0) { const char *e = getenv("GMS_LDS_PAD"); lds_pad = (GMS_EXPERIMENTS && e) ? atoi(e) : 0; }
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, (size_t)lds_pad, stream>>>(g, a));
     }
     GMS_KERNEL_CHECK(debug, stream, "micro_bwd");
     return GMS_OK;
