@@ -183,14 +183,22 @@ __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, 
 }
 
 // ------------------------------------------------------------------------------------ the unit, resident in LDS
-struct UnitRecs {
+template <bool WITHD> struct RecTail { using type = float2; };          // b, 1/depth
+template <> struct RecTail<false> { using type = float; };              // b alone (the backward without an inverse-depth gradient)
+__device__ __forceinline__ void set_tail(float2 &d, float b, float invd) { d = make_float2(b, invd); }
+__device__ __forceinline__ void set_tail(float &d, float b, float) { d = b; }
+__device__ __forceinline__ float2 get_tail(const float2 &d) { return d; }
+__device__ __forceinline__ float2 get_tail(const float &d) { return make_float2(d, 0.f); }
+template <bool WITHD>
+struct UnitRecsT {
     float4 ra[LMAX];           // pix.x, pix.y, conic A, conic B
     float4 rb[LMAX];           // conic C, opacity', r, g
-    float2 rc[LMAX];           // b, 1/depth
+    typename RecTail<WITHD>::type rc[LMAX];
     uint8_t list[16][LMAX];    // per 4x4 block: the entries that reach it, in list (depth) order
     uint32_t order[16], ocnt[16];
     uint32_t wcnt[4][16];
 };
+using UnitRecs = UnitRecsT<true>;
 
 template <int NE> __device__ __forceinline__ uint32_t list_load(const uint8_t *lst, uint32_t pos);
 template <> __device__ __forceinline__ uint32_t list_load<1>(const uint8_t *lst, uint32_t pos) { return lst[pos]; }
@@ -200,23 +208,31 @@ template <> __device__ __forceinline__ uint32_t list_load<4>(const uint8_t *lst,
 // Staging.  FILTER = this launch is the first to touch the unit: the thread of an entry computes the entry's block mask from the
 // record it has just gathered and leaves it in global memory (g.mmask) for the later launches, which read
 // it back instead -- every launch therefore builds IDENTICAL lists (n_contrib holds positions in them).
-template <bool FILTER>
-__device__ __forceinline__ void unit_stage(const BlendGrid &g, const Unit &u, UnitRecs &S, const SplatRec *rec, uint32_t *uid)
+// `cmax_out` (forward launches): the largest |colour component| of the unit's splats is folded into the tile's maximum
+// (ImageState::tile_cmax; one integer atomic per wave), which the backward needs to bound the colour behind a splat.
+// Returns the Gaussian id of the thread's entry.
+template <bool FILTER, bool WITHD>
+__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD> &S, const SplatRec *rec, uint32_t *cmax_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
     uint16_t *mm = g.mmask;
-    uint32_t mask = 0;
+    uint32_t mask = 0, id = 0;
+    float cm = 0.f;
     if ((uint32_t)tid < cn) {
-        const uint32_t id = reinterpret_cast<const uint32_t *>(g.keys)[2 * (size_t)(u.beg + tid)];      // low word of the (depth, id) key
+        id = reinterpret_cast<const uint32_t *>(g.keys)[2 * (size_t)(u.beg + tid)];      // low word of the (depth, id) key
         if (!FILTER) mask = mm[u.beg + tid];
         const SplatRec r = rec[id];
         if (FILTER) { mask = block_mask(r, (float)(u.tx * TILE), (float)(u.ty * TILE)); mm[u.beg + tid] = (uint16_t)mask; }
-        S.ra[tid] = r.q0; S.rb[tid] = r.q1; S.rc[tid] = make_float2(r.q2.x, r.q2.y);
-        if (uid) uid[tid] = id;
+        S.ra[tid] = r.q0; S.rb[tid] = r.q1; set_tail(S.rc[tid], r.q2.x, r.q2.y);
+        cm = fmaxf(fmaxf(fabsf(r.q1.z), fabsf(r.q1.w)), fabsf(r.q2.x));
     } else {
         // a row that idles behind the end of its list reads whatever byte lies there: every record it can name must be finite
-        S.ra[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rb[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rc[tid] = make_float2(0.f, 0.f);
+        S.ra[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rb[tid] = make_float4(0.f, 0.f, 0.f, 0.f); set_tail(S.rc[tid], 0.f, 0.f);
+    }
+    if (cmax_out) {
+        for (int d = 32; d >= 1; d >>= 1) cm = fmaxf(cm, __shfl_xor(cm, d));
+        if (lane == 0 && cm > 0.f) atomicMax(cmax_out, __float_as_uint(cm));         // (non-negative floats order like their bits)
     }
     uint32_t mycnt = 0;                        // lane b < 16: hits of block b among this wave's 64 entries
 #pragma unroll
@@ -247,6 +263,7 @@ __device__ __forceinline__ void unit_stage(const BlendGrid &g, const Unit &u, Un
         S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
     }
     __syncthreads();
+    return id;
 }
 
 template <int NE>
@@ -374,7 +391,7 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
         g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + threadIdx.x] = 0.f;
         return;
     }
-    unit_stage<true>(g, u, S, o.rec, nullptr);
+    unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, q);
     else micro_tloc_unit<NE>(g, u, S, phase, q);
@@ -387,33 +404,122 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
-    if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, nullptr);       // last segments are first touched here
-    else unit_stage<false>(g, u, S, o.rec, nullptr);                          // middle segments: filtered by the first launch
+    if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);       // last segments are first touched here
+    else unit_stage<false>(g, u, S, o.rec, g.tile_cmax + u.tile);                          // middle segments: filtered by the first launch
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     micro_fwd_unit<NE>(g, o, u, S, q);
 }
 
+// ------------------------------------------------------------------------------------ fixed-point gradient table (round 5)
+// An LDS float atomic costs ~2.7 cycles PER ACTIVE LANE on MI355X; an integer one runs at the rate of a plain store (tools/lds_bench.hip:
+// ds_add_f32 on 4 rows x 10 lanes 45 ns per CU, ds_add_u64 3.3 ns).  The backward issues 16.6 M lane-adds per frame, so the unit's
+// gradient table holds 64-bit FIXED-POINT sums: a partial sum y of field f of entry e is added as round(y * 2^(58 - E)) with an
+// exponent E fixed per (entry, field) BEFORE any add -- |y| <= 2^E -- so the sum is exact to 2^(E-59) per add, independent of the
+// order of the adds (deterministic), and cannot overflow (at most 16 adds of magnitude <= 2^58).  The bound, for the sum over a 4x4
+// block's 16 pixels (gms_blend.h::bwd_step): |q| = |G op dL/dalpha| <= op_e ((Cmax + |bg|max) D1 + 5 Dd), where Cmax is the largest
+// |colour component| of the tile's splats (the colour behind a splat is a convex combination of those: ImageState::tile_cmax, raised
+// by the forward launches), D1 / Dd the tile's largest sum_c |dL/dpixel_c| / |dL/dinvdepth|, 1/depth <= 1/0.2, T <= 1 and
+// Tfinal / (1 - alpha) <= T; |dx| <= X_e, |dy| <= Y_e from the entry's centre and the tile's corners; the colour weights w <= 1.  A
+// factor 2 covers the rounding of T and of the colour behind.  The bounds are loose by many orders of magnitude on purpose: a value
+// 2^34 below its bound still carries 24 bits, and what lies further below is under the 1e-6 floor of the parity criterion.
+constexpr int FX_SHIFT = 58;
+
+// x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
+__device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
+
+// round(y * 2^(FX_SHIFT - E)) in integer arithmetic, for |y| <= 2^E
+__device__ __forceinline__ long long fx_from_float(float y, int E)
+{
+    const uint32_t b = __float_as_uint(y);
+    const int ef = (int)((b >> 23) & 0xffu);
+    const uint32_t man = (b & 0x7fffffu) | (ef ? 0x800000u : 0u);      // y = +- man * 2^(max(ef, 1) - 150)
+    int s = max(ef, 1) - 150 + FX_SHIFT - E;
+    s = min(s, 38);          // (|y| <= 2^E keeps s <= 35: the clamp only keeps a violated bound from wrapping around)
+    long long v;
+    if (s >= 0) v = (long long)((unsigned long long)man << s);
+    else {
+        const int r = -s;            // round to nearest, ties away from zero
+        v = r > 25 ? 0ll : (long long)(((unsigned long long)man + (1ull << (r - 1))) >> r);
+    }
+    return (b >> 31) ? -v : v;
+}
+
+// (exact in double, one rounding to float)
+__device__ __forceinline__ float fx_to_float(long long v, int E) { return (float)ldexp((double)v, E - FX_SHIFT); }
+
+// exponent of field `f` (GRAD_*) of an entry with centre (px, py) and opacity op in the tile at (tx0, ty0)
+struct FxTile { int eK, eCol, eId; float tx0, ty0; };
+__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind, float px, float py, float op)
+{
+    if (kind == 1) return t.eCol;
+    if (kind == 2) return t.eId;
+    const int ex = fx_exp(fmaxf(fabsf(px - t.tx0), fabsf(px - t.tx0 - 15.f)) + 1.f);
+    const int ey = fx_exp(fmaxf(fabsf(py - t.ty0), fabsf(py - t.ty0 - 15.f)) + 1.f);
+    return t.eK + fx_exp(fabsf(op)) + cx * ex + cy * ey;
+}
+// field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
+__device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
+{
+    cx = f == GRAD_MX || f == GRAD_CB ? 1 : (f == GRAD_CA ? 2 : 0);
+    cy = f == GRAD_MY || f == GRAD_CB ? 1 : (f == GRAD_CC ? 2 : 0);
+    kind = f == GRAD_ID ? 2 : (f >= GRAD_R && f <= GRAD_B ? 1 : 0);
+}
+
 // Backward.  The rows of a wave are aligned at the BOTTOM of their lists: global trip position `pos` is the same list index
 // for every row (rows whose list ends below it idle), so a trip's entry bytes are one aligned LDS read per NE entries.
-template <bool INVD, int NE, int FAULT, bool DET = false>
+// FIXED (default): the gradient table is 64-bit fixed point (above), integer LDS atomics.  DET (deterministic mode, gmsplat.h): one
+// float table per WAVE, the four rows of a wave add one after the other, the flush sums the four tables in wave-group order into ONE
+// partial record per instance, stored -- not added -- at the instance's position in the sorted list.
+template <bool INVD, int NE, int FAULT, bool DET = false, bool FIXED = true>
 __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    __shared__ UnitRecs S;
-    __shared__ uint32_t uid[LMAX];
-    __shared__ float table_all[(DET ? 4 : 1) * LMAX * 10];
+    static_assert(!(DET && FIXED), "the deterministic mode keeps its per-wave float tables");
+    constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
+    __shared__ UnitRecsT<INVD> S;
+    __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : (DET ? 4 : 1) * LMAX * 10 * 4];
+    __shared__ uint32_t tile_d1, tile_dd;                   // FIXED: bits of the tile's largest sum_c |dL/dpixel_c| and |dL/dinvdepth|
+    long long *const fxt = reinterpret_cast<long long *>(table_mem);
+    float *const table_all = reinterpret_cast<float *>(table_mem);
+    uint32_t *const uid = reinterpret_cast<uint32_t *>(S.rc);          // (written after the walks: the tails are dead by then)
     Phases ph(g);
     ph.mark(0);
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
-    for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
-    unit_stage<false>(g, u, S, a.rec, uid);                  // (its barriers also order the table clear)
+    const size_t HW = (size_t)g.W * g.H;
+    if (FIXED) {
+        for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
+        if (threadIdx.x == 0) { tile_d1 = 0u; tile_dd = 0u; }
+    } else {
+        for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
+    }
+    float my_d1 = 0.f, my_dd = 0.f;
+    if (FIXED) {          // pixel threadIdx.x of the tile, in raster order: only the maxima matter here
+        const int xi = u.tx * TILE + (int)(threadIdx.x & 15), yi = u.ty * TILE + (int)(threadIdx.x >> 4);
+        if (xi < g.W && yi < g.H) {
+            const size_t pd = (size_t)yi * g.W + xi;
+            my_d1 = (fabsf(a.dL_dpix[pd]) + fabsf(a.dL_dpix[HW + pd])) + fabsf(a.dL_dpix[2 * HW + pd]);
+            if (INVD) my_dd = fabsf(a.dL_dinvd[pd]);
+        }
+    }
+    const uint32_t my_id = unit_stage<false, INVD>(g, u, S, a.rec, nullptr);          // (its barriers also order the table clear)
     ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     float *const table = table_all + (DET ? q * LMAX * 10 : 0);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    FxTile fx = {0, 0, 0, (float)(u.tx * TILE), (float)(u.ty * TILE)};
+    if (FIXED) {
+        for (int d = 32; d >= 1; d >>= 1) { my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d)); }
+        if (lane == 0) { atomicMax(&tile_d1, __float_as_uint(my_d1)); if (INVD) atomicMax(&tile_dd, __float_as_uint(my_dd)); }
+        __syncthreads();
+        const float D1 = __uint_as_float(tile_d1), Dd = INVD ? __uint_as_float(tile_dd) : 0.f;
+        const float cmax = __uint_as_float(g.tile_cmax[u.tile]);
+        const float bgm = fmaxf(fmaxf(fabsf(a.bg[0]), fabsf(a.bg[1])), fabsf(a.bg[2]));
+        fx.eK = fx_exp(32.f * ((cmax + bgm) * D1 + 5.f * Dd));
+        fx.eCol = fx_exp(32.f * D1);
+        fx.eId = fx_exp(32.f * Dd);
+    }
     const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
-    const size_t HW = (size_t)g.W * g.H;
     const size_t pid = (size_t)p.yi * g.W + p.xi;
     const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
     const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
@@ -484,18 +590,21 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     default: afield = GRAD_G; break;       // lane 9
     }
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
+    int fcx, fcy, fkind;
+    fx_field_kind(afield, fcx, fcy, fkind);
 
     // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
     for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
         const uint32_t ep = list_load<NE>(lst, (uint32_t)g0);
-        bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE]; float2 r2[NE]; uint32_t se[NE];
+        bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE]; float2 r2[NE]; uint32_t se[NE]; float cpx[NE], cpy[NE];
         bool anyact = false;
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t pos = (uint32_t)g0 + (uint32_t)(NE - 1 - e);          // descending within the trip
             se[e] = (ep >> (8 * (NE - 1 - e))) & 0xffu;
             const float4 r0 = S.ra[se[e]];
-            r1[e] = S.rb[se[e]]; r2[e] = S.rc[se[e]];
+            r1[e] = S.rb[se[e]]; r2[e] = get_tail(S.rc[se[e]]);
+            cpx[e] = r0.x; cpy[e] = r0.y;
             dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
             const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
             G[e] = __expf(pw);
@@ -512,14 +621,18 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             bwd_step<INVD>(st8, act[e], r1[e], q2, dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
             const float y = row_reduce10(v, b3, b2, b1, b0);
             // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
-            if (DET) {
+            if (FIXED) {
+                if (alane && y != 0.f) {
+                    const int E = fx_field_exp(fx, fcx, fcy, fkind, cpx[e], cpy[e], r1[e].y);
+                    const long long val = dbg_on(g, 2048u) ? (long long)__float_as_uint(y) : fx_from_float(y, E);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)val);
+                }
+            } else if (DET) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     if (row == r && alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
                     asm volatile("" ::: "memory");          // four separate LDS instructions, in row order
                 }
-            } else if (dbg_on(g, 2048u)) {        // (timing experiment, wrong results: an INTEGER LDS atomic in place of the float one)
-                if (alane && y != 0.f) atomicAdd(reinterpret_cast<unsigned int *>(table) + se[e] * 10u + (uint32_t)afield, __float_as_uint(y));
             } else if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
         }
     }
@@ -527,15 +640,28 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     ph.mark(3);
     __syncthreads();
     ph.mark(4);
+    if ((uint32_t)threadIdx.x < cn) uid[threadIdx.x] = my_id;          // (over the record tails, which no walk reads any more)
+    __syncthreads();
     // flush: sixteen entries per step, ten lanes per entry on the ten fields of its 64-byte record (one cache line)
     {
         const int f = threadIdx.x & 15;
+        int cx, cy, kind;
+        fx_field_kind(f, cx, cy, kind);
         for (uint32_t e = threadIdx.x >> 4; e < cn; e += BLOCK / 16) {
             if (DET) {
                 // every instance of the unit gets its record (zeros included: the buffer is not cleared between frames)
                 const uint32_t k = e * 10u + (uint32_t)f;
                 const float y = f < 10 ? ((table_all[k] + table_all[LMAX * 10 + k]) + table_all[2 * LMAX * 10 + k]) + table_all[3 * LMAX * 10 + k] : 0.f;
                 a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] = y;
+            } else if (FIXED) {
+                if (f < NF) {
+                    const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
+                    if (sv != 0ll) {
+                        const float4 r0 = S.ra[e];
+                        const float y = fx_to_float(sv, fx_field_exp(fx, cx, cy, kind, r0.x, r0.y, S.rb[e].y));
+                        unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, y);
+                    }
+                }
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];
                 if (y != 0.f) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, y);
@@ -579,11 +705,16 @@ int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     static int trip = -1;
     if (trip < 0) { const char *e = getenv("GMS_TRIP_BWD"); trip = e ? atoi(e) : 2; }
     const bool invd = a.has_invd && a.dL_dinvd;
+    static int fixed = -1;              // GMS_BWD_FIXED=0: the float LDS table of rounds 3-4 (ds_add_f32) instead of the 64-bit fixed-point one
+    if (fixed < 0) { const char *e = getenv("GMS_BWD_FIXED"); fixed = e ? (atoi(e) != 0) : 1; }
     if (a.part) {                           // deterministic mode (gmsplat.h): per-wave tables, ordered adds, per-instance partial records
-        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
-        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true, false><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true, false><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
+    } else if (!fixed) {
+        auto kern = invd ? micro_bwd_kernel<true, 2, 0, false, false> : micro_bwd_kernel<false, 2, 0, false, false>;
+        GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     } else {
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)

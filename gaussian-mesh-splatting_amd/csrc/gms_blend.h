@@ -21,6 +21,7 @@ struct BlendGrid {
     const uint64_t *keys;          // sorted (depth, id) keys
     float *seg_state;              // [slots][SEG_FIELDS][256]
     uint32_t *tile_dead;           // [T] set by the tloc check: every pixel finished within the first segments
+    uint32_t *tile_cmax;           // [T] micro mode: bits of the largest |colour component| of the tile's splats (ImageState)
     uint64_t capacity;             // instances the binning buffer can hold
     uint32_t max_units;            // entries of unit_tile
     uint32_t dbg;                  // experiment switches (env GMS_DBG; 0 in production)

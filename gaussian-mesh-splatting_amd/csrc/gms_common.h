@@ -69,12 +69,15 @@ struct ImageState {
     uint32_t *class_first;  // [8][T+1] exclusive scans per dispatch class (full, 4 partial size classes, empty), of the
                             //          1024-key sort runs of every tile (row 6) and of the tiles with more than one run (row 7)
     uint32_t *tile_dead;    // [T]     all pixels of the tile finished within the first few segments
+    uint32_t *tile_cmax;    // [T]     bits of the largest |colour component| among the tile's splats (cleared by preprocess_fwd, raised by
+                            //          the forward micro-tile launches that stage the tile's units): bounds the colour behind any splat in
+                            //          the backward's fixed-point gradient table (blend_micro.hip)
     uint32_t *scan_out;     // [4]     {N, deepest tile, work units} of this frame, for the launch that publishes them to the host
     static __host__ __device__ size_t bytes(size_t W, size_t H)
     {
         size_t T = ((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
         return 2 * align_up(W * H * 4, 256) + 2 * align_up(T * 4, 256) + 3 * align_up((T + 1) * 4, 256) +
-               align_up(8 * (T + 1) * 4, 256) + align_up(T * 4, 256) + 256;
+               align_up(8 * (T + 1) * 4, 256) + 2 * align_up(T * 4, 256) + 256;
     }
     static __host__ __device__ ImageState carve(void *base, size_t W, size_t H)
     {
@@ -90,6 +93,7 @@ struct ImageState {
         s.mseg_first = (uint32_t *)p;  p += align_up((T + 1) * 4, 256);
         s.class_first = (uint32_t *)p; p += align_up(8 * (T + 1) * 4, 256);
         s.tile_dead = (uint32_t *)p;   p += align_up(T * 4, 256);
+        s.tile_cmax = (uint32_t *)p;   p += align_up(T * 4, 256);
         s.scan_out = (uint32_t *)p;
         return s;
     }

@@ -550,7 +550,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
         g.seg_state = bin.seg_state; g.capacity = cap;
-        g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
+        g.max_units = (uint32_t)BinningState::n_units((size_t)cap, (size_t)T, L); g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead; g.tile_cmax = img.tile_cmax;
         g.mmask = bin.mmask;
         BlendBwdArgs b;
         b.rec = geom.rec; b.bg = A->background; b.final_T = img.final_T; b.n_contrib = img.n_contrib;

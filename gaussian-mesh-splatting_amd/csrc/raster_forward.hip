@@ -61,6 +61,7 @@ struct PreArgs {
     GeomState geom;
     uint32_t *tile_count;
     uint32_t *zero_cursor;   // [T] emit cursors, cleared here when the frame takes the inline-scan emit (else NULL: tile_scan clears them)
+    uint32_t *zero_cmax;     // [T] per-tile colour maxima (ImageState::tile_cmax), cleared here for the micro-tile launches of this frame
     int T;
     GmsMeshArgs mesh;        // K0 instantiation only: centre / scale / rotation / opacity are derived from the mesh in the thread
 };
@@ -149,6 +150,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     const bool valid = i < a.P;
     if (MODE != 2 && a.zero_cursor)
         for (int q = i; q < a.T; q += (int)gridDim.x * BLOCK) a.zero_cursor[q] = 0u;
+    if (MODE != 2 && a.zero_cmax)
+        for (int q = i; q < a.T; q += (int)gridDim.x * BLOCK) a.zero_cmax[q] = 0u;
 
     // Fast path: every global load of this thread is issued before anything is computed, so the
     // position / scale / rotation / opacity / SH round trips overlap instead of chaining.
@@ -1566,6 +1569,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const bool inline_scan = inline_env && A->binning_capacity_hint > 0 && frame_L_pre != 0 && T <= INLINE_SCAN_MAX_T &&
                              (P + BLOCK - 1) / BLOCK <= 1536;
     pa.zero_cursor = inline_scan ? img.tile_cursor : nullptr; pa.T = T;
+    pa.zero_cmax = micro_mode() ? img.tile_cmax : nullptr;
     const unsigned pblocks = (unsigned)((P + BLOCK - 1) / BLOCK);
     const bool split = A->shs_rest != nullptr;
     const bool sh_fast = A->shs && A->M == 16 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
@@ -1707,7 +1711,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;
         g.unit_first = img.unit_first; g.mseg_first = img.mseg_first; g.unit_tile = bin.unit_tile; g.keys = bin.keys;
-        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead;
+        g.seg_state = bin.seg_state; g.capacity = capacity; g.max_units = mu; g.dbg = 0; g.unit_run = unit_run(); g.dbg_buf = nullptr; g.tile_dead = img.tile_dead; g.tile_cmax = img.tile_cmax;
         g.mmask = bin.mmask;
         if (aux) GMS_HIP_CHECK(hipStreamWaitEvent(stream, aux->join, 0));      // the colours (second stream) before the compositing
         t_last_used_micro = use_micro(capacity, T) ? 1 : 0;
