@@ -195,8 +195,9 @@ struct UnitRecsT {
     float4 rb[LMAX];           // conic C, opacity', r, g
     typename RecTail<WITHD>::type rc[LMAX];
     uint8_t list[16][LMAX];    // per 4x4 block: the entries that reach it, in list (depth) order
-    uint32_t order[16], ocnt[16];
-    uint32_t wcnt[4][16];
+    uint16_t ocnt[16];         // list lengths, longest first
+    uint8_t order[16];         // ... and whose they are
+    uint8_t wcnt[4][16];       // staging: a wave's hits per block (<= 64)
 };
 using UnitRecs = UnitRecsT<true>;
 
@@ -240,7 +241,7 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
         const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((mask >> b) & 1u));
         if (lane == b) mycnt = n;
     }
-    if (lane < 16) S.wcnt[wave][lane] = mycnt;
+    if (lane < 16) S.wcnt[wave][lane] = (uint8_t)mycnt;
     __syncthreads();
     const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -253,14 +254,14 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
         }
     }
     if (tid < 16) {
-        const uint32_t c = S.wcnt[0][tid] + S.wcnt[1][tid] + S.wcnt[2][tid] + S.wcnt[3][tid];
+        const uint32_t c = (uint32_t)S.wcnt[0][tid] + S.wcnt[1][tid] + S.wcnt[2][tid] + S.wcnt[3][tid];
         uint32_t rank = 0;
 #pragma unroll
         for (int s0 = 0; s0 < 16; s0++) {
             const uint32_t cs = (uint32_t)__shfl((int)c, s0);
             rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
         }
-        S.order[rank] = (uint32_t)tid; S.ocnt[rank] = c;
+        S.order[rank] = (uint8_t)tid; S.ocnt[rank] = (uint16_t)c;
     }
     __syncthreads();
     return id;
@@ -419,43 +420,40 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // block's 16 pixels (gms_blend.h::bwd_step): |q| = |G op dL/dalpha| <= op_e ((Cmax + |bg|max) D1 + 5 Dd), where Cmax is the largest
 // |colour component| of the tile's splats (the colour behind a splat is a convex combination of those: ImageState::tile_cmax, raised
 // by the forward launches), D1 / Dd the tile's largest sum_c |dL/dpixel_c| / |dL/dinvdepth|, 1/depth <= 1/0.2, T <= 1 and
-// Tfinal / (1 - alpha) <= T; |dx| <= X_e, |dy| <= Y_e from the entry's centre and the tile's corners; the colour weights w <= 1.  A
-// factor 2 covers the rounding of T and of the colour behind.  The bounds are loose by many orders of magnitude on purpose: a value
-// 2^34 below its bound still carries 24 bits, and what lies further below is under the 1e-6 floor of the parity criterion.
+// Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; op_e <= the unit's
+// largest opacity; the colour weights w <= 1.  A factor 2 covers the rounding of T and of the colour behind.  Every bound is taken over
+// the whole UNIT, so a field's exponent is one number per unit -- a constant of the lane that holds the field -- and the walks pay
+// for nothing but the conversion (~12 integer VALU per entry; per-entry exponents were measured first: 189 us, the exponent arithmetic
+// and 18 KB more LDS cost more than the atomics saved).  The bounds are loose by many orders of magnitude on purpose: a value 2^34
+// below its bound still carries 24 bits, and what lies further below is under the 1e-6 floor of the parity criterion.
 constexpr int FX_SHIFT = 58;
 
 // x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
 __device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
 
-// round(y * 2^(FX_SHIFT - E)) in integer arithmetic, for |y| <= 2^E
-__device__ __forceinline__ long long fx_from_float(float y, int E)
+// round(y * 2^(FX_SHIFT - E)) in integer arithmetic, for |y| <= 2^E; `bias` = 150 - FX_SHIFT + E (a constant of the lane)
+__device__ __forceinline__ long long fx_from_float(float y, int bias)
 {
     const uint32_t b = __float_as_uint(y);
     const int ef = (int)((b >> 23) & 0xffu);
-    const uint32_t man = (b & 0x7fffffu) | (ef ? 0x800000u : 0u);      // y = +- man * 2^(max(ef, 1) - 150)
-    int s = max(ef, 1) - 150 + FX_SHIFT - E;
-    s = min(s, 38);          // (|y| <= 2^E keeps s <= 35: the clamp only keeps a violated bound from wrapping around)
-    long long v;
-    if (s >= 0) v = (long long)((unsigned long long)man << s);
-    else {
-        const int r = -s;            // round to nearest, ties away from zero
-        v = r > 25 ? 0ll : (long long)(((unsigned long long)man + (1ull << (r - 1))) >> r);
-    }
-    return (b >> 31) ? -v : v;
+    const unsigned long long man = (unsigned long long)((b & 0x7fffffu) | (ef ? 0x800000u : 0u));      // y = +- man * 2^(max(ef, 1) - 150)
+    // left shift by s = max(ef, 1) - bias when that is >= 0 (|y| <= 2^E keeps s <= 35; 38 only keeps a violated bound from wrapping),
+    // else a rounding right shift by -s: the mantissa is pre-shifted left by 26, so ONE right shift by 26 - s covers both
+    const int sh = 26 - min(max(ef, 1) - bias, 38);                    // >= -12
+    const unsigned long long wide = man << 26;                          // < 2^50
+    const unsigned long long v = sh <= 0 ? wide << (-sh) : (sh > 52 ? 0ull : (wide + (1ull << (sh - 1))) >> sh);
+    return (b >> 31) ? -(long long)v : (long long)v;
 }
 
 // (exact in double, one rounding to float)
 __device__ __forceinline__ float fx_to_float(long long v, int E) { return (float)ldexp((double)v, E - FX_SHIFT); }
 
-// exponent of field `f` (GRAD_*) of an entry with centre (px, py) and opacity op in the tile at (tx0, ty0)
-struct FxTile { int eK, eCol, eId; float tx0, ty0; };
-__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind, float px, float py, float op)
+// exponents of one unit: every bound is taken over the whole unit (largest opacity, largest centre-to-corner distances), so a field's
+// exponent is ONE number per unit -- nothing per entry in the walks
+struct FxTile { int eK, eOp, eX, eY, eCol, eId; };
+__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind)
 {
-    if (kind == 1) return t.eCol;
-    if (kind == 2) return t.eId;
-    const int ex = fx_exp(fmaxf(fabsf(px - t.tx0), fabsf(px - t.tx0 - 15.f)) + 1.f);
-    const int ey = fx_exp(fmaxf(fabsf(py - t.ty0), fabsf(py - t.ty0 - 15.f)) + 1.f);
-    return t.eK + fx_exp(fabsf(op)) + cx * ex + cy * ey;
+    return kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + t.eOp + cx * t.eX + cy * t.eY);
 }
 // field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
 __device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
@@ -477,7 +475,8 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
     __shared__ UnitRecsT<INVD> S;
     __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : (DET ? 4 : 1) * LMAX * 10 * 4];
-    __shared__ uint32_t tile_d1, tile_dd;                   // FIXED: bits of the tile's largest sum_c |dL/dpixel_c| and |dL/dinvdepth|
+    __shared__ uint32_t tile_max[5];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|, |opacity|,
+                                                            //        centre-to-corner distances in x and in y
     long long *const fxt = reinterpret_cast<long long *>(table_mem);
     float *const table_all = reinterpret_cast<float *>(table_mem);
     uint32_t *const uid = reinterpret_cast<uint32_t *>(S.rc);          // (written after the walks: the tails are dead by then)
@@ -489,7 +488,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const size_t HW = (size_t)g.W * g.H;
     if (FIXED) {
         for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
-        if (threadIdx.x == 0) { tile_d1 = 0u; tile_dd = 0u; }
+        if (threadIdx.x < 5) tile_max[threadIdx.x] = 0u;
     } else {
         for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     }
@@ -507,15 +506,30 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     float *const table = table_all + (DET ? q * LMAX * 10 : 0);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    FxTile fx = {0, 0, 0, (float)(u.tx * TILE), (float)(u.ty * TILE)};
+    FxTile fx = {0, 0, 0, 0, 0, 0};
     if (FIXED) {
-        for (int d = 32; d >= 1; d >>= 1) { my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d)); }
-        if (lane == 0) { atomicMax(&tile_d1, __float_as_uint(my_d1)); if (INVD) atomicMax(&tile_dd, __float_as_uint(my_dd)); }
+        // the unit's largest opacity and centre-to-corner distances (entry threadIdx.x; the records behind the unit's end are zero)
+        const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
+        const float4 mine = S.ra[threadIdx.x];
+        float my_op = fabsf(S.rb[threadIdx.x].y);
+        float my_x = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f;
+        float my_y = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f;
+        for (int d = 32; d >= 1; d >>= 1) {
+            my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d)); my_op = fmaxf(my_op, __shfl_xor(my_op, d));
+            my_x = fmaxf(my_x, __shfl_xor(my_x, d)); my_y = fmaxf(my_y, __shfl_xor(my_y, d));
+        }
+        if (lane == 0) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
+            atomicMax(&tile_max[0], __float_as_uint(my_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(my_dd));
+            atomicMax(&tile_max[2], __float_as_uint(my_op)); atomicMax(&tile_max[3], __float_as_uint(my_x)); atomicMax(&tile_max[4], __float_as_uint(my_y));
+        }
         __syncthreads();
-        const float D1 = __uint_as_float(tile_d1), Dd = INVD ? __uint_as_float(tile_dd) : 0.f;
+        const float D1 = __uint_as_float(tile_max[0]), Dd = INVD ? __uint_as_float(tile_max[1]) : 0.f;
         const float cmax = __uint_as_float(g.tile_cmax[u.tile]);
         const float bgm = fmaxf(fmaxf(fabsf(a.bg[0]), fabsf(a.bg[1])), fabsf(a.bg[2]));
         fx.eK = fx_exp(32.f * ((cmax + bgm) * D1 + 5.f * Dd));
+        fx.eOp = fx_exp(__uint_as_float(tile_max[2]));
+        fx.eX = fx_exp(__uint_as_float(tile_max[3]));
+        fx.eY = fx_exp(__uint_as_float(tile_max[4]));
         fx.eCol = fx_exp(32.f * D1);
         fx.eId = fx_exp(32.f * Dd);
     }
@@ -592,11 +606,12 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
     int fcx, fcy, fkind;
     fx_field_kind(afield, fcx, fcy, fkind);
+    const int fxbias = 150 - FX_SHIFT + fx_field_exp(fx, fcx, fcy, fkind);          // (the lane's field: a constant of the unit)
 
     // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
     for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
         const uint32_t ep = list_load<NE>(lst, (uint32_t)g0);
-        bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE]; float2 r2[NE]; uint32_t se[NE]; float cpx[NE], cpy[NE];
+        bool act[NE]; float dx[NE], dy[NE], G[NE], al[NE]; float4 r1[NE]; float2 r2[NE]; uint32_t se[NE];
         bool anyact = false;
 #pragma unroll
         for (int e = 0; e < NE; e++) {
@@ -604,7 +619,6 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             se[e] = (ep >> (8 * (NE - 1 - e))) & 0xffu;
             const float4 r0 = S.ra[se[e]];
             r1[e] = S.rb[se[e]]; r2[e] = get_tail(S.rc[se[e]]);
-            cpx[e] = r0.x; cpy[e] = r0.y;
             dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
             const float pw = pair_power(r0.z, r0.w, r1[e].x, dx[e], dy[e]);
             G[e] = __expf(pw);
@@ -622,11 +636,8 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             const float y = row_reduce10(v, b3, b2, b1, b0);
             // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
             if (FIXED) {
-                if (alane && y != 0.f) {
-                    const int E = fx_field_exp(fx, fcx, fcy, fkind, cpx[e], cpy[e], r1[e].y);
-                    const long long val = dbg_on(g, 2048u) ? (long long)__float_as_uint(y) : fx_from_float(y, E);
-                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)val);
-                }
+                if (alane && y != 0.f)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)fx_from_float(y, fxbias));
             } else if (DET) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -656,11 +667,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             } else if (FIXED) {
                 if (f < NF) {
                     const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
-                    if (sv != 0ll) {
-                        const float4 r0 = S.ra[e];
-                        const float y = fx_to_float(sv, fx_field_exp(fx, cx, cy, kind, r0.x, r0.y, S.rb[e].y));
-                        unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, y);
-                    }
+                    if (sv != 0ll) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, fx_to_float(sv, fx_field_exp(fx, cx, cy, kind)));
                 }
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];
