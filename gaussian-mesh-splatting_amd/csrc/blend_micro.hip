@@ -414,46 +414,45 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // ------------------------------------------------------------------------------------ fixed-point gradient table (round 5)
 // An LDS float atomic costs ~2.7 cycles PER ACTIVE LANE on MI355X; an integer one runs at the rate of a plain store (tools/lds_bench.hip:
 // ds_add_f32 on 4 rows x 10 lanes 45 ns per CU, ds_add_u64 3.3 ns).  The backward issues 16.6 M lane-adds per frame, so the unit's
-// gradient table holds 64-bit FIXED-POINT sums: a partial sum y of field f of entry e is added as round(y * 2^(58 - E)) with an
-// exponent E fixed per (entry, field) BEFORE any add -- |y| <= 2^E -- so the sum is exact to 2^(E-59) per add, independent of the
-// order of the adds (deterministic), and cannot overflow (at most 16 adds of magnitude <= 2^58).  The bound, for the sum over a 4x4
+// gradient table holds 64-bit FIXED-POINT sums: a partial sum y of field f of entry e is added as round(y * 2^(47 - E)) with an
+// exponent E fixed per (entry, field) BEFORE any add -- |y| <= 2^E -- so the sum is exact to 2^(E-48) per add, independent of the
+// order of the adds (deterministic), and cannot overflow (at most 16 adds of magnitude <= 2^47).  The bound, for the sum over a 4x4
 // block's 16 pixels (gms_blend.h::bwd_step): |q| = |G op dL/dalpha| <= op_e ((Cmax + |bg|max) D1 + 5 Dd), where Cmax is the largest
 // |colour component| of the tile's splats (the colour behind a splat is a convex combination of those: ImageState::tile_cmax, raised
 // by the forward launches), D1 / Dd the tile's largest sum_c |dL/dpixel_c| / |dL/dinvdepth|, 1/depth <= 1/0.2, T <= 1 and
-// Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; op_e <= the unit's
-// largest opacity; the colour weights w <= 1.  A factor 2 covers the rounding of T and of the colour behind.  Every bound is taken over
-// the whole UNIT, so a field's exponent is one number per unit -- a constant of the lane that holds the field -- and the walks pay
-// for nothing but the conversion (~12 integer VALU per entry; per-entry exponents were measured first: 189 us, the exponent arithmetic
-// and 18 KB more LDS cost more than the atomics saved).  The bounds are loose by many orders of magnitude on purpose: a value 2^34
-// below its bound still carries 24 bits, and what lies further below is under the 1e-6 floor of the parity criterion.
-constexpr int FX_SHIFT = 58;
+// Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; the colour weights
+// w <= 1.  A factor 2 covers the rounding of T and of the colour behind.  D1, Cmax, X, Y are taken over the whole UNIT, so a field's
+// exponent is one number per unit -- a constant of the lane that holds the field -- plus the exponent of the entry's own opacity: the
+// walks pay for the conversion alone (seven instructions per entry).  Measured on the way: exponents from every entry's own centre,
+// mantissas shifted by hand, 58 bits: 189 us (4 blocks per CU: 32.1 KB of LDS is 152 bytes too many for five); unit-level exponents,
+// hand-shifted mantissas: 149 us; the float table this replaces: 142 us.  The bounds are loose by orders of magnitude on purpose: a
+// value 2^23 below its bound still carries 24 bits, and what lies far below is under the 1e-6 floor of the parity criterion.
+constexpr int FX_SHIFT = 47;
 
 // x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
 __device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
 
-// round(y * 2^(FX_SHIFT - E)) in integer arithmetic, for |y| <= 2^E; `bias` = 150 - FX_SHIFT + E (a constant of the lane)
-__device__ __forceinline__ long long fx_from_float(float y, int bias)
+// round(y * 2^k) as a 64-bit integer, k = FX_SHIFT - E, for |y| <= 2^E: the scaled value is exact in double, and adding 1.5 * 2^52
+// leaves its nearest integer (ties to even) in the low mantissa bits for |x| < 2^51 -- five f64 / integer instructions, no branch
+// (the first version shifted the float's mantissa by hand: 25 instructions with two divergent branches, 149 us against 142).
+__device__ __forceinline__ long long fx_from_float(float y, int k)
 {
-    const uint32_t b = __float_as_uint(y);
-    const int ef = (int)((b >> 23) & 0xffu);
-    const unsigned long long man = (unsigned long long)((b & 0x7fffffu) | (ef ? 0x800000u : 0u));      // y = +- man * 2^(max(ef, 1) - 150)
-    // left shift by s = max(ef, 1) - bias when that is >= 0 (|y| <= 2^E keeps s <= 35; 38 only keeps a violated bound from wrapping),
-    // else a rounding right shift by -s: the mantissa is pre-shifted left by 26, so ONE right shift by 26 - s covers both
-    const int sh = 26 - min(max(ef, 1) - bias, 38);                    // >= -12
-    const unsigned long long wide = man << 26;                          // < 2^50
-    const unsigned long long v = sh <= 0 ? wide << (-sh) : (sh > 52 ? 0ull : (wide + (1ull << (sh - 1))) >> sh);
-    return (b >> 31) ? -(long long)v : (long long)v;
+    const double MAGIC = 6755399441055744.0;
+    double x = ldexp((double)y, k);
+    x = fmin(fmax(x, -1125899906842624.0), 1125899906842624.0);          // (2^50: only a violated bound ever gets here)
+    return __double_as_longlong(x + MAGIC) - __double_as_longlong(MAGIC);
 }
 
 // (exact in double, one rounding to float)
 __device__ __forceinline__ float fx_to_float(long long v, int E) { return (float)ldexp((double)v, E - FX_SHIFT); }
 
-// exponents of one unit: every bound is taken over the whole unit (largest opacity, largest centre-to-corner distances), so a field's
-// exponent is ONE number per unit -- nothing per entry in the walks
-struct FxTile { int eK, eOp, eX, eY, eCol, eId; };
-__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind)
+// exponents of one unit: the bounds on the pixel gradients, the colours and the centre-to-corner distances are taken over the whole
+// unit, so a field's exponent is ONE number per unit (a constant of the lane that holds the field) plus, for the geometric fields,
+// the exponent of the entry's own opacity (two instructions per entry in the walks)
+struct FxTile { int eK, eX, eY, eCol, eId; };
+__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind, float op)
 {
-    return kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + t.eOp + cx * t.eX + cy * t.eY);
+    return kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + fx_exp(fabsf(op)) + cx * t.eX + cy * t.eY);
 }
 // field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
 __device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
@@ -475,7 +474,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
     __shared__ UnitRecsT<INVD> S;
     __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : (DET ? 4 : 1) * LMAX * 10 * 4];
-    __shared__ uint32_t tile_max[5];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|, |opacity|,
+    __shared__ uint32_t tile_max[4];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|,
                                                             //        centre-to-corner distances in x and in y
     long long *const fxt = reinterpret_cast<long long *>(table_mem);
     float *const table_all = reinterpret_cast<float *>(table_mem);
@@ -488,7 +487,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const size_t HW = (size_t)g.W * g.H;
     if (FIXED) {
         for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
-        if (threadIdx.x < 5) tile_max[threadIdx.x] = 0u;
+        if (threadIdx.x < 4) tile_max[threadIdx.x] = 0u;
     } else {
         for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     }
@@ -506,30 +505,28 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     float *const table = table_all + (DET ? q * LMAX * 10 : 0);
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
-    FxTile fx = {0, 0, 0, 0, 0, 0};
+    FxTile fx = {0, 0, 0, 0, 0};
     if (FIXED) {
-        // the unit's largest opacity and centre-to-corner distances (entry threadIdx.x; the records behind the unit's end are zero)
+        // the unit's largest centre-to-corner distances (entry threadIdx.x)
         const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
         const float4 mine = S.ra[threadIdx.x];
-        float my_op = fabsf(S.rb[threadIdx.x].y);
         float my_x = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f;
         float my_y = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f;
         for (int d = 32; d >= 1; d >>= 1) {
-            my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d)); my_op = fmaxf(my_op, __shfl_xor(my_op, d));
+            my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d));
             my_x = fmaxf(my_x, __shfl_xor(my_x, d)); my_y = fmaxf(my_y, __shfl_xor(my_y, d));
         }
         if (lane == 0) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
             atomicMax(&tile_max[0], __float_as_uint(my_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(my_dd));
-            atomicMax(&tile_max[2], __float_as_uint(my_op)); atomicMax(&tile_max[3], __float_as_uint(my_x)); atomicMax(&tile_max[4], __float_as_uint(my_y));
+            atomicMax(&tile_max[2], __float_as_uint(my_x)); atomicMax(&tile_max[3], __float_as_uint(my_y));
         }
         __syncthreads();
         const float D1 = __uint_as_float(tile_max[0]), Dd = INVD ? __uint_as_float(tile_max[1]) : 0.f;
         const float cmax = __uint_as_float(g.tile_cmax[u.tile]);
         const float bgm = fmaxf(fmaxf(fabsf(a.bg[0]), fabsf(a.bg[1])), fabsf(a.bg[2]));
         fx.eK = fx_exp(32.f * ((cmax + bgm) * D1 + 5.f * Dd));
-        fx.eOp = fx_exp(__uint_as_float(tile_max[2]));
-        fx.eX = fx_exp(__uint_as_float(tile_max[3]));
-        fx.eY = fx_exp(__uint_as_float(tile_max[4]));
+        fx.eX = fx_exp(__uint_as_float(tile_max[2]));
+        fx.eY = fx_exp(__uint_as_float(tile_max[3]));
         fx.eCol = fx_exp(32.f * D1);
         fx.eId = fx_exp(32.f * Dd);
     }
@@ -606,7 +603,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
     int fcx, fcy, fkind;
     fx_field_kind(afield, fcx, fcy, fkind);
-    const int fxbias = 150 - FX_SHIFT + fx_field_exp(fx, fcx, fcy, fkind);          // (the lane's field: a constant of the unit)
+    const int fxk = FX_SHIFT - fx_field_exp(fx, fcx, fcy, fkind, 1.f) + 1;          // (the lane's field, at opacity exponent 0: fx_exp(1.f) = 1)
 
     // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
     for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
@@ -636,8 +633,10 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             const float y = row_reduce10(v, b3, b2, b1, b0);
             // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
             if (FIXED) {
-                if (alane && y != 0.f)
-                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)fx_from_float(y, fxbias));
+                if (alane && y != 0.f) {
+                    const int k = fxk - (fkind == 0 ? fx_exp(fabsf(r1[e].y)) : 0);
+                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)fx_from_float(y, k));
+                }
             } else if (DET) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -667,7 +666,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             } else if (FIXED) {
                 if (f < NF) {
                     const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
-                    if (sv != 0ll) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, fx_to_float(sv, fx_field_exp(fx, cx, cy, kind)));
+                    if (sv != 0ll) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, fx_to_float(sv, fx_field_exp(fx, cx, cy, kind, S.rb[e].y)));
                 }
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];

@@ -1,8 +1,8 @@
 # round 5, GPU call 6: fixed-point table with unit-uniform exponents: timing first, then parity
 set -x
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; T=r05f
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; T=r05g
 bash tools/ab.sh $T "-" "GMS_BWD_FIXED=0" "-" "GMS_BWD_FIXED=0" "GMS_TRIP_BWD=4"
 X=$GRAFT_REPO_ROOT/gaussian-mesh-splatting_amd/lib_exp
 LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=1024 timeout 300 python tools/micro_phases.py > gpurun_out/${T}_phases_fixed.txt 2>&1; tail -14 gpurun_out/${T}_phases_fixed.txt | cut -c1-300
 timeout 1500 python -m pytest tests/test_gpu_raster.py tests/test_gpu_deterministic.py tests/test_gpu_negative_controls.py tests/test_gpu_c4.py tests/test_gpu_training.py -m gpu -q --maxfail=6 2>&1 | tail -30 > gpurun_out/${T}_pytest.log; tail -8 gpurun_out/${T}_pytest.log | cut -c1-400
-timeout 500 python tools/fuzz_parity.py 150 56000 > gpurun_out/${T}_fuzz_150cases.log 2>&1; tail -4 gpurun_out/${T}_fuzz_150cases.log | cut -c1-300
+timeout 500 python tools/fuzz_parity.py 150 57000 > gpurun_out/${T}_fuzz_150cases.log 2>&1; tail -4 gpurun_out/${T}_fuzz_150cases.log | cut -c1-300
