@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; the colour weights
 // w <= 1.  A factor 2 covers the rounding of T and of the colour behind.  D1, Cmax, X, Y are taken over the whole UNIT, so a field's
 // exponent is one number per unit -- a constant of the lane that holds the field -- plus the exponent of the entry's own opacity: the
-// walks pay for the conversion alone (seven instructions per entry).  Measured on the way: exponents from every entry's own centre,
+// walks pay for the conversion alone (about ten instructions per entry, two of them f64).  Measured on the way: exponents from every entry's own centre,
 // mantissas shifted by hand, 58 bits: 189 us (4 blocks per CU: 32.1 KB of LDS is 152 bytes too many for five); unit-level exponents,
 // hand-shifted mantissas: 149 us; the float table this replaces: 142 us.  The bounds are loose by orders of magnitude on purpose: a
 // value 2^23 below its bound still carries 24 bits, and what lies far below is under the 1e-6 floor of the parity criterion.
@@ -432,28 +432,45 @@ constexpr int FX_SHIFT = 47;
 // x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
 __device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
 
-// round(y * 2^k) as a 64-bit integer, k = FX_SHIFT - E, for |y| <= 2^E: the scaled value is exact in double, and adding 1.5 * 2^52
-// leaves its nearest integer (ties to even) in the low mantissa bits for |x| < 2^51 -- five f64 / integer instructions, no branch
-// (the first version shifted the float's mantissa by hand: 25 instructions with two divergent branches, 149 us against 142).
+// The power of two a partial sum is scaled by before it is rounded: k = FX_SHIFT - E.  `base` = FX_SHIFT minus the unit-level part of
+// the field's exponent (a constant of the lane that holds the field), `op_exp` = the biased exponent of the entry's opacity for the
+// geometric fields (op < 2^(op_exp - 126)), 126 for the colour / inverse-depth weights.  Kept inside a float's exponent range.
+__device__ __forceinline__ int fx_scale_exp(int base, uint32_t op_exp) { return min(max(base + 126 - (int)op_exp, -100), 100); }
+
+// round(y * 2^k) as a 64-bit integer for |y| * 2^k <= 2^47: the product with a power of two is exact in float, and adding 1.5 * 2^52 in
+// double leaves its nearest integer (ties to even) in the low mantissa bits for |x| < 2^51 -- no branch, two f64 instructions.
+// (The first version shifted the float's mantissa by hand: 25 instructions with two divergent branches.)
 __device__ __forceinline__ long long fx_from_float(float y, int k)
 {
     const double MAGIC = 6755399441055744.0;
-    double x = ldexp((double)y, k);
-    x = fmin(fmax(x, -1125899906842624.0), 1125899906842624.0);          // (2^50: only a violated bound ever gets here)
-    return __double_as_longlong(x + MAGIC) - __double_as_longlong(MAGIC);
+    const float ys = y * __uint_as_float((uint32_t)(k + 127) << 23);
+    return __double_as_longlong((double)ys + MAGIC) - __double_as_longlong(MAGIC);
 }
 
 // (exact in double, one rounding to float)
-__device__ __forceinline__ float fx_to_float(long long v, int E) { return (float)ldexp((double)v, E - FX_SHIFT); }
+__device__ __forceinline__ float fx_to_float(long long v, int k) { return (float)ldexp((double)v, -k); }
 
-// exponents of one unit: the bounds on the pixel gradients, the colours and the centre-to-corner distances are taken over the whole
-// unit, so a field's exponent is ONE number per unit (a constant of the lane that holds the field) plus, for the geometric fields,
-// the exponent of the entry's own opacity (two instructions per entry in the walks)
+// unit-level exponents: the bounds on the pixel gradients, the colours and the centre-to-corner distances hold for the whole unit
 struct FxTile { int eK, eX, eY, eCol, eId; };
-__device__ __forceinline__ int fx_field_exp(const FxTile &t, int cx, int cy, int kind, float op)
+// FX_SHIFT minus the unit-level part of a field's exponent
+__device__ __forceinline__ int fx_field_base(const FxTile &t, int cx, int cy, int kind)
 {
-    return kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + fx_exp(fabsf(op)) + cx * t.eX + cy * t.eY);
+    return FX_SHIFT - (kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + cx * t.eX + cy * t.eY));
 }
+
+// largest value of a wave's 64 lanes (non-negative inputs), valid in lane 63: DPP row operations, no LDS
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max_to_lane63(float v)
+{
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
+    v = dpp_max<0x142, 0xa>(v); v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
 // field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
 __device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
 {
@@ -464,16 +481,18 @@ __device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind
 
 // Backward.  The rows of a wave are aligned at the BOTTOM of their lists: global trip position `pos` is the same list index
 // for every row (rows whose list ends below it idle), so a trip's entry bytes are one aligned LDS read per NE entries.
-// FIXED (default): the gradient table is 64-bit fixed point (above), integer LDS atomics.  DET (deterministic mode, gmsplat.h): one
-// float table per WAVE, the four rows of a wave add one after the other, the flush sums the four tables in wave-group order into ONE
-// partial record per instance, stored -- not added -- at the instance's position in the sorted list.
+// FIXED (default): the gradient table is 64-bit fixed point (above), integer LDS atomics; FIXED = false keeps the float table of
+// rounds 3-4 (ds_add_f32; GMS_BWD_FIXED=0).  DET (deterministic mode, gmsplat.h): the fixed-point table -- integer sums do not depend
+// on the order of the adds, so the table IS deterministic (rounds 3-4 kept one float table per wave and added the rows one after
+// the other: 55 KB of LDS, 235 us) -- and a flush that stores ONE partial record per instance at the instance's position in the
+// sorted list instead of adding to the Gaussian's record with float atomics.
 template <bool INVD, int NE, int FAULT, bool DET = false, bool FIXED = true>
 __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
-    static_assert(!(DET && FIXED), "the deterministic mode keeps its per-wave float tables");
+    static_assert(!DET || FIXED, "the deterministic mode is built on the fixed-point table");
     constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
     __shared__ UnitRecsT<INVD> S;
-    __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : (DET ? 4 : 1) * LMAX * 10 * 4];
+    __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : LMAX * 10 * 4];
     __shared__ uint32_t tile_max[4];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|,
                                                             //        centre-to-corner distances in x and in y
     long long *const fxt = reinterpret_cast<long long *>(table_mem);
@@ -489,36 +508,37 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
         if (threadIdx.x < 4) tile_max[threadIdx.x] = 0u;
     } else {
-        for (int k = threadIdx.x; k < (DET ? 4 : 1) * LMAX * 10; k += BLOCK) table_all[k] = 0.f;
-    }
-    float my_d1 = 0.f, my_dd = 0.f;
-    if (FIXED) {          // pixel threadIdx.x of the tile, in raster order: only the maxima matter here
-        const int xi = u.tx * TILE + (int)(threadIdx.x & 15), yi = u.ty * TILE + (int)(threadIdx.x >> 4);
-        if (xi < g.W && yi < g.H) {
-            const size_t pd = (size_t)yi * g.W + xi;
-            my_d1 = (fabsf(a.dL_dpix[pd]) + fabsf(a.dL_dpix[HW + pd])) + fabsf(a.dL_dpix[2 * HW + pd]);
-            if (INVD) my_dd = fabsf(a.dL_dinvd[pd]);
-        }
+        for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     }
     const uint32_t my_id = unit_stage<false, INVD>(g, u, S, a.rec, nullptr);          // (its barriers also order the table clear)
     ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
-    float *const table = table_all + (DET ? q * LMAX * 10 : 0);
+    float *const table = table_all;
     const int lane = threadIdx.x & 63, row = lane >> 4, li = lane & 15;
+    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
+    const size_t pid = (size_t)p.yi * g.W + p.xi;
+    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
+    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
+    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
+    if (p.inside) {
+        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
+        if (INVD) dinvd = a.dL_dinvd[pid];
+    }
+    const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
     FxTile fx = {0, 0, 0, 0, 0};
     if (FIXED) {
-        // the unit's largest centre-to-corner distances (entry threadIdx.x)
+        // the unit's bounds: largest sum_c |dL/dpixel_c| (the block's 256 lanes hold the tile's 256 pixels), |dL/dinvdepth|, and
+        // centre-to-corner distances of its splats (entry threadIdx.x; the records behind the unit's end are zero)
         const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
         const float4 mine = S.ra[threadIdx.x];
-        float my_x = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f;
-        float my_y = (uint32_t)threadIdx.x < u.end - u.beg ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f;
-        for (int d = 32; d >= 1; d >>= 1) {
-            my_d1 = fmaxf(my_d1, __shfl_xor(my_d1, d)); my_dd = fmaxf(my_dd, __shfl_xor(my_dd, d));
-            my_x = fmaxf(my_x, __shfl_xor(my_x, d)); my_y = fmaxf(my_y, __shfl_xor(my_y, d));
-        }
-        if (lane == 0) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
-            atomicMax(&tile_max[0], __float_as_uint(my_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(my_dd));
-            atomicMax(&tile_max[2], __float_as_uint(my_x)); atomicMax(&tile_max[3], __float_as_uint(my_y));
+        const bool real = (uint32_t)threadIdx.x < u.end - u.beg;
+        const float m_d1 = wave_max_to_lane63((fabsf(dp0) + fabsf(dp1)) + fabsf(dp2));
+        const float m_x = wave_max_to_lane63(real ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f);
+        const float m_y = wave_max_to_lane63(real ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f);
+        const float m_dd = INVD ? wave_max_to_lane63(fabsf(dinvd)) : 0.f;
+        if (lane == 63) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
+            atomicMax(&tile_max[0], __float_as_uint(m_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(m_dd));
+            atomicMax(&tile_max[2], __float_as_uint(m_x)); atomicMax(&tile_max[3], __float_as_uint(m_y));
         }
         __syncthreads();
         const float D1 = __uint_as_float(tile_max[0]), Dd = INVD ? __uint_as_float(tile_max[1]) : 0.f;
@@ -530,16 +550,6 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         fx.eCol = fx_exp(32.f * D1);
         fx.eId = fx_exp(32.f * Dd);
     }
-    const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
-    const size_t pid = (size_t)p.yi * g.W + p.xi;
-    const float Tfinal = p.inside ? a.final_T[pid] : 0.f;
-    const uint32_t last = p.inside ? a.n_contrib[pid] : 0u;      // seg * L + index + 1 of the last splat this pixel applied
-    float dp0 = 0.f, dp1 = 0.f, dp2 = 0.f, dinvd = 0.f;
-    if (p.inside) {
-        dp0 = a.dL_dpix[pid]; dp1 = a.dL_dpix[HW + pid]; dp2 = a.dL_dpix[2 * HW + pid];
-        if (INVD) dinvd = a.dL_dinvd[pid];
-    }
-    const float Tfinal_bgdot = Tfinal * (a.bg[0] * dp0 + a.bg[1] * dp1 + a.bg[2] * dp2);
     const uint32_t posbase = (uint32_t)u.seg * u.L;
     const uint32_t cn = u.end - u.beg;
     const uint32_t cnt = S.ocnt[4 * q + row];
@@ -603,7 +613,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const bool alane = (li & 1) == 0 ? (li != 14 || INVD) : (li == 1 || li == 9);
     int fcx, fcy, fkind;
     fx_field_kind(afield, fcx, fcy, fkind);
-    const int fxk = FX_SHIFT - fx_field_exp(fx, fcx, fcy, fkind, 1.f) + 1;          // (the lane's field, at opacity exponent 0: fx_exp(1.f) = 1)
+    const int fxbase = fx_field_base(fx, fcx, fcy, fkind);          // (the lane's field: a constant of the unit)
 
     // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
     for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
@@ -633,15 +643,9 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             const float y = row_reduce10(v, b3, b2, b1, b0);
             // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
             if (FIXED) {
-                if (alane && y != 0.f) {
-                    const int k = fxk - (fkind == 0 ? fx_exp(fabsf(r1[e].y)) : 0);
+                if (alane && y != 0.f) {          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
+                    const int k = fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u);
                     atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)fx_from_float(y, k));
-                }
-            } else if (DET) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (row == r && alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
-                    asm volatile("" ::: "memory");          // four separate LDS instructions, in row order
                 }
             } else if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
         }
@@ -660,13 +664,15 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         for (uint32_t e = threadIdx.x >> 4; e < cn; e += BLOCK / 16) {
             if (DET) {
                 // every instance of the unit gets its record (zeros included: the buffer is not cleared between frames)
-                const uint32_t k = e * 10u + (uint32_t)f;
-                const float y = f < 10 ? ((table_all[k] + table_all[LMAX * 10 + k]) + table_all[2 * LMAX * 10 + k]) + table_all[3 * LMAX * 10 + k] : 0.f;
-                a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] = y;
+                const long long sv = f < NF ? fxt[e * (uint32_t)NF + (uint32_t)f] : 0ll;
+                a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] =
+                    sv != 0ll ? fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), kind == 0 ? __float_as_uint(S.rb[e].y) >> 23 : 126u)) : 0.f;
             } else if (FIXED) {
                 if (f < NF) {
                     const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
-                    if (sv != 0ll) unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f, fx_to_float(sv, fx_field_exp(fx, cx, cy, kind, S.rb[e].y)));
+                    if (sv != 0ll)
+                        unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f,
+                                        fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), kind == 0 ? __float_as_uint(S.rb[e].y) >> 23 : 126u)));
                 }
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];
@@ -713,9 +719,9 @@ int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
     const bool invd = a.has_invd && a.dL_dinvd;
     static int fixed = -1;              // GMS_BWD_FIXED=0: the float LDS table of rounds 3-4 (ds_add_f32) instead of the 64-bit fixed-point one
     if (fixed < 0) { const char *e = getenv("GMS_BWD_FIXED"); fixed = e ? (atoi(e) != 0) : 1; }
-    if (a.part) {                           // deterministic mode (gmsplat.h): per-wave tables, ordered adds, per-instance partial records
-        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true, false><<<blocks, BLOCK, 0, stream>>>(g, a)));
-        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true, false><<<blocks, BLOCK, 0, stream>>>(g, a)));
+    if (a.part) {                           // deterministic mode (gmsplat.h): the fixed-point table, per-instance partial records
+        if (invd) GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<true, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
+        else GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, true><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else if (fault_mode() == 2 && !invd) {       // negative control (gms_set_fault): its own instantiation
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 2><<<blocks, BLOCK, 0, stream>>>(g, a)));
     } else if (!fixed) {
