@@ -635,19 +635,33 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             anyact = anyact || act[e];
         }
         if (!__any(anyact)) continue;
+        // the recurrence runs entry by entry; the NE row reductions that follow are independent DPP chains the compiler may interleave
+        // (each stage waits two states for its operands: with one chain per branch region the slots stayed empty), and the table adds come last
+        float y[NE];
+        {
+            float v[NE][10];
 #pragma unroll
-        for (int e = 0; e < NE; e++) {
-            float v[10];
-            const float4 q2 = make_float4(r2[e].x, r2[e].y, 0.f, 0.f);
-            bwd_step<INVD>(st8, act[e], r1[e], q2, dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v);
-            const float y = row_reduce10(v, b3, b2, b1, b0);
-            // a row with no active pixel for this entry sums exact zeros: nothing to add (and its entry byte may be stale)
-            if (FIXED) {
-                if (alane && y != 0.f) {          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
-                    const int k = fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u);
-                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)fx_from_float(y, k));
-                }
-            } else if (alane && y != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y);
+            for (int e = 0; e < NE; e++) {
+                const float4 q2 = make_float4(r2[e].x, r2[e].y, 0.f, 0.f);
+                bwd_step<INVD>(st8, act[e], r1[e], q2, dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < NE; e++) y[e] = row_reduce10(v[e], b3, b2, b1, b0);
+        }
+        // a row with no active pixel for an entry sums exact zeros: nothing to add (and its entry byte may be stale)
+        if (FIXED) {
+            long long val[NE];
+#pragma unroll
+            for (int e = 0; e < NE; e++)          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
+                val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u));
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+                if (alane && y[e] != 0.f)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)val[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; e++)
+                if (alane && y[e] != 0.f) atomicAdd(&table[se[e] * 10u + (uint32_t)afield], y[e]);
         }
     }
     }
