@@ -654,10 +654,13 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 #pragma unroll
             for (int e = 0; e < NE; e++)          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
                 val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u));
+            // (no test for zero: an integer LDS atomic costs what a store costs, a zero sum converts to zero, and a row that idles behind
+            // the end of its list names some entry of the unit -- adding zero to it is harmless; the test cost a compare and a branch per entry)
+            if (alane) {
 #pragma unroll
-            for (int e = 0; e < NE; e++)
-                if (alane && y[e] != 0.f)
+                for (int e = 0; e < NE; e++)
                     atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)val[e]);
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < NE; e++)
