@@ -427,36 +427,8 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // mantissas shifted by hand, 58 bits: 189 us (4 blocks per CU: 32.1 KB of LDS is 152 bytes too many for five); unit-level exponents,
 // hand-shifted mantissas: 149 us; the float table this replaces: 142 us.  The bounds are loose by orders of magnitude on purpose: a
 // value 2^23 below its bound still carries 24 bits, and what lies far below is under the 1e-6 floor of the parity criterion.
-constexpr int FX_SHIFT = 47;
-
-// x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
-__device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
-
-// The power of two a partial sum is scaled by before it is rounded: k = FX_SHIFT - E.  `base` = FX_SHIFT minus the unit-level part of
-// the field's exponent (a constant of the lane that holds the field), `op_exp` = the biased exponent of the entry's opacity for the
-// geometric fields (op < 2^(op_exp - 126)), 126 for the colour / inverse-depth weights.  Kept inside a float's exponent range.
-__device__ __forceinline__ int fx_scale_exp(int base, uint32_t op_exp) { return min(max(base + 126 - (int)op_exp, -100), 100); }
-
-// round(y * 2^k) as a 64-bit integer for |y| * 2^k <= 2^47: the product with a power of two is exact in float, and adding 1.5 * 2^52 in
-// double leaves its nearest integer (ties to even) in the low mantissa bits for |x| < 2^51 -- no branch, two f64 instructions.
-// (The first version shifted the float's mantissa by hand: 25 instructions with two divergent branches.)
-__device__ __forceinline__ long long fx_from_float(float y, int k)
-{
-    const double MAGIC = 6755399441055744.0;
-    const float ys = y * __uint_as_float((uint32_t)(k + 127) << 23);
-    return __double_as_longlong((double)ys + MAGIC) - __double_as_longlong(MAGIC);
-}
-
-// (exact in double, one rounding to float)
-__device__ __forceinline__ float fx_to_float(long long v, int k) { return (float)ldexp((double)v, -k); }
-
-// unit-level exponents: the bounds on the pixel gradients, the colours and the centre-to-corner distances hold for the whole unit
-struct FxTile { int eK, eX, eY, eCol, eId; };
-// FX_SHIFT minus the unit-level part of a field's exponent
-__device__ __forceinline__ int fx_field_base(const FxTile &t, int cx, int cy, int kind)
-{
-    return FX_SHIFT - (kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + cx * t.eX + cy * t.eY));
-}
+// (fx_exp, fx_scale_exp, fx_from_float, fx_to_float, FxTile, fx_field_base, fx_field_kind live in gms_blend.h: the test hooks run the very
+// conversions on adversarial values, tests/test_gpu_fixed_point.py)
 
 // largest value of a wave's 64 lanes (non-negative inputs), valid in lane 63: DPP row operations, no LDS
 template <int CTRL, int ROW_MASK = 0xf>
@@ -469,14 +441,6 @@ __device__ __forceinline__ float wave_max_to_lane63(float v)
     v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
     v = dpp_max<0x142, 0xa>(v); v = dpp_max<0x143, 0xc>(v);
     return v;
-}
-
-// field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
-__device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
-{
-    cx = f == GRAD_MX || f == GRAD_CB ? 1 : (f == GRAD_CA ? 2 : 0);
-    cy = f == GRAD_MY || f == GRAD_CB ? 1 : (f == GRAD_CC ? 2 : 0);
-    kind = f == GRAD_ID ? 2 : (f >= GRAD_R && f <= GRAD_B ? 1 : 0);
 }
 
 // Backward.  The rows of a wave are aligned at the BOTTOM of their lists: global trip position `pos` is the same list index
@@ -654,13 +618,11 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 #pragma unroll
             for (int e = 0; e < NE; e++)          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
                 val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u));
-            // (no test for zero: an integer LDS atomic costs what a store costs, a zero sum converts to zero, and a row that idles behind
-            // the end of its list names some entry of the unit -- adding zero to it is harmless; the test cost a compare and a branch per entry)
-            if (alane) {
+            // (adding without the test for zero was measured: 141 us against 133 -- the zeros of the idle rows are atomics too)
 #pragma unroll
-                for (int e = 0; e < NE; e++)
+            for (int e = 0; e < NE; e++)
+                if (alane && y[e] != 0.f)
                     atomicAdd(reinterpret_cast<unsigned long long *>(fxt) + se[e] * (uint32_t)NF + (uint32_t)afield, (unsigned long long)val[e]);
-            }
         } else {
 #pragma unroll
             for (int e = 0; e < NE; e++)

@@ -253,6 +253,46 @@ __device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1
     v[0] = qx; v[1] = qy; v[2] = qx * dx; v[3] = qx * dy; v[4] = qy * dy; v[5] = q;
 }
 
+// ---- 64-bit fixed-point gradient table of the micro-tile backward (blend_micro.hip, where the scheme is described)
+constexpr int FX_SHIFT = 47;
+
+// x < 2^fx_exp(x) for every finite x >= 0 (biased exponent - 126; zero and denormals: -126)
+__device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
+
+// The power of two a partial sum is scaled by before it is rounded: k = FX_SHIFT - E.  `base` = FX_SHIFT minus the unit-level part of
+// the field's exponent (a constant of the lane that holds the field), `op_exp` = the biased exponent of the entry's opacity for the
+// geometric fields (op < 2^(op_exp - 126)), 126 for the colour / inverse-depth weights.  Kept inside a float's exponent range.
+__device__ __forceinline__ int fx_scale_exp(int base, uint32_t op_exp) { return min(max(base + 126 - (int)op_exp, -100), 100); }
+
+// round(y * 2^k) as a 64-bit integer for |y| * 2^k <= 2^47: the product with a power of two is exact in float, and adding 1.5 * 2^52 in
+// double leaves its nearest integer (ties to even) in the low mantissa bits for |x| < 2^51 -- no branch, two f64 instructions.
+// (The first version shifted the float's mantissa by hand: 25 instructions with two divergent branches.)
+__device__ __forceinline__ long long fx_from_float(float y, int k)
+{
+    const double MAGIC = 6755399441055744.0;
+    const float ys = y * __uint_as_float((uint32_t)(k + 127) << 23);
+    return __double_as_longlong((double)ys + MAGIC) - __double_as_longlong(MAGIC);
+}
+
+// (exact in double, one rounding to float)
+__device__ __forceinline__ float fx_to_float(long long v, int k) { return (float)ldexp((double)v, -k); }
+
+// unit-level exponents: the bounds on the pixel gradients, the colours and the centre-to-corner distances hold for the whole unit
+struct FxTile { int eK, eX, eY, eCol, eId; };
+// FX_SHIFT minus the unit-level part of a field's exponent
+__device__ __forceinline__ int fx_field_base(const FxTile &t, int cx, int cy, int kind)
+{
+    return FX_SHIFT - (kind == 1 ? t.eCol : (kind == 2 ? t.eId : t.eK + cx * t.eX + cy * t.eY));
+}
+
+// field -> (power of dx, power of dy, kind: 0 geometry, 1 colour weight, 2 inverse-depth weight)
+__device__ __forceinline__ void fx_field_kind(int f, int &cx, int &cy, int &kind)
+{
+    cx = f == GRAD_MX || f == GRAD_CB ? 1 : (f == GRAD_CA ? 2 : 0);
+    cy = f == GRAD_MY || f == GRAD_CB ? 1 : (f == GRAD_CC ? 2 : 0);
+    kind = f == GRAD_ID ? 2 : (f >= GRAD_R && f <= GRAD_B ? 1 : 0);
+}
+
 struct Unit {
     int tile, seg, nseg, tx, ty;
     uint32_t tile_beg;     // first entry of the tile in the sorted list

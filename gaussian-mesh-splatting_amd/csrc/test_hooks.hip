@@ -48,7 +48,39 @@ __global__ void __launch_bounds__(256) test_cull_kernel(int n, const float *in, 
     out[4 * (size_t)i + 3] = __float_as_uint(ey);
 }
 
+// gms_test_fixed_point: the conversions of the micro-tile backward's fixed-point gradient table (gms_blend.h: fx_from_float,
+// fx_to_float) on caller-supplied (value, scale exponent) pairs
+__global__ void __launch_bounds__(256) test_fx_kernel(int n, const float *y, const int *k, long long *fixed, float *back)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const long long v = fx_from_float(y[i], k[i]);
+    fixed[i] = v;
+    back[i] = fx_to_float(v, k[i]);
+}
+
 }  // namespace gms
+
+extern "C" int32_t gms_test_fixed_point(int32_t n, const float *y_host, const int32_t *k_host, long long *fixed_host, float *back_host)
+{
+    if (n <= 0) return 0;
+    float *dy = nullptr, *db = nullptr; int *dk = nullptr; long long *dv = nullptr;
+    hipError_t e = hipMalloc(&dy, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&db, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dk, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&dv, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(dy, y_host, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dk, k_host, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        gms::test_fx_kernel<<<(unsigned)((n + 255) / 256), 256>>>(n, dy, dk, dv, db);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(fixed_host, dv, (size_t)n * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(back_host, db, (size_t)n * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dy); (void)hipFree(db); (void)hipFree(dk); (void)hipFree(dv);
+    return e == hipSuccess ? 0 : -(int32_t)e;
+}
 
 // host buffers in, host buffers out (the hook owns its device memory); returns 0 or a negative hipError
 extern "C" int32_t gms_test_cull(int32_t n, const float *in_host, uint32_t *out_host)
