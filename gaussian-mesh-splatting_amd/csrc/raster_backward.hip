@@ -44,16 +44,10 @@ struct PreBwdArgs {
 // SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
 // (ds_read_b128, conflict-free at the 52-dword pitch), d loss / d sh is written back in place, the
 // direction gradient is accumulated.  r[k*3+c] lives in registers (all indices are constants).
+// (the arithmetic, on a coefficient row held in registers: r[k*3+c] in, d loss / d sh [k*3+c] out)
 template <int DEG>
-__device__ __forceinline__ void sh_backward(float *row_lds, float x, float y, float z, const float dRGB[3], float gdir[3])
+__device__ __forceinline__ void sh_backward_regs(float *r, float x, float y, float z, const float dRGB[3], float gdir[3])
 {
-    constexpr int NQ = ((DEG + 1) * (DEG + 1) * 3 + 3) / 4;
-    float r[NQ * 4];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) {
-        const float4 v = *reinterpret_cast<const float4 *>(row_lds + q * 4);
-        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
-    }
 #define GMS_SH_TERM(K, BV, BDX, BDY, BDZ)                                          \
     {                                                                              \
         const float bv = (BV), bx = (BDX), by = (BDY), bz = (BDZ);                 \
@@ -88,6 +82,19 @@ __device__ __forceinline__ void sh_backward(float *row_lds, float x, float y, fl
         GMS_SH_TERM(15, SH_C3[6] * x * (xx - 3.f * yy), SH_C3[6] * (3.f * xx - 3.f * yy), SH_C3[6] * (-6.f * x * y), 0.f)
     }
 #undef GMS_SH_TERM
+}
+
+template <int DEG>
+__device__ __forceinline__ void sh_backward(float *row_lds, float x, float y, float z, const float dRGB[3], float gdir[3])
+{
+    constexpr int NQ = ((DEG + 1) * (DEG + 1) * 3 + 3) / 4;
+    float r[NQ * 4];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        const float4 v = *reinterpret_cast<const float4 *>(row_lds + q * 4);
+        r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+    }
+    sh_backward_regs<DEG>(r, x, y, z, dRGB, gdir);
     // coefficients beyond the active degree inside the last chunk get zero gradient
 #pragma unroll
     for (int k = (DEG + 1) * (DEG + 1) * 3; k < NQ * 4; k++) r[k] = 0.f;
@@ -106,7 +113,7 @@ __device__ __forceinline__ void stage_sh_rows_b(const float *shs, int g0, int ro
     }
 }
 
-__global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
+__global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a, int pre_bwd_linear)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,7 +131,34 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     // stage the SH rows of this wave's 64 Gaussians into LDS (coalesced)
     const bool split = a.shs_rest != nullptr;         // DC [P,3] + REST [P,45] stored separately (M = 16)
     constexpr int RESTF = 45;
-    if (use_sh && split) {
+    // Round 5, split degree-3 storage (the training layout): the wave's coefficient block goes global -> LDS by LDS-DMA as it lies (64 rows
+    // of `_features_rest` = 11 520 contiguous bytes, row pitch 45 dwords, then the 768 bytes of `_features_dc`), the gradients go back
+    // into the same linear image and leave as one contiguous float4 stream: no scatter with a division by 45 on either side.
+    const bool linear = use_sh && split && a.D == 3 && pre_bwd_linear;
+    float *const lin_dc = wl + WAVE * RESTF;
+    if (linear) {
+        if (__any(vis)) {
+            const int rr = max(rows, 0);
+            const float *sp = a.shs_rest + (size_t)g0 * RESTF;       // g0 % 64 == 0: 16-byte aligned
+            const int nfl = rr * RESTF, nd = rr * 3;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int e4 = (lane + WAVE * j) * 4;
+                if (e4 + 3 < nfl)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + e4),
+                                                     (__attribute__((address_space(3))) void *)(wl + WAVE * 4 * j), 16, 0, 0);
+            }
+            if (lane * 4 + 3 < nd)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.shs + (size_t)g0 * 3 + lane * 4),
+                                                 (__attribute__((address_space(3))) void *)lin_dc, 16, 0, 0);
+            if (rr < WAVE) {          // last wave of the array: the (at most one) 16-byte chunk of each block that straddles its end
+                for (int e = (nfl & ~3) + lane; e < nfl; e += WAVE) wl[e] = sp[e];
+                for (int e = (nd & ~3) + lane; e < nd; e += WAVE) lin_dc[e] = a.shs[(size_t)g0 * 3 + e];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the LDS-DMA copies have landed
+        }
+        wave_sync();      // the rows are this wave's own
+    } else if (use_sh && split) {
         if (__any(vis)) {
             for (int e = lane; e < rows * 3; e += WAVE) wl[(e / 3) * SH_PITCH_B + (e % 3)] = a.shs[(size_t)g0 * 3 + e];
             const int need = nb * 3 - 3;              // floats of each REST row the active degree uses
@@ -283,6 +317,20 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
 #pragma unroll
             for (int c = 0; c < 3; c++) { dRGB[c] = ((cl >> c) & 1u) ? 0.f : acc_col[c]; dcol_sh[c] = dRGB[c]; }
             float gdir[3] = {0.f, 0.f, 0.f};
+            if (linear) {
+                float r[48];
+#pragma unroll
+                for (int c = 0; c < 3; c++) r[c] = lin_dc[lane * 3 + c];
+#pragma unroll
+                for (int m = 0; m < RESTF; m++) r[3 + m] = wl[lane * RESTF + m];
+                sh_backward_regs<3>(r, x, y, z, dRGB, gdir);
+                if (!a.dL_dcolor_sh) {          // (factorised mode writes no SH gradient rows)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) lin_dc[lane * 3 + c] = r[c];
+#pragma unroll
+                    for (int m = 0; m < RESTF; m++) wl[lane * RESTF + m] = r[3 + m];
+                }
+            } else
             switch (a.D) {
             case 0: sh_backward<0>(row, x, y, z, dRGB, gdir); break;
             case 1: sh_backward<1>(row, x, y, z, dRGB, gdir); break;
@@ -332,6 +380,26 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a)
     // ---- SH gradient rows: zero what was not written, then stream the wave's rows out coalesced
     // (factorised mode: dL/dsh = Y(dir) x dL/dcolour is formed later, by sh_grad_expand, from the [P,3] factor written below)
     if (use_sh && a.dL_dcolor_sh) {
+    } else if (linear) {
+        if (!vis) {          // culled Gaussian: a zero gradient row
+#pragma unroll
+            for (int c = 0; c < 3; c++) lin_dc[lane * 3 + c] = 0.f;
+#pragma unroll
+            for (int m = 0; m < RESTF; m++) wl[lane * RESTF + m] = 0.f;
+        }
+        wave_sync();      // the rows are this wave's own
+        if (rows > 0) {
+            const int nfl = rows * RESTF, nd = rows * 3;
+            float *dp = a.dL_dsh_rest + (size_t)g0 * RESTF, *dd = a.dL_dsh + (size_t)g0 * 3;
+#pragma unroll
+            for (int j = 0; j < 12; j++) {
+                const int e4 = (lane + WAVE * j) * 4;
+                if (e4 + 3 < nfl) *reinterpret_cast<float4 *>(dp + e4) = *reinterpret_cast<const float4 *>(wl + e4);
+                else for (int t = 0; t < 4; t++) if (e4 + t < nfl) dp[e4 + t] = wl[e4 + t];
+            }
+            if (lane * 4 + 3 < nd) *reinterpret_cast<float4 *>(dd + lane * 4) = *reinterpret_cast<const float4 *>(lin_dc + lane * 4);
+            else for (int t = 0; t < 4; t++) if (lane * 4 + t < nd) dd[lane * 4 + t] = lin_dc[lane * 4 + t];
+        }
     } else if (use_sh && split) {
         for (int q = vis ? (nb * 3 + 3) / 4 : 0; q < 12; q++)
             *reinterpret_cast<float4 *>(row + q * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -588,7 +656,11 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     p.clamped = geom.clamped; p.accum = A->grad_accum; p.rezero = fault_mode() == 3 ? 0 : A->grad_accum_rezero; p.dL_dmean2D = A->dL_dmeans2D;
     p.dL_dcolors = A->colors_precomp ? A->dL_dcolors : nullptr; p.dL_dcolor_sh = (A->shs && A->sh_factor_mode) ? A->dL_dcolors : nullptr; p.campos_row = A->factor_campos_row; p.dL_dopacity = A->dL_dopacity; p.dL_dmeans3D = A->dL_dmeans3D;
     p.dL_dcov3D = A->dL_dcov3D; p.dL_dsh = A->dL_dsh; p.dL_dsh_rest = A->dL_dsh_rest; p.dL_dscales = A->dL_dscales; p.dL_drots = A->dL_drotations;
-    GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p));
+    static int pre_linear = -1;         // GMS_PRE_BWD_LINEAR=0: the 52-dword-pitch scatter staging of rounds 1-4 for split degree-3 storage
+    if (pre_linear < 0) { const char *e = getenv("GMS_PRE_BWD_LINEAR"); pre_linear = e ? (atoi(e) != 0) : 1; }
+    const int lin_ok = pre_linear && A->shs && A->shs_rest && A->D == 3 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
+                       (A->sh_factor_mode || ((((uintptr_t)A->dL_dsh) & 15u) == 0 && (((uintptr_t)A->dL_dsh_rest) & 15u) == 0));
+    GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p, lin_ok));
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
     if (fault_mode() == 4 && A->dL_dscales)      // negative control: dL/dscale.x of every 1000th Gaussian off by 2e-3
         fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->dL_dscales, P, 3, 0, 1000, 1.002f);
