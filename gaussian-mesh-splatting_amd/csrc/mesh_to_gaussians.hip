@@ -128,14 +128,6 @@ __device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, c
     if (u2 > 0.f) G.ds2 += dL_dscaling[3 * p + 2] * sc * (a.fused_activations ? 1.f : 1.f / (u2 + EPS));
 }
 
-template <int S>
-__device__ __forceinline__ void face_splats(const GmsMeshArgs &a, int64_t b, const Frame &fr, const float *dL_dxyz, const float *dL_dscaling,
-                                            const float *dL_drot, FaceGrad &G)
-{
-#pragma unroll
-    for (int k = 0; k < S; k++) splat_contrib(a, b + k, fr, dL_dxyz, dL_dscaling, dL_drot, G);          // (same order of the sums as the loop)
-}
-
 // differentiate quaternion + frame once per face and scatter into the three vertices
 // returns d loss / d (t0, t1, t2) of the face in out[9]
 __device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float out[9])
@@ -246,14 +238,7 @@ __device__ __forceinline__ void bwd_face_thread_body(const GmsMeshArgs &a, unsig
     FaceGrad G = {};
     int64_t b, e;
     face_splat_range(a, f, b, e);
-    // (uniform small counts: the loop is unrolled so that the loads of ALL the face's splats are issued before the first is used --
-    // a loop with a run-time trip count pays one memory round trip per splat, and this thread's chain is the launch's critical path)
-    switch (a.splats_per_face) {
-    case 1: splat_contrib(a, b, fr, dL_dxyz, dL_dscaling, dL_drot, G); break;
-    case 2: face_splats<2>(a, b, fr, dL_dxyz, dL_dscaling, dL_drot, G); break;
-    case 3: face_splats<3>(a, b, fr, dL_dxyz, dL_dscaling, dL_drot, G); break;
-    default: for (int64_t p = b; p < e; p++) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
-    }
+    for (int64_t p = b; p < e; p++) splat_contrib(a, p, fr, dL_dxyz, dL_dscaling, dL_drot, G);
     face_backward(a, f, fr, G, out);
     }
     if (corner_grad) {
