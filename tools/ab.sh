@@ -16,7 +16,7 @@ k = d.get("kernels", {})
 def us(n):
     v = k.get(n)
     return round(v["avg_us"] * v.get("launches_per_step", 1), 1) if isinstance(v, dict) else None
-names = ["blend_head", "blend_fwd", "blend_finalize", "blend_bwd", "emit_instances", "tile_sort", "preprocess_fwd", "preprocess_bwd", "mesh_fwd", "mesh_bwd"]
+names = ["blend_head", "blend_fwd", "blend_finalize", "blend_bwd", "emit_instances", "tile_sort", "preprocess_fwd", "preprocess_bwd", "mesh_fwd", "mesh_bwd_face"]
 print(f"{sys.argv[1]:40s} {d['value']:8.1f} it/s {d['ms_per_step']:.4f} ms  " + " ".join(f"{n.replace('blend_','b_').replace('preprocess','pre')}={us(n)}" for n in names if us(n) is not None))
 PY
 done
