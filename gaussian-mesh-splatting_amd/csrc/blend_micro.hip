@@ -450,6 +450,10 @@ __device__ __forceinline__ float wave_max_to_lane63(float v)
 // on the order of the adds, so the table IS deterministic (rounds 3-4 kept one float table per wave and added the rows one after
 // the other: 55 KB of LDS, 235 us) -- and a flush that stores ONE partial record per instance at the instance's position in the
 // sorted list instead of adding to the Gaussian's record with float atomics.
+#ifndef GMS_FX_ENTRY_OPACITY
+#define GMS_FX_ENTRY_OPACITY 0
+#endif
+constexpr bool FX_ENTRY_OPACITY = GMS_FX_ENTRY_OPACITY != 0;      // 1: the exponent of every entry's own opacity (3 more instructions per entry, up to 8 bits tighter)
 template <bool INVD, int NE, int FAULT, bool DET = false, bool FIXED = true>
 __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
@@ -457,7 +461,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
     __shared__ UnitRecsT<INVD> S;
     __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : LMAX * 10 * 4];
-    __shared__ uint32_t tile_max[4];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|,
+    __shared__ uint32_t tile_max[5];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|,
                                                             //        centre-to-corner distances in x and in y
     long long *const fxt = reinterpret_cast<long long *>(table_mem);
     float *const table_all = reinterpret_cast<float *>(table_mem);
@@ -470,7 +474,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     const size_t HW = (size_t)g.W * g.H;
     if (FIXED) {
         for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
-        if (threadIdx.x < 4) tile_max[threadIdx.x] = 0u;
+        if (threadIdx.x < 5) tile_max[threadIdx.x] = 0u;
     } else {
         for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table_all[k] = 0.f;
     }
@@ -500,15 +504,18 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         const float m_x = wave_max_to_lane63(real ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f);
         const float m_y = wave_max_to_lane63(real ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f);
         const float m_dd = INVD ? wave_max_to_lane63(fabsf(dinvd)) : 0.f;
+        const float m_op = FX_ENTRY_OPACITY ? 0.f : wave_max_to_lane63(fabsf(S.rb[threadIdx.x].y));
         if (lane == 63) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
             atomicMax(&tile_max[0], __float_as_uint(m_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(m_dd));
             atomicMax(&tile_max[2], __float_as_uint(m_x)); atomicMax(&tile_max[3], __float_as_uint(m_y));
+            if (!FX_ENTRY_OPACITY) atomicMax(&tile_max[4], __float_as_uint(m_op));
         }
         __syncthreads();
         const float D1 = __uint_as_float(tile_max[0]), Dd = INVD ? __uint_as_float(tile_max[1]) : 0.f;
         const float cmax = __uint_as_float(g.tile_cmax[u.tile]);
         const float bgm = fmaxf(fmaxf(fabsf(a.bg[0]), fabsf(a.bg[1])), fabsf(a.bg[2]));
-        fx.eK = fx_exp(32.f * ((cmax + bgm) * D1 + 5.f * Dd));
+        // (unit-level opacity bound: folded into eK, and a field's scale is then ONE constant per lane and unit)
+        fx.eK = fx_exp(32.f * ((cmax + bgm) * D1 + 5.f * Dd)) + (FX_ENTRY_OPACITY ? 0 : fx_exp(__uint_as_float(tile_max[4])));
         fx.eX = fx_exp(__uint_as_float(tile_max[2]));
         fx.eY = fx_exp(__uint_as_float(tile_max[3]));
         fx.eCol = fx_exp(32.f * D1);
@@ -617,7 +624,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             long long val[NE];
 #pragma unroll
             for (int e = 0; e < NE; e++)          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
-                val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u));
+                val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, (FX_ENTRY_OPACITY && fkind == 0) ? __float_as_uint(r1[e].y) >> 23 : 126u));
             // (adding without the test for zero was measured: 141 us against 133 -- the zeros of the idle rows are atomics too)
 #pragma unroll
             for (int e = 0; e < NE; e++)
@@ -645,13 +652,13 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
                 // every instance of the unit gets its record (zeros included: the buffer is not cleared between frames)
                 const long long sv = f < NF ? fxt[e * (uint32_t)NF + (uint32_t)f] : 0ll;
                 a.part[(size_t)(u.beg + e) * GRAD_STRIDE + f] =
-                    sv != 0ll ? fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), kind == 0 ? __float_as_uint(S.rb[e].y) >> 23 : 126u)) : 0.f;
+                    sv != 0ll ? fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), (FX_ENTRY_OPACITY && kind == 0) ? __float_as_uint(S.rb[e].y) >> 23 : 126u)) : 0.f;
             } else if (FIXED) {
                 if (f < NF) {
                     const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
                     if (sv != 0ll)
                         unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f,
-                                        fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), kind == 0 ? __float_as_uint(S.rb[e].y) >> 23 : 126u)));
+                                        fx_to_float(sv, fx_scale_exp(fx_field_base(fx, cx, cy, kind), (FX_ENTRY_OPACITY && kind == 0) ? __float_as_uint(S.rb[e].y) >> 23 : 126u)));
                 }
             } else if (f < 10) {
                 const float y = table[e * 10u + (uint32_t)f];
