@@ -415,18 +415,20 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // An LDS float atomic costs ~2.7 cycles PER ACTIVE LANE on MI355X; an integer one runs at the rate of a plain store (tools/lds_bench.hip:
 // ds_add_f32 on 4 rows x 10 lanes 45 ns per CU, ds_add_u64 3.3 ns).  The backward issues 16.6 M lane-adds per frame, so the unit's
 // gradient table holds 64-bit FIXED-POINT sums: a partial sum y of field f of entry e is added as round(y * 2^(47 - E)) with an
-// exponent E fixed per (entry, field) BEFORE any add -- |y| <= 2^E -- so the sum is exact to 2^(E-48) per add, independent of the
+// exponent E fixed per (unit, field) BEFORE any add -- |y| <= 2^E -- so the sum is exact to 2^(E-48) per add, independent of the
 // order of the adds (deterministic), and cannot overflow (at most 16 adds of magnitude <= 2^47).  The bound, for the sum over a 4x4
-// block's 16 pixels (gms_blend.h::bwd_step): |q| = |G op dL/dalpha| <= op_e ((Cmax + |bg|max) D1 + 5 Dd), where Cmax is the largest
+// block's 16 pixels (gms_blend.h::bwd_step): |q| = |G op dL/dalpha| <= OP ((Cmax + |bg|max) D1 + 5 Dd), where Cmax is the largest
 // |colour component| of the tile's splats (the colour behind a splat is a convex combination of those: ImageState::tile_cmax, raised
 // by the forward launches), D1 / Dd the tile's largest sum_c |dL/dpixel_c| / |dL/dinvdepth|, 1/depth <= 1/0.2, T <= 1 and
 // Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; the colour weights
-// w <= 1.  A factor 2 covers the rounding of T and of the colour behind.  D1, Cmax, X, Y are taken over the whole UNIT, so a field's
-// exponent is one number per unit -- a constant of the lane that holds the field -- plus the exponent of the entry's own opacity: the
-// walks pay for the conversion alone (about ten instructions per entry, two of them f64).  Measured on the way: exponents from every entry's own centre,
+// w <= 1; OP the unit's largest opacity.  A factor 2 covers the rounding of T and of the colour behind.  Every bound is taken over the
+// whole UNIT, so a field's scale 2^(47 - E) is ONE constant per unit for the lane that holds the field, and the walks pay for the
+// conversion alone: a float multiply by that constant, a conversion to double, the add of the magic number 1.5 * 2^52 and one integer
+// add on the high word -- four instructions per entry.  Measured on the way (HIP events): exponents from every entry's own centre,
 // mantissas shifted by hand, 58 bits: 189 us (4 blocks per CU: 32.1 KB of LDS is 152 bytes too many for five); unit-level exponents,
-// hand-shifted mantissas: 149 us; the float table this replaces: 142 us.  The bounds are loose by orders of magnitude on purpose: a
-// value 2^23 below its bound still carries 24 bits, and what lies far below is under the 1e-6 floor of the parity criterion.
+// hand-shifted mantissas: 149 us; float scaling + magic number with the exponent of every entry's own opacity (GMS_FX_ENTRY_OPACITY=1):
+// 133 us; this form: 126 us; the float table it replaces: 139-142 us.  The bounds are loose by orders of magnitude on purpose: a value
+// 2^23 below its bound still carries 24 bits, and what lies far below is under the 1e-6 floor of the parity criterion.
 // (fx_exp, fx_scale_exp, fx_from_float, fx_to_float, FxTile, fx_field_base, fx_field_kind live in gms_blend.h: the test hooks run the very
 // conversions on adversarial values, tests/test_gpu_fixed_point.py)
 

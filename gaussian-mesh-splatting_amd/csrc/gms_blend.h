@@ -260,8 +260,9 @@ constexpr int FX_SHIFT = 47;
 __device__ __forceinline__ int fx_exp(float x) { return (int)((__float_as_uint(x) >> 23) & 0xffu) - 126; }
 
 // The power of two a partial sum is scaled by before it is rounded: k = FX_SHIFT - E.  `base` = FX_SHIFT minus the unit-level part of
-// the field's exponent (a constant of the lane that holds the field), `op_exp` = the biased exponent of the entry's opacity for the
-// geometric fields (op < 2^(op_exp - 126)), 126 for the colour / inverse-depth weights.  Kept inside a float's exponent range.
+// the field's exponent (a constant of the lane that holds the field), `op_exp` = 126 (the opacity bound is part of `base`), or -- builds
+// with GMS_FX_ENTRY_OPACITY=1 -- the biased exponent of the entry's own opacity for the geometric fields (op < 2^(op_exp - 126)).
+// Kept inside a float's exponent range.
 __device__ __forceinline__ int fx_scale_exp(int base, uint32_t op_exp) { return min(max(base + 126 - (int)op_exp, -100), 100); }
 
 // round(y * 2^k) as a 64-bit integer for |y| * 2^k <= 2^47: the product with a power of two is exact in float, and adding 1.5 * 2^52 in
