@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // |colour component| of the tile's splats (the colour behind a splat is a convex combination of those: ImageState::tile_cmax, raised
 // by the forward launches), D1 / Dd the tile's largest sum_c |dL/dpixel_c| / |dL/dinvdepth|, 1/depth <= 1/0.2, T <= 1 and
 // Tfinal / (1 - alpha) <= T; |dx| <= X, |dy| <= Y, the largest centre-to-corner distances of the unit's splats; the colour weights
-// w <= 1; OP the unit's largest opacity.  A factor 2 covers the rounding of T and of the colour behind.  Every bound is taken over the
+// w <= 1; OP the unit's largest opacity.  A factor 2 covers |c - behind| <= 2 Cmax for colours of either sign (colors_precomp; SH colours
+// are clamped at zero and need half of it).  Rounding (T a few ulps above 1) is covered by the headroom behind the bound: the conversion
+// is exact up to 2^51 and sixteen adds of 2^51 still fit 64 bits, so a bound exceeded 8-fold would be summed exactly all the same.
+// Every bound is taken over the
 // whole UNIT, so a field's scale 2^(47 - E) is ONE constant per unit for the lane that holds the field, and the walks pay for the
 // conversion alone: a float multiply by that constant, a conversion to double, the add of the magic number 1.5 * 2^52 and one integer
 // add on the high word -- four instructions per entry.  Measured on the way (HIP events): exponents from every entry's own centre,
