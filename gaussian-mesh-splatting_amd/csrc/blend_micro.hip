@@ -183,21 +183,35 @@ __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, 
 }
 
 // ------------------------------------------------------------------------------------ the unit, resident in LDS
+// largest value of a wave's 64 lanes (non-negative inputs), valid in lane 63: DPP row operations, no LDS
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false)));
+}
+__device__ __forceinline__ float wave_max_to_lane63(float v)
+{
+    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
+    v = dpp_max<0x142, 0xa>(v); v = dpp_max<0x143, 0xc>(v);
+    return v;
+}
+
 template <bool WITHD> struct RecTail { using type = float2; };          // b, 1/depth
 template <> struct RecTail<false> { using type = float; };              // b alone (the backward without an inverse-depth gradient)
 __device__ __forceinline__ void set_tail(float2 &d, float b, float invd) { d = make_float2(b, invd); }
 __device__ __forceinline__ void set_tail(float &d, float b, float) { d = b; }
 __device__ __forceinline__ float2 get_tail(const float2 &d) { return d; }
 __device__ __forceinline__ float2 get_tail(const float &d) { return make_float2(d, 0.f); }
-template <bool WITHD>
+template <bool WITHD, int LM = LMAX>
 struct UnitRecsT {
-    float4 ra[LMAX];           // pix.x, pix.y, conic A, conic B
-    float4 rb[LMAX];           // conic C, opacity', r, g
-    typename RecTail<WITHD>::type rc[LMAX];
-    uint8_t list[16][LMAX];    // per 4x4 block: the entries that reach it, in list (depth) order
+    static constexpr int CAP = LM;      // entries the image holds (the frame's segment length must not exceed it)
+    float4 ra[LM];             // pix.x, pix.y, conic A, conic B
+    float4 rb[LM];             // conic C, opacity', r, g
+    typename RecTail<WITHD>::type rc[LM];
+    uint8_t list[16][LM];      // per 4x4 block: the entries that reach it, in list (depth) order
     uint16_t ocnt[16];         // list lengths, longest first
     uint8_t order[16];         // ... and whose they are
-    uint8_t wcnt[4][16];       // staging: a wave's hits per block (<= 64)
+    uint8_t wcnt4[16][4];      // staging: per block, the hits of each of the four waves (<= 64): one dword per block
 };
 using UnitRecs = UnitRecsT<true>;
 
@@ -212,8 +226,8 @@ template <> __device__ __forceinline__ uint32_t list_load<4>(const uint8_t *lst,
 // `cmax_out` (forward launches): the largest |colour component| of the unit's splats is folded into the tile's maximum
 // (ImageState::tile_cmax; one integer atomic per wave), which the backward needs to bound the colour behind a splat.
 // Returns the Gaussian id of the thread's entry.
-template <bool FILTER, bool WITHD>
-__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD> &S, const SplatRec *rec, uint32_t *cmax_out)
+template <bool FILTER, bool WITHD, int LM>
+__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD, LM> &S, const SplatRec *rec, uint32_t *cmax_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
@@ -227,38 +241,44 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
         if (FILTER) { mask = block_mask(r, (float)(u.tx * TILE), (float)(u.ty * TILE)); mm[u.beg + tid] = (uint16_t)mask; }
         S.ra[tid] = r.q0; S.rb[tid] = r.q1; set_tail(S.rc[tid], r.q2.x, r.q2.y);
         cm = fmaxf(fmaxf(fabsf(r.q1.z), fabsf(r.q1.w)), fabsf(r.q2.x));
-    } else {
+    } else if (tid < LM) {
         // a row that idles behind the end of its list reads whatever byte lies there: every record it can name must be finite
         S.ra[tid] = make_float4(0.f, 0.f, 0.f, 0.f); S.rb[tid] = make_float4(0.f, 0.f, 0.f, 0.f); set_tail(S.rc[tid], 0.f, 0.f);
     }
     if (cmax_out) {
-        for (int d = 32; d >= 1; d >>= 1) cm = fmaxf(cm, __shfl_xor(cm, d));
-        if (lane == 0 && cm > 0.f) atomicMax(cmax_out, __float_as_uint(cm));         // (non-negative floats order like their bits)
+        cm = wave_max_to_lane63(cm);              // (DPP row operations: no LDS round trips)
+        if (lane == 63 && cm > 0.f) atomicMax(cmax_out, __float_as_uint(cm));        // (non-negative floats order like their bits)
     }
+    // Lists.  One ballot per block, kept in scalar registers across the barrier; the counts of a wave go to LDS as ONE byte per
+    // (block, wave), a block's four bytes in one dword, so that after the barrier lane b reads its block's four counts with a single
+    // load and forms the wave's base (the hits of the waves in front) and the block's total with two byte-sum instructions.  (Round 5
+    // looped over the waves in front with a dependent LDS byte read each, inside every one of the sixteen block iterations: ~540 VALU
+    // and ~180 LDS instructions of staging per wave in a kernel that is bound by VALU issue -- tools/valu_bench.hip.)
+    uint64_t bal[16];
     uint32_t mycnt = 0;                        // lane b < 16: hits of block b among this wave's 64 entries
 #pragma unroll
     for (int b = 0; b < 16; b++) {
-        const uint32_t n = (uint32_t)__builtin_popcountll(__ballot((mask >> b) & 1u));
-        if (lane == b) mycnt = n;
+        bal[b] = __ballot((mask >> b) & 1u);
+        const uint32_t n = (uint32_t)__builtin_popcountll(bal[b]);          // (wave-uniform: a scalar register)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(mycnt) : "s"(n), "n"(b));
     }
-    if (lane < 16) S.wcnt[wave][lane] = (uint8_t)mycnt;
+    if (lane < 16) S.wcnt4[lane][wave] = (uint8_t)mycnt;
     __syncthreads();
-    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t w4 = *reinterpret_cast<const uint32_t *>(&S.wcnt4[lane & 15][0]);
+    // bytes of the waves in front of this one, summed (v_sad_u8 against zero adds a dword's four bytes)
+    const uint32_t basev = __builtin_amdgcn_sad_u8(w4 & ((1u << (8 * wave)) - 1u), 0u, 0u);
 #pragma unroll
     for (int b = 0; b < 16; b++) {
-        const uint64_t bal = __ballot((mask >> b) & 1u);
-        if ((mask >> b) & 1u) {
-            uint32_t base = 0;
-            for (int w = 0; w < wave; w++) base += S.wcnt[w][b];
-            S.list[b][base + (uint32_t)__builtin_popcountll(bal & lt)] = (uint8_t)tid;
-        }
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)basev, b);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[b] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[b], base));
+        if ((mask >> b) & 1u) S.list[b][pos] = (uint8_t)tid;
     }
     if (tid < 16) {
-        const uint32_t c = (uint32_t)S.wcnt[0][tid] + S.wcnt[1][tid] + S.wcnt[2][tid] + S.wcnt[3][tid];
+        const uint32_t c = __builtin_amdgcn_sad_u8(w4, 0u, 0u);
         uint32_t rank = 0;
 #pragma unroll
         for (int s0 = 0; s0 < 16; s0++) {
-            const uint32_t cs = (uint32_t)__shfl((int)c, s0);
+            const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)c, s0);
             rank += (cs > c || (cs == c && s0 < tid)) ? 1u : 0u;
         }
         S.order[rank] = (uint8_t)tid; S.ocnt[rank] = (uint16_t)c;
@@ -435,19 +455,6 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
 // (fx_exp, fx_scale_exp, fx_from_float, fx_to_float, FxTile, fx_field_base, fx_field_kind live in gms_blend.h: the test hooks run the very
 // conversions on adversarial values, tests/test_gpu_fixed_point.py)
 
-// largest value of a wave's 64 lanes (non-negative inputs), valid in lane 63: DPP row operations, no LDS
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_max(float v)
-{
-    return fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false)));
-}
-__device__ __forceinline__ float wave_max_to_lane63(float v)
-{
-    v = dpp_max<0xB1>(v); v = dpp_max<0x4E>(v); v = dpp_max<0x141>(v); v = dpp_max<0x140>(v);
-    v = dpp_max<0x142, 0xa>(v); v = dpp_max<0x143, 0xc>(v);
-    return v;
-}
-
 // Backward.  The rows of a wave are aligned at the BOTTOM of their lists: global trip position `pos` is the same list index
 // for every row (rows whose list ends below it idle), so a trip's entry bytes are one aligned LDS read per NE entries.
 // FIXED (default): the gradient table is 64-bit fixed point (above), integer LDS atomics; FIXED = false keeps the float table of
@@ -459,13 +466,14 @@ __device__ __forceinline__ float wave_max_to_lane63(float v)
 #define GMS_FX_ENTRY_OPACITY 0
 #endif
 constexpr bool FX_ENTRY_OPACITY = GMS_FX_ENTRY_OPACITY != 0;      // 1: the exponent of every entry's own opacity (3 more instructions per entry, up to 8 bits tighter)
-template <bool INVD, int NE, int FAULT, bool DET = false, bool FIXED = true>
+template <bool INVD, int NE, int FAULT, bool DET = false, bool FIXED = true, int LM = LMAX>
 __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdArgs a)
 {
     static_assert(!DET || FIXED, "the deterministic mode is built on the fixed-point table");
     constexpr int NF = INVD ? 10 : 9;                       // fields per entry of the fixed-point table (GRAD_ID last)
-    __shared__ UnitRecsT<INVD> S;
-    __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LMAX * NF * 8 : LMAX * 10 * 4];
+    constexpr uint32_t EMASK = (uint32_t)LM - 1u;           // (LM < 256: a stale list byte behind a row's end must still name a record of the image)
+    __shared__ UnitRecsT<INVD, LM> S;
+    __shared__ __attribute__((aligned(8))) unsigned char table_mem[FIXED ? LM * NF * 8 : LM * 10 * 4];
     __shared__ uint32_t tile_max[5];                        // FIXED: bits of the unit's largest sum_c |dL/dpixel_c|, |dL/dinvdepth|,
                                                             //        centre-to-corner distances in x and in y
     long long *const fxt = reinterpret_cast<long long *>(table_mem);
@@ -476,12 +484,13 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.end <= u.beg) return;
+    if (u.end - u.beg > (uint32_t)LM) return;               // (host picks the instantiation from the frame's segment length)
     const size_t HW = (size_t)g.W * g.H;
     if (FIXED) {
-        for (int k = threadIdx.x; k < LMAX * NF; k += BLOCK) fxt[k] = 0ll;
+        for (int k = threadIdx.x; k < LM * NF; k += BLOCK) fxt[k] = 0ll;
         if (threadIdx.x < 5) tile_max[threadIdx.x] = 0u;
     } else {
-        for (int k = threadIdx.x; k < LMAX * 10; k += BLOCK) table_all[k] = 0.f;
+        for (int k = threadIdx.x; k < LM * 10; k += BLOCK) table_all[k] = 0.f;
     }
     const uint32_t my_id = unit_stage<false, INVD>(g, u, S, a.rec, nullptr);          // (its barriers also order the table clear)
     ph.mark(1);
@@ -503,13 +512,13 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
         // the unit's bounds: largest sum_c |dL/dpixel_c| (the block's 256 lanes hold the tile's 256 pixels), |dL/dinvdepth|, and
         // centre-to-corner distances of its splats (entry threadIdx.x; the records behind the unit's end are zero)
         const float tx0 = (float)(u.tx * TILE), ty0 = (float)(u.ty * TILE);
-        const float4 mine = S.ra[threadIdx.x];
+        const float4 mine = S.ra[threadIdx.x & EMASK];
         const bool real = (uint32_t)threadIdx.x < u.end - u.beg;
         const float m_d1 = wave_max_to_lane63((fabsf(dp0) + fabsf(dp1)) + fabsf(dp2));
         const float m_x = wave_max_to_lane63(real ? fmaxf(fabsf(mine.x - tx0), fabsf(mine.x - tx0 - 15.f)) + 1.f : 1.f);
         const float m_y = wave_max_to_lane63(real ? fmaxf(fabsf(mine.y - ty0), fabsf(mine.y - ty0 - 15.f)) + 1.f : 1.f);
         const float m_dd = INVD ? wave_max_to_lane63(fabsf(dinvd)) : 0.f;
-        const float m_op = FX_ENTRY_OPACITY ? 0.f : wave_max_to_lane63(fabsf(S.rb[threadIdx.x].y));
+        const float m_op = FX_ENTRY_OPACITY ? 0.f : wave_max_to_lane63(real ? fabsf(S.rb[threadIdx.x & EMASK].y) : 0.f);
         if (lane == 63) {          // (non-negative floats order like their bits; integer LDS atomics run at the rate of stores)
             atomicMax(&tile_max[0], __float_as_uint(m_d1)); if (INVD) atomicMax(&tile_max[1], __float_as_uint(m_dd));
             atomicMax(&tile_max[2], __float_as_uint(m_x)); atomicMax(&tile_max[3], __float_as_uint(m_y));
@@ -599,7 +608,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t pos = (uint32_t)g0 + (uint32_t)(NE - 1 - e);          // descending within the trip
-            se[e] = (ep >> (8 * (NE - 1 - e))) & 0xffu;
+            se[e] = (ep >> (8 * (NE - 1 - e))) & (0xffu & EMASK);
             const float4 r0 = S.ra[se[e]];
             r1[e] = S.rb[se[e]]; r2[e] = get_tail(S.rc[se[e]]);
             dx[e] = r0.x - p.xf; dy[e] = r0.y - p.yf;
@@ -719,6 +728,16 @@ int32_t launch_micro_backward(const BlendGrid &g_in, const BlendBwdArgs &a, uint
         auto kern = invd ? micro_bwd_kernel<true, 2, 0, false, false> : micro_bwd_kernel<false, 2, 0, false, false>;
         GMS_LAUNCH(GMS_K_BLEND_BWD, stream, kern<<<blocks, BLOCK, 0, stream>>>(g, a));
     } else {
+#if GMS_EXPERIMENTS
+        // Occupancy experiment (make EXPERIMENTS=1, GMS_SEG_LEN=128): a 128-entry unit image is 16 KB of LDS -> 8 blocks per CU instead
+        // of 5.  Measured (round 6, profiles/r06c_*): 126.2 us against 125.7 -- 8 192 resident waves instead of 5 120, the same ~2 400 of
+        // them in the walk, every phase of a wave proportionally slower.  The kernel is bound by VALU issue, not by latency or occupancy.
+        if (seg_len_forced() != 0 && seg_len_forced() <= 128u && !invd) {
+            GMS_LAUNCH(GMS_K_BLEND_BWD, stream, (micro_bwd_kernel<false, 2, 0, false, true, 128><<<blocks, BLOCK, 0, stream>>>(g, a)));
+            GMS_KERNEL_CHECK(debug, stream, "micro_bwd");
+            return GMS_OK;
+        }
+#endif
         auto kern = trip == 1 ? (invd ? micro_bwd_kernel<true, 1, 0> : micro_bwd_kernel<false, 1, 0>)
                   : trip == 4 ? (invd ? micro_bwd_kernel<true, 4, 0> : micro_bwd_kernel<false, 4, 0>)
                               : (invd ? micro_bwd_kernel<true, 2, 0> : micro_bwd_kernel<false, 2, 0>);

@@ -110,6 +110,11 @@ __device__ __forceinline__ void rot_to_quat(const Frame &f, float q[4], QuatSel 
     }
 }
 
+// host: sizes / tables of a GmsMeshArgs are consistent (F * splats_per_face == P or the CSR tables present, a known alpha_mode, no
+// negative size, no null input); sets the error string.  `need_face_offsets` = false: the per-splat readers (splat_from_face) alone will
+// run, which use `splat_face` and not the per-face offsets.  mesh_to_gaussians.hip
+int32_t check_mesh_args(const GmsMeshArgs *A, bool need_face_offsets = true);
+
 __device__ __forceinline__ int splat_to_face(const GmsMeshArgs &a, int64_t p)
 {
     return a.splats_per_face > 0 ? (int)(p / a.splats_per_face) : a.splat_face[p];

@@ -419,24 +419,25 @@ __global__ void __launch_bounds__(BLOCK) det_vertex_gather_wave_kernel(int V, co
     if (lane == 0) { dL_dvertices[3 * (size_t)v] = gx; dL_dvertices[3 * (size_t)v + 1] = gy; dL_dvertices[3 * (size_t)v + 2] = gz; }
 }
 
-}  // namespace gms
-
-using namespace gms;
-
-static int32_t check_mesh_args(const GmsMeshArgs *A)
+// shared with the fused mesh input of gms_rasterize_forward (raster_forward.hip), which reads the same tables in splat_from_face
+int32_t check_mesh_args(const GmsMeshArgs *A, bool need_face_offsets)
 {
     if (!A || A->F < 0 || A->P < 0 || A->V < 0) { set_error("mesh args: negative size"); return GMS_ERR_INVALID_ARGUMENT; }
     if (A->P == 0) return GMS_OK;
     if (!A->vertices || !A->faces || !A->_alpha || !A->_scale) { set_error("mesh args: null input"); return GMS_ERR_INVALID_ARGUMENT; }
     if (A->splats_per_face > 0) {
         if ((int64_t)A->F * A->splats_per_face != A->P) { set_error("mesh args: P != F * splats_per_face"); return GMS_ERR_INVALID_ARGUMENT; }
-    } else if (!A->face_splat_offset || !A->splat_face) {
+    } else if ((need_face_offsets && !A->face_splat_offset) || !A->splat_face) {
         set_error("mesh args: non-uniform splat counts need face_splat_offset and splat_face");
         return GMS_ERR_INVALID_ARGUMENT;
     }
     if (A->alpha_mode != GMS_ALPHA_RELU && A->alpha_mode != GMS_ALPHA_SOFTMAX) { set_error("mesh args: bad alpha_mode"); return GMS_ERR_INVALID_ARGUMENT; }
     return GMS_OK;
 }
+
+}  // namespace gms
+
+using namespace gms;
 
 extern "C" int32_t gms_mesh_to_gaussians_forward(const GmsMeshArgs *A, float *alpha, float *xyz, float *scaling,
                                                  float *rotation, float *scaling_act, float *rotation_unit,

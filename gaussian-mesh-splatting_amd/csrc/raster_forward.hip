@@ -1473,6 +1473,9 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
     const GmsMeshArgs *mesh = A->mesh;          // forward-only frame straight from a mesh (gmsplat.h): K0 runs inside the preprocess thread
     if (P > 0 && mesh) {
+        // the thread of a Gaussian reads faces / vertices / _alpha through the same tables as the K0 launch: same checks
+        const int32_t mrc = check_mesh_args(mesh, false);
+        if (mrc != GMS_OK) return mrc;
         if (mesh->P != (int64_t)P || !mesh->vertices || !mesh->faces || !mesh->_alpha || !mesh->_scale || !mesh->_opacity ||
             (mesh->splats_per_face <= 0 && !mesh->splat_face) || !A->shs || !A->shs_rest || A->M != 16 || A->D != 3 || A->colors_precomp ||
             A->cov3D_precomp || (((uintptr_t)A->shs) & 15u) || (((uintptr_t)A->shs_rest) & 15u)) {
@@ -1552,7 +1555,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     uint32_t &deepest_seen = fs->deepest_seen;      // deepest tile of the previous frame of this shape
     uint32_t &units_hint = fs->units_hint;          // slowly decaying maximum of its work-unit counts (views differ)
 
-    PreArgs pa;
+    PreArgs pa{};          // (zero-initialised: `mesh` is only filled for the K0 instantiation)
     pa.P = P; pa.D = A->D; pa.M = A->M; pa.W = W; pa.H = H; pa.gx = gx; pa.gy = gy;
     pa.means3D = A->means3D; pa.shs = A->shs; pa.shs_rest = A->shs_rest; pa.colors = A->colors_precomp; pa.opac = A->opacities;
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;

@@ -478,6 +478,11 @@ std::tuple<Tensor, Tensor, Tensor> render_mesh_forward(const Tensor &vertices, c
     Tensor v = f32c(vertices), al = f32c(_alpha), sc = f32c(_scale), op = f32c(_opacity);
     const int64_t P = sc.numel();
     TORCH_CHECK(al.numel() == 3 * P && op.numel() == P && sh_dc.size(0) == P && sh_rest.size(0) == P, "render_mesh_forward: P mismatch");
+    TORCH_CHECK(faces.dim() == 2 && faces.size(1) == 3, "faces must have dimensions (num_faces, 3)");
+    TORCH_CHECK(v.dim() == 2 && v.size(1) == 3, "vertices must have dimensions (num_vertices, 3)");
+    TORCH_CHECK(faces.device() == sh_dc.device() && v.device() == sh_dc.device(), "render_mesh_forward: mesh and SH tensors live on different devices");
+    if (spf > 0) { TORCH_CHECK(faces.size(0) * spf == P, "render_mesh_forward: ", faces.size(0), " faces x ", spf, " splats per face != ", P, " Gaussians"); }
+    else { TORCH_CHECK(splat_face.defined() && splat_face.numel() == P, "render_mesh_forward: non-uniform splat counts need splat_face [P]"); }
     TORCH_CHECK(sh_dc.dim() == 3 && sh_dc.size(1) == 1 && sh_rest.dim() == 3 && sh_rest.size(1) == 15, "render_mesh_forward needs split degree-3 SH storage ([P,1,3] + [P,15,3])");
     GmsMeshArgs m = mesh_args(v, faces, al, sc, mode, spf, Tensor(), splat_face, true, op);
     // (P stands in for means3D: forward_core reads the device and the count from its first tensor argument)

@@ -141,7 +141,11 @@ def render_mesh_frame(vertices: torch.Tensor, faces: torch.Tensor, viewpoint_cam
                       scaling_modifier=1.0):
     """One forward-only frame straight from a (deformed) mesh: vertices [V,3] + faces [F,3] -> image, with the face -> Gaussian
     parameterization computed inside the rasterizer's preprocess thread (no K0 launch, no xyz / scale / rotation tensors; SURVEY.md
-    section 7 step 9).  Same image, bit for bit, as `render_animated(None, vertices[faces], ...)`; callers check `_fused_frame_ok`."""
+    section 7 step 9).  Same image, bit for bit, as `render_animated(None, vertices[faces], ...)`; callers check `_fused_frame_ok`.
+    Side effects differ from the unfused route ON PURPOSE (the frame materialises no per-Gaussian tensor): `pc._scaling` / `pc._rotation`
+    / `pc._xyz` keep the values of the last `prepare_scaling_rot()` (the undeformed mesh), and `viewspace_points` is None -- a
+    forward-only frame has no screen-space gradient to receive.  Code that saves or inspects the DEFORMED Gaussians after a frame
+    calls `render_animated` with `GMS_ANIMATE_FUSED=0` (or assigns `pc.triangles` and calls `prepare_scaling_rot()`)."""
     import diff_gaussian_rasterization as dgr
     from .mesh_op import ALPHA_MODES
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
@@ -164,6 +168,8 @@ def render_animated(idxs, triangles, viewpoint_camera, pc, pipe, bg_color: torch
         # forward-only frame (the animated drivers run under no_grad): K0 inside the preprocess thread, explicit triangles as an
         # identity-indexed mesh.  (The cached kernel sigmoid is what the unfused frame would read from get_opacity.)
         F_ = int(triangles.shape[0])
+        if F_ != int(pc._alpha.shape[0]):          # (the unfused route fails in `alpha @ triangles`: same error class here)
+            raise RuntimeError(f"render_animated: {F_} triangles for a model with {int(pc._alpha.shape[0])} faces")
         key = (triangles.device, F_)
         if key not in _identity_faces:
             _identity_faces[key] = torch.arange(3 * F_, device=triangles.device, dtype=torch.int64).reshape(F_, 3)

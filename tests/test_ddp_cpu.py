@@ -18,6 +18,29 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _spawn_world(target, world, extra=(), timeout=300):
+    """Start `world` ranks of `target(rank, world, port, q, *extra)` and return their results sorted by rank; a failed rendezvous
+    (e.g. the probed port taken in between) is retried once."""
+    last = None
+    for _ in range(2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            return sorted([q.get(timeout=timeout) for _ in range(world)], key=lambda t: t[0])
+        except Exception as e:          # noqa: BLE001 -- retried once, re-raised below
+            last = e
+        finally:
+            for p in procs:
+                p.join(timeout=60)
+                if p.is_alive():
+                    p.kill()
+    raise last
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -149,20 +172,8 @@ def _direct_worker(rank, world, port, q):
 
 def test_direct_two_phase_allreduce_equals_allreduce():
     for world in (2, 3):
-        ctx = mp.get_context("spawn")
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_direct_worker, args=(r, world, port, q)) for r in range(world)]
-        for p in procs:
-            p.start()
-        try:
-            res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
-        finally:
-            for p in procs:
-                p.join(timeout=120)
-                if p.is_alive():
-                    p.kill()
-        assert all(p.exitcode == 0 for p in procs) and all(r[1] for r in res)
+        res = _spawn_world(_direct_worker, world, timeout=180)
+        assert all(r[1] for r in res)
         for k in range(3):
             mean = sum(torch.from_numpy(r[2][k]) for r in res) / world
             for r in res:
@@ -232,15 +243,7 @@ def _factor_worker(rank, world, port, q):
 
 def test_sh_factor_exchange_world2_equals_the_sum_of_dense_gradients():
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_factor_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
+    res = _spawn_world(_factor_worker, world)
     dense = res[0][2] + res[1][2]                                   # four views in all
     scale = float(dense.abs().max())
     for rank, got, _, mode in res:
@@ -286,15 +289,7 @@ def test_packed_single_collective_exchange(world):
     """ONE all-gather of [small gradients | SH factors]: the small gradients come out as the sum over ranks, the SH gradient as
     the sum of the views' dense gradients, bit-identical on every rank (world sizes 2 and 3)."""
     import numpy as np
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_packed_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
+    res = _spawn_world(_packed_worker, world)
     for k in range(3):
         total = sum(r[1][k] for r in res)
         for r in res:
@@ -364,15 +359,7 @@ def test_exchanges_default_to_the_mean_like_allreduce_gradients(variant):
     parameter -- the SH features included -- the MEAN over the ranks, exactly what `allreduce_gradients(params, world)` gives
     on the dense gradients (round-3 advisor finding: the factor exchanges summed while everything else averaged)."""
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_default_semantics_worker, args=(r, world, port, q, variant, [1, 1])) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
+    res = _spawn_world(_default_semantics_worker, world, extra=(variant, [1, 1]))
     for rank, err, rel in res:
         assert err is None, err
         assert max(rel) <= 3e-6, (rank, rel)
@@ -380,14 +367,6 @@ def test_exchanges_default_to_the_mean_like_allreduce_gradients(variant):
 
 def test_unequal_view_counts_raise_instead_of_corrupting_the_gather():
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_default_semantics_worker, args=(r, world, port, q, "packed", [1, 2])) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
-    for p in procs:
-        p.join(60)
+    res = _spawn_world(_default_semantics_worker, world, extra=("packed", [1, 2]))
     for rank, err, _ in res:
         assert err is not None and "different numbers of views" in err, (rank, err)

@@ -89,6 +89,43 @@ def test_c_abi_rejects_an_incomplete_fused_request():
     assert rc == -1 and b"fused mesh input" in lib.gms_last_error()
 
 
+def test_fused_frame_rejects_a_mesh_that_does_not_match_the_model():
+    """F * splats_per_face must equal P before the preprocess thread indexes faces / vertices -- through the
+    python driver, through the torch binding and through the C ABI itself."""
+    import ctypes as C
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _lib
+    from games_hip.render import PipelineParams, render_animated, render_mesh_frame
+    model = _model()
+    view = syn.orbit_camera(1, width=96, height=96).to("cuda")
+    bg = torch.ones(3, device="cuda")
+    pipe = PipelineParams()
+    faces = model.faces.long()
+    with torch.no_grad():
+        tri = model.vertices[faces].float()
+        with pytest.raises(RuntimeError, match="triangles for a model"):
+            render_animated(None, tri[:-3], view, model, pipe, bg)
+        with pytest.raises(RuntimeError, match="splats per face"):
+            render_mesh_frame(model.vertices, faces[:-3], view, model, pipe, bg)
+        with pytest.raises(RuntimeError, match=r"\(num_faces, 3\)"):
+            render_mesh_frame(model.vertices, faces.reshape(-1, 1), view, model, pipe, bg)
+        assert torch.isfinite(render_mesh_frame(model.vertices, faces, view, model, pipe, bg)["render"]).all()
+    # the C ABI: a GmsMeshArgs whose F * splats_per_face != P is refused before any launch
+    lib = _lib.load()
+    a = _lib.RasterForwardArgs()
+    m = _lib.MeshArgs()
+    if True:
+        P = int(model._scale.numel())
+        m.F, m.V, m.P, m.splats_per_face = int(faces.shape[0]) - 1, int(model.vertices.shape[0]), P, int(model._alpha.shape[1])
+        buf = torch.zeros(4096, device="cuda")
+        m.vertices = m._alpha = m._scale = m._opacity = buf.data_ptr(); m.faces = faces.data_ptr()
+        a.P, a.D, a.M, a.width, a.height = P, 3, 16, 64, 64
+        a.out_color = a.out_invdepth = a.background = buf.data_ptr()
+        a.mesh = C.cast(C.pointer(m), C.c_void_p).value
+        rc = lib.gms_rasterize_forward(C.byref(a), None)
+        assert rc == -1 and b"P != F * splats_per_face" in lib.gms_last_error()
+
+
 def test_graphed_animation_replays_fused_frames():
     from games_hip.animate import GraphedAnimation
     from games_hip.render import PipelineParams, render_animated

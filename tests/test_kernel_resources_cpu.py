@@ -34,14 +34,14 @@ def test_no_kernel_spills_or_uses_scratch(table):
 
 
 def test_occupancies_design_md_argues_from(table):
-    bwd = table["micro_bwd_kernel<false, 2, 0, false, true>"]           # the shipped backward: 64-bit fixed-point table
+    bwd = table["micro_bwd_kernel<false, 2, 0, false, true, 256>"]           # the shipped backward: 64-bit fixed-point table
     assert bwd["lds"] <= 31984 and bwd["occ"] == 5                      # five blocks per CU
-    det = table["micro_bwd_kernel<false, 2, 0, true, true>"]
+    det = table["micro_bwd_kernel<false, 2, 0, true, true, 256>"]
     assert det["occ"] == 5 and det["lds"] == bwd["lds"]                 # the deterministic mode rides on the same table
-    flt = table["micro_bwd_kernel<false, 2, 0, false, false>"]          # GMS_BWD_FIXED=0: the float table, six blocks
+    flt = table["micro_bwd_kernel<false, 2, 0, false, false, 256>"]          # GMS_BWD_FIXED=0: the float table, six blocks
     assert flt["occ"] == 6 and flt["lds"] < bwd["lds"]
     for name in ("micro_head_kernel<4>", "micro_fwd_kernel<4>"):        # forward compositing: at the wave limit
         assert table[name]["occ"] == 8 and table[name]["vgpr"] <= 64, name
     pre = table["preprocess_bwd_kernel"]
     assert pre["occ"] == 3 and pre["lds"] == 53248                      # 52 KB of SH rows: three blocks per CU
-    assert table["mesh_bwd_fused_kernel"]["occ"] == 4
+    assert table["mesh_bwd_fused_kernel"]["occ"] == 5                   # (4 with the SLP vectoriser's packed operands: round 6, Makefile NOSLP)

@@ -31,7 +31,11 @@ def demangle(names):
 
 
 def remarks(src, tmp):
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function",
+    # the Makefile's per-file flags: the files it lists under NOSLP are compiled without the SLP vectoriser
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    m = re.search(r"^NOSLP\s*:=\s*(.*)$", mk, re.M)
+    noslp = ["-fno-slp-vectorize"] if m and os.path.basename(src) in m.group(1).split() else []
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function"] + noslp + [
            "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.path.join(tmp, "o.o")]
     err = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC).stderr
     kernels, cur = [], None
