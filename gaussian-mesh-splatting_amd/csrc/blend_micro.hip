@@ -145,9 +145,9 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
 // start / after the staging / before the walk / after the walk / after the block barrier / at the end, and the wave's trips.
 struct Phases {
     unsigned long long *buf; bool on;
-    __device__ __forceinline__ Phases(const BlendGrid &g) : buf(nullptr), on(false)
+    __device__ __forceinline__ Phases(const BlendGrid &g, uint32_t bit = 1024u) : buf(nullptr), on(false)
     {
-        if (dbg_on(g, 1024u) && g.dbg_buf) {
+        if (dbg_on(g, bit) && g.dbg_buf) {
             buf = g.dbg_buf + 8ull * 65536ull * (threadIdx.x >> 6) + 8ull * (blockIdx.x & 65535u);
             on = (threadIdx.x & 63) == 0;
         }
@@ -402,33 +402,56 @@ template <int NE>
 __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwdOut o, int phase)
 {
     __shared__ UnitRecs S;
+    Phases ph(g, 2048u);          // (make EXPERIMENTS=1, GMS_DBG & 2048: start / staged / end of every wave, word 6 = 1 exact walk, 2 products)
+    ph.mark(0);
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     const bool walk = u.seg == 0 ? phase <= 0
                                  : (u.nseg > 1 && u.seg != u.nseg - 1 && (phase < 0 || (u.seg < tloc_head(u.L)) == (phase == 0)));
     if (!walk) return;
+    if (u.end == u.beg) {          // an empty tile (1 320 of the headline frame's 2 500): background, nothing to stage
+        const MPix p = micro_pixel(g, u.tx, u.ty, (int)(threadIdx.x >> 4), (int)(threadIdx.x & 15));
+        if (p.inside) {
+            const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
+            o.final_T[pid] = 1.f;
+            o.n_contrib[pid] = 0u;
+            o.out_color[pid] = 0.f + 1.f * o.bg[0];
+            o.out_color[HW + pid] = 0.f + 1.f * o.bg[1];
+            o.out_color[2 * HW + pid] = 0.f + 1.f * o.bg[2];
+            o.out_invdepth[pid] = 0.f;
+        }
+        return;
+    }
     if (u.seg > 0 && phase == 1 && g.tile_dead[u.tile]) {          // products of a dead tile: nothing to walk, empty lists on record
         if (threadIdx.x < u.end - u.beg) g.mmask[u.beg + threadIdx.x] = 0;
         g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + threadIdx.x] = 0.f;
         return;
     }
     unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);
+    ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, q);
     else micro_tloc_unit<NE>(g, u, S, phase, q);
+    ph.value(6, u.seg == 0 ? 1ull : 2ull);
+    ph.mark(5);
 }
 
 template <int NE>
 __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdOut o)
 {
     __shared__ UnitRecs S;
+    Phases ph(g, 4096u);          // (GMS_DBG & 4096)
+    ph.mark(0);
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
     if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);       // last segments are first touched here
     else unit_stage<false>(g, u, S, o.rec, g.tile_cmax + u.tile);                          // middle segments: filtered by the first launch
+    ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     micro_fwd_unit<NE>(g, o, u, S, q);
+    ph.value(6, u.seg == u.nseg - 1 ? 3ull : 4ull);
+    ph.mark(5);
 }
 
 // ------------------------------------------------------------------------------------ fixed-point gradient table (round 5)
@@ -684,8 +707,10 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
 }
 
 // ------------------------------------------------------------------------------------ host
-int32_t launch_micro_forward(const BlendGrid &g, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
+int32_t launch_micro_forward(const BlendGrid &g_in, const BlendFwdOut &o, uint32_t max_units, bool debug, hipStream_t stream)
 {
+    BlendGrid g = g_in;
+    experiment_switches(g, 2048u | 4096u, stream);          // (make EXPERIMENTS=1 only: per-wave stamps of micro_head / micro_fwd)
     static int deep_env = -2;
     if (deep_env == -2) { const char *e = getenv("GMS_DEEP"); deep_env = e ? atoi(e) : -1; }
     const bool deep = deep_env >= 0 ? deep_env != 0 : g.capacity > 512ull * (uint64_t)g.T;

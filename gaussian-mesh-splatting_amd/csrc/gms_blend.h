@@ -271,7 +271,9 @@ __device__ __forceinline__ int fx_scale_exp(int base, uint32_t op_exp) { return 
 __device__ __forceinline__ long long fx_from_float(float y, int k)
 {
     const double MAGIC = 6755399441055744.0;
-    const float ys = y * __uint_as_float((uint32_t)(k + 127) << 23);
+    // saturated at +-2^50 (one v_med3): a bound exceeded more than 8-fold, or a non-finite pixel gradient, clamps this one partial sum
+    // instead of leaving wrong bits in the low mantissa (NaN -> -2^50 by v_med3's ordering, still a finite table entry)
+    const float ys = __builtin_amdgcn_fmed3f(y * __uint_as_float((uint32_t)(k + 127) << 23), -1125899906842624.f, 1125899906842624.f);
     return __double_as_longlong((double)ys + MAGIC) - __double_as_longlong(MAGIC);
 }
 

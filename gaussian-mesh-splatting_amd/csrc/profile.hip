@@ -4,6 +4,7 @@
 #include <dlfcn.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -74,11 +75,17 @@ int det_mode()
 }
 
 // ---- upstream-quirk switch (gmsplat.h)
-static int g_scale_mod_quirk = -1;          // -1: not yet read from the environment
+static std::atomic<int> g_scale_mod_quirk{-1};          // -1: not yet read from the environment (set / read from any host thread)
 int upstream_scale_mod_grad()
 {
-    if (g_scale_mod_quirk < 0) { const char *e = getenv("GMS_UPSTREAM_SCALE_MOD_GRAD"); g_scale_mod_quirk = (e && atoi(e) != 0) ? 1 : 0; }
-    return g_scale_mod_quirk;
+    int v = g_scale_mod_quirk.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("GMS_UPSTREAM_SCALE_MOD_GRAD");
+        int expected = -1;
+        g_scale_mod_quirk.compare_exchange_strong(expected, (e && atoi(e) != 0) ? 1 : 0);        // (an explicit gms_set_... that raced in wins)
+        v = g_scale_mod_quirk.load(std::memory_order_relaxed);
+    }
+    return v;
 }
 
 namespace {
@@ -232,5 +239,5 @@ extern "C" void gms_set_deterministic(int32_t on) { gms::g_det = on ? 1 : 0; }
 extern "C" int32_t gms_get_deterministic(void) { return gms::det_mode(); }
 extern "C" void gms_set_fault(int32_t fault) { gms::g_fault = (fault >= 1 && fault <= 5) ? fault : 0; }      // the five documented defects, nothing else
 extern "C" int32_t gms_get_fault(void) { return gms::fault_mode(); }
-extern "C" void gms_set_upstream_scale_mod_grad(int32_t on) { gms::g_scale_mod_quirk = on ? 1 : 0; }
+extern "C" void gms_set_upstream_scale_mod_grad(int32_t on) { gms::g_scale_mod_quirk.store(on ? 1 : 0); }
 extern "C" int32_t gms_get_upstream_scale_mod_grad(void) { return gms::upstream_scale_mod_grad(); }

@@ -1189,7 +1189,7 @@ __global__ void __launch_bounds__(256) tile_mergepath_kernel(const uint32_t *til
 }
 
 __global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_offset, const uint32_t *multi_total, const uint32_t *multi_tab,
-                                                          uint32_t max_multi, uint64_t *keys, uint64_t capacity, int passes_launched, int by_rank)
+                                                          uint32_t max_multi, uint64_t *keys, uint64_t capacity, int passes_launched)
 {
     constexpr int THREADS = 1024, CHUNK = SORT_BIG_CHUNK;
     __shared__ uint64_t s[CHUNK];
@@ -1216,42 +1216,6 @@ __global__ void __launch_bounds__(1024) tile_merge_kernel(const uint32_t *tile_o
         for (int i = tid; i < m; i += THREADS) s[i] = i < n ? g[i] : INF;
         __syncthreads();
         const int K = m / THREADS;                // 2, 4 or 8 outputs per thread
-        if (by_rank) {
-            // Round 5: merge by RANK.  A thread keeps K consecutive INPUT keys of a run and finds, for each, how many keys of the
-            // partner run precede it -- K independent binary searches whose LDS round trips overlap (11-14 dependent steps per
-            // level) instead of one co-rank search followed by a serial K-step merge (13 + 2 K dependent steps) -- and scatters
-            // the keys to  base + own index + rank.  Left run: keys of the right run strictly below; right run: keys of the left
-            // run not above (the padding keys are equal: this keeps them apart).
-            for (int w = SORT_RUN; w < m; w <<= 1) {
-                const int i0 = tid * K;
-                const int base = (i0 / (2 * w)) * (2 * w);
-                const bool left = i0 - base < w;
-                const uint64_t *other = s + base + (left ? w : 0);
-                const int own0 = i0 - base - (left ? 0 : w);
-                uint64_t key[8]; int lo[8], hi[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (k < K) { key[k] = s[i0 + k]; lo[k] = 0; hi[k] = w; }
-                for (int step = w; step > 0; step >>= 1) {          // log2(w) + 1 rounds: every interval is empty afterwards
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        if (k < K && lo[k] < hi[k]) {
-                            const int mid = (lo[k] + hi[k]) >> 1;
-                            const uint64_t o = other[mid];
-                            const bool before = left ? o < key[k] : o <= key[k];
-                            if (before) lo[k] = mid + 1; else hi[k] = mid;
-                        }
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < 8; k++)
-                    if (k < K) s[base + own0 + k + lo[k]] = key[k];
-                __syncthreads();
-            }
-            for (int i = tid; i < n; i += THREADS) g[i] = s[i];
-            return;
-        }
         for (int w = SORT_RUN; w < m; w <<= 1) {
             const int o = tid * K;
             const int base = (o / (2 * w)) * (2 * w);
@@ -1706,10 +1670,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         for (int pass = 0; pass < sort_np; pass++)
             GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_mergepath_kernel<<<max_deep, 256, 0, stream>>>(img.tile_offset, run_total, bin.deep_tab, max_deep, bin.keys,
                                                                                                    sort_tmp, capacity, sort_np, pass));
-        static int merge_by_rank = -1;      // GMS_MERGE=rank: the rank merge (measured in round 5: SLOWER, tile_sort 32.5 -> 58 us; kept for the record)
-        if (merge_by_rank < 0) { const char *e = getenv("GMS_MERGE"); merge_by_rank = (e && e[0] == 'r') ? 1 : 0; }
+        // (a merge by RANK -- K interleaved binary searches per thread instead of co-rank + serial merge -- was measured in round 5 and is
+        //  slower, tile_sort 32.5 -> 58 us: profiles/r05c_ab_merge.txt; the code is in the history of round 5)
         GMS_LAUNCH(GMS_K_TILE_SORT, stream, tile_merge_kernel<<<max_multi, 1024, 0, stream>>>(img.tile_offset, multi_total, bin.multi_tab, max_multi, bin.keys,
-                                                                                             capacity, sort_np, merge_by_rank));
+                                                                                             capacity, sort_np));
         GMS_KERNEL_CHECK(A->debug, stream, "tile_sort");
         BlendGrid g;
         g.W = W; g.H = H; g.gx = gx; g.gy = gy; g.T = T; g.scan_out = img.scan_out; g.tile_offset = img.tile_offset;

@@ -88,3 +88,18 @@ def test_sixteen_adds_are_order_independent_and_cannot_overflow():
     # the fixed-point sum is the exact sum of the float inputs to within 16 half-units
     exact = y.astype(np.float64).sum(axis=1) * 2.0 ** 47
     assert np.abs(s1.astype(np.float64) - exact).max() <= 8.0 + 1e-6 * np.abs(exact).max()
+
+
+def test_out_of_range_and_non_finite_values_saturate():
+    """a partial sum beyond 2^50 fixed-point units -- a bound exceeded more than 8-fold, or a non-finite pixel
+    gradient -- is clamped to +-2^50 instead of leaving arbitrary mantissa bits in the table: sixteen such adds still fit 64 bits, and
+    every other entry of the unit keeps its own exact value."""
+    y = np.array([2.0 ** 52, -(2.0 ** 52), 2.0 ** 60, np.inf, -np.inf, np.nan, 2.0 ** 50, 2.0 ** 49, -(2.0 ** 49), 1.0], np.float32)
+    k = np.zeros(y.size, np.int32)
+    fixed, back = _run(y, k)
+    lim = 2 ** 50
+    assert [int(v) for v in fixed[:5]] == [lim, -lim, lim, lim, -lim]
+    assert abs(int(fixed[5])) == lim                               # NaN: a finite, saturated entry (v_med3 orders it below everything)
+    assert [int(v) for v in fixed[6:]] == [lim, 2 ** 49, -(2 ** 49), 1]
+    assert np.isfinite(back).all()
+    assert 16 * lim < 2 ** 63                                       # sixteen saturated adds cannot wrap the 64-bit sum

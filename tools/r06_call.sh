@@ -17,5 +17,12 @@ phases)    # per-wave phase stamps of micro_bwd on the EXPERIMENTS build (tools/
   X=$PWD/gaussian-mesh-splatting_amd/lib_exp
   env "$@" LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=1024 timeout 300 python tools/micro_phases.py > gpurun_out/${T}_micro_bwd_phases.txt 2>&1
   tail -14 gpurun_out/${T}_micro_bwd_phases.txt | cut -c1-300 ;;
+fwdphases) # per-wave stamps of micro_head (GMS_DBG 2048) and micro_fwd (4096) on the EXPERIMENTS build: bash tools/r06_call.sh fwdphases TAG
+  T=$1; shift
+  X=$PWD/gaussian-mesh-splatting_amd/lib_exp
+  for B in 2048 4096; do
+    env "$@" LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=$B timeout 300 python tools/micro_fwd_phases.py > gpurun_out/${T}_micro_fwd_phases_$B.txt 2>&1
+    tail -12 gpurun_out/${T}_micro_fwd_phases_$B.txt | cut -c1-330
+  done ;;
 *) echo "unknown step $S"; exit 2 ;;
 esac
