@@ -215,7 +215,25 @@ def rccl_summary(path):
 
 
 BASELINE_METRIC = "train iters/s (fwd+bwd raster) @800×800, 300k Gaussians; HBM GB/s vs roofline"
-VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12     # 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-op/s (MI355X_MICROARCH.md)
+# Vector-instruction issue rate, MEASURED (tools/valu_bench.hip, profiles/r06_valu_microbenchmark.txt: 8 waves per SIMD of independent
+# chains): a plain f32 wave-instruction occupies a SIMD for 1.2 ns (DPP 1.76, packed / f64 1.8, transcendental 3.4) -- the chip clocks to
+# its power budget under vector load, so the 2 cycles at 2.4 GHz = 0.83 ns that rounds 2-5 priced against (78.6 T lane-op/s) is not
+# reachable.  256 CUs x 4 SIMDs x 64 lanes / 1.2 ns:
+VALU_NS_PLAIN = 1.2
+VALU_PEAK_TLANEOPS = 256 * 4 * 64 / VALU_NS_PLAIN * 1e9 / 1e12     # 54.6 T lane-op/s for plain instructions
+
+
+def valu_model():
+    """profiles/valu_model.json (tools/valu_mix.py): per compositing kernel the static instruction-class mix of its walk loop and the
+    mix-weighted issue cost per wave-instruction; ignored when it was made from other kernel sources than this build's."""
+    path = os.path.join(ROOT, "profiles", "valu_model.json")
+    if not os.path.exists(path):
+        return {}, "no profiles/valu_model.json"
+    with open(path) as f:
+        m = json.load(f)
+    if m.get("_source_hash") != kernel_source_hash():
+        return {}, f"profiles/valu_model.json was made from kernel sources {m.get('_source_hash')}, this build is {kernel_source_hash()}: plain-rate figures only"
+    return m.get("kernels", {}), "tools/valu_mix.py on this build's sources x tools/valu_bench.hip"
 
 
 def parse_args(argv=None):
@@ -225,6 +243,10 @@ def parse_args(argv=None):
                          "itself through torch.distributed.run on 127.0.0.1")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="the K-step timed region (barrier + synchronize on both sides, exactly K steps) is run this many times back to "
+                         "back; `value` / `ms_per_step` are the MEDIAN region, every region is listed under `repeats` (round-5 review: "
+                         "with the driver's --steps 20 one region is 8 ms -- a single sample is not a record)")
     ap.add_argument("--workload", default=None,
                     help="default: c2_hotdog_like (gs_mesh, BASELINE configs[1]/[2]) on one GPU, c4_ficus_like (gs_multi_mesh, "
                          "BASELINE configs[3]: 8 views sharded one per GPU) on several")
@@ -564,7 +586,15 @@ def main():
             for _ in range(10):
                 step()
             torch.cuda.synchronize(device)
-    elapsed = timed(step, args.steps, args.warmup, tag="headline")
+    _lib.load().gms_wait_stats(None, None, 1)          # (reset: host time spent polling for N inside the timed regions)
+    regions = [timed(step, args.steps, args.warmup, tag="headline")]
+    for _ in range(max(1, args.repeats) - 1):
+        regions.append(timed(step, args.steps, 0))
+    import ctypes as _Cw
+    _wms, _wcalls = _Cw.c_double(0.0), _Cw.c_int64(0)
+    _lib.load().gms_wait_stats(_Cw.byref(_wms), _Cw.byref(_wcalls), 0)
+    host_wait_us_per_step = 1000.0 * _wms.value / max(1, args.steps * len(regions))
+    elapsed = sorted(regions)[len(regions) // 2]          # the median region (each one: exactly K steps, bracketed as the contract says)
     ms_per_step = 1000.0 * elapsed / args.steps
     value = world * vps * args.steps / elapsed
     keep_buffers(True)          # one untimed step whose scratch stays referenced: visible count / interactions for the JSON
@@ -674,6 +704,7 @@ def main():
             if name in sq and sq[name].get("SQ_INSTS_VALU"):
                 lane_ops = sq[name]["SQ_INSTS_VALU"] * 64.0
                 kernels[name]["valu_wave_insts"] = sq[name]["SQ_INSTS_VALU"]
+                # wave-instructions x the measured 1.2 ns of a PLAIN instruction / 1 024 SIMDs: a lower bound of the issue time
                 kernels[name]["valu_issue_frac"] = round(lane_ops / (avg_us * 1e-6) / 1e12 / VALU_PEAK_TLANEOPS, 4)
         stages = {}
         for sname, (members, fn) in STAGES.items():
@@ -704,25 +735,47 @@ def main():
             kd = dict(kd, achieved_GBps=st["achieved_GBps"], frac_of_8TBps=st["frac_of_8TBps"], algorithmic_bytes=st["algorithmic_bytes"],
                       traffic=st["traffic"], avg_us=st["sum_us_per_view"])
             dom = kd["priced_with"]
+        # `bound` / `achieved` / `peak` / `frac` are the HBM form SURVEY.md 8(d) prescribes for every kernel.  For the compositing kernels
+        # that is NOT the resource that binds them (round-5 review, item 8): `binding_resource` names the one that does and `valu` prices it.
         roofline = {"kernel": dom, "avg_launch_us": kd["avg_us"], "bound": "hbm", "achieved": kd["achieved_GBps"], "peak": 8000.0,
                     "unit": "GB/s", "frac": kd["frac_of_8TBps"], "algorithmic_bytes": kd["algorithmic_bytes"],
                     "traffic": kd["traffic"], "pmc": pmc_note}
         if dom.startswith("blend"):
+            vmodel, vnote = valu_model()
             vi = kd.get("valu_wave_insts")
             ach = vi * 64.0 / (kd["avg_us"] * 1e-6) / 1e12 if vi else None
+            ns_mix = vmodel.get(dom, {}).get("ns_per_inst_mix_weighted")
+            floor_us = vi * ns_mix * 1e-3 / 1024.0 if (vi and ns_mix) else None          # wave-instructions x ns each / 1 024 SIMDs
+            roofline["binding_resource"] = ("valu_issue: the kernel issues %s vector wave-instructions per launch; at the issue costs measured on this "
+                                            "chip they need %s us of its 1 024 SIMDs, %s of the launch -- against %s of the HBM roofline.  More resident "
+                                            "waves do not shorten it (128-entry units at 8 blocks per CU: 126.2 us against 125.7, "
+                                            "profiles/r06c_*), integer LDS atomics already run at the rate of stores (round 5)"
+                                            % (f"{vi / 1e6:.1f} M" if vi else "?", f"{floor_us:.1f}" if floor_us else "?",
+                                               f"{floor_us / kd['avg_us']:.2f}" if floor_us else "?", kd["frac_of_8TBps"])) if dom == "blend_bwd" else "valu_issue + staging latency"
             roofline["valu"] = {"achieved": round(ach, 2) if ach else None, "peak": round(VALU_PEAK_TLANEOPS, 1), "unit": "Tlane-op/s",
                                 "frac": round(ach / VALU_PEAK_TLANEOPS, 4) if ach else None,
+                                "wave_insts": vi, "ns_per_inst_mix_weighted": ns_mix,
+                                "issue_time_floor_us": round(floor_us, 1) if floor_us else None,
+                                "frac_mix_weighted": round(floor_us / kd["avg_us"], 4) if floor_us else None,
+                                "mix": vmodel.get(dom, {}).get("walk_loop", {}).get("mix"), "model": vnote,
                                 "interactions_sum_n_contrib": interactions,
                                 "active_lane_frac": sq.get(dom, {}).get("active_lane_frac"),
                                 "active_pairs": sq.get(dom, {}).get("active_pairs"),
-                                "note": "vector lane-operations/s = SQ_INSTS_VALU x 64 / the HIP-event duration measured here; "
-                                        "peak = 256 CU x 4 SIMD-32 x 2.4 GHz"}
+                                "note": "vector lane-operations/s = SQ_INSTS_VALU x 64 / the HIP-event duration measured here; peak = 256 CU x 4 SIMD "
+                                        "x 64 lanes / 1.2 ns, the issue cost of a plain f32 wave-instruction measured by tools/valu_bench.hip "
+                                        "(DPP 1.76, packed / f64 1.8, transcendental 3.4 ns); `frac_mix_weighted` prices the walk loop's own "
+                                        "instruction mix"}
         std = workload in ("c2_hotdog_like", "c4_ficus_like") and size == 800
         out = {
             "metric": BASELINE_METRIC if std else f"train iters/s (fwd+bwd raster) @{size}×{size}, {round(P / 1000)}k Gaussians; HBM GB/s vs roofline",
             "value": round(value, 2), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "repeats": {"n": len(regions), "ms_per_step": [round(1000.0 * r / args.steps, 4) for r in regions],
+                        "median": round(ms_per_step, 4), "min": round(1000.0 * min(regions) / args.steps, 4),
+                        "max": round(1000.0 * max(regions) / args.steps, 4),
+                        "note": "every region: exactly --steps steps between barrier + synchronize on both sides; value = the median region"},
+            "host_wait_us_per_step": round(host_wait_us_per_step, 1),
             "config": {"workload": f"{desc['text']}, SH degree 3, {size}x{size}, orbit camera k=(rank*views+v)%8, white bg",
                        "model": desc["model"], "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
                        "interactions": interactions, "interactions_kind": stats.get("interactions_kind"),

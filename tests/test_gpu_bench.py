@@ -36,6 +36,10 @@ def test_single_gpu_line_has_the_contract_fields():
         assert k["frac_of_8TBps"] is None or k["frac_of_8TBps"] > 0, name
         assert (k["frac_of_8TBps"] is None) == ("priced_with" in k), name
     assert 0.0 < d["kernel_timing"]["event_overhead_us"] < 20.0
+    # round 6: the K-step region is repeated and the MEDIAN region is the record; the host's wait for N is on the line
+    rp = d["repeats"]
+    assert rp["n"] == 5 and len(rp["ms_per_step"]) == 5 and rp["min"] <= rp["median"] <= rp["max"] and rp["median"] == d["ms_per_step"]
+    assert d["host_wait_us_per_step"] >= 0.0
 
 
 def test_kernel_table_sums_to_no_more_than_the_step():

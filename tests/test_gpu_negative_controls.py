@@ -127,3 +127,30 @@ def test_a_skipped_re_zero_of_the_gradient_records_fails_the_criterion(fault):
         _assert(inputs, kw, gc, o, h_bad, where="negative control 3: stale gradient records")
     h_ok = U.hip_render(inputs, kw, grad_color=gc)   # ... which that backward re-zeroed: the following frame is clean again
     _assert(inputs, kw, gc, o, h_ok, where="negative control 3: recovered")
+
+
+@pytest.mark.parametrize("det", [True, False])
+def test_small_entry_check_on_hip_gradients(det):
+    """Round-5 review, item 9 (CPU twin: tests/test_oracle_raster.py::test_small_entry_check_closes_the_blind_spot_of_the_allclose_rule).
+    The HIP gradients themselves pass the purely relative check of the entries between 1e-6 and 1e-3 of each tensor's largest -- in the
+    deterministic mode with K = 4 and not one violation -- and the same gradients with the faintest 1 % of the live Gaussians off by
+    5 % fail it, on a scene where `assert_grads` (allclose with a 1e-6 max|g| floor) accepts that defect."""
+    import diff_gaussian_rasterization as dgr
+    inputs, kw, gc, o = _case(4000, 1, 160, 128, scale_lo=0.01, scale_hi=0.1)
+    g64 = U.oracle_render(inputs, kw, gc, precision="f64")["grads"]
+    reals = U.f32_realisations(inputs, kw, gc) + [o["grads"]]
+    skip = U.excused_rows(o["details"]) | U.alt_oracles(inputs, kw, gc, None, o["details"])[0]
+    was = dgr.deterministic()
+    dgr.set_deterministic(det)
+    try:
+        h = U.hip_render(inputs, kw, grad_color=gc)
+    finally:
+        dgr.set_deterministic(was)
+    _assert(inputs, kw, gc, o, h, where="small-entry control: undamaged")
+    rep = U.assert_small_entries(h["grads"], g64, reals, where="hip, undamaged", strict=det, skip_rows=skip)
+    assert sum(v["band"] for v in rep.values()) > 1000
+    for key in ("scales", "means3D", "opacities"):
+        bad = U.faint_row_defect(h["grads"], g64, key)
+        _assert(inputs, kw, gc, o, dict(grads=bad), where="small-entry control: the allclose rule does not see the defect on " + key)
+        with pytest.raises(AssertionError, match="small entries"):
+            U.assert_small_entries(bad, g64, reals, where="hip, defect on " + key, strict=det, skip_rows=skip)

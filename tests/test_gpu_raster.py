@@ -28,7 +28,7 @@ def _check(inputs, kw, W, H, gd=True, q=0.999):
                                      lambda: U.oracle_render(inputs, kw, gc, gdm, precision="f64")["grads"], q=q,
                                      where=f"P={inputs['means3D'].shape[0]} {W}x{H}", excuse=U.excused_rows(o["details"]),
                                      go32acc_fn=lambda: U.f32_realisations(inputs, kw, gc, gdm),
-                                     alt=U.alt_oracles(inputs, kw, gc, gdm, o["details"]))
+                                     alt=U.alt_oracles(inputs, kw, gc, gdm, o["details"]), small=True)
     rep = U.forward_report(h, o, W, H)
     assert rep["radii_unexplained"] == 0, rep
     assert rep["amb_frac"] < 0.01, rep

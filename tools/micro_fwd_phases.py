@@ -53,3 +53,14 @@ ts = np.linspace(0, en[live].max(), 24)
 s_, e_, m_ = st[live], en[live], mid[live]
 print("resident waves over time :", [int(((s_ <= x) & (e_ > x)).sum()) for x in ts])
 print("... of which walking     :", [int(((m_ <= x) & (e_ > x)).sum()) for x in ts])
+# the stragglers: the blocks that end last -- when they started, how long they staged and walked, what they are
+bend = en[:, blk].max(axis=0); bst = st[:, blk].min(axis=0); bmid = mid[:, blk].max(axis=0)
+order = np.argsort(-bend)[:24]
+print("last blocks to end (block index: start -> staged -> end us, kind):")
+print("  " + "  ".join(f"{int(blk[i])}: {bst[i]:.1f}->{bmid[i]:.1f}->{bend[i]:.1f} k{int(kind[0, blk[i]])}" for i in order))
+for frac in (0.5, 0.8, 0.9, 0.95, 0.99):
+    print(f"  {100 * frac:.0f} % of the blocks have ended by {np.quantile(bend, frac):.1f} us", end=";")
+print()
+late = bend > np.quantile(bend, 0.97)
+print(f"the last 3 % of blocks: start mean {bst[late].mean():.1f} (all: {bst.mean():.1f}), staging mean {(bmid - bst)[late].mean():.1f} (all {(bmid - bst).mean():.1f}), "
+      f"walk mean {(bend - bmid)[late].mean():.1f} (all {(bend - bmid).mean():.1f}), block index mean {blk[late].mean():.0f} of {blk.max()}")
