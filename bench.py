@@ -275,6 +275,10 @@ def parse_args(argv=None):
                          "factor: all-gather of the per-view [P,3] colour-gradient factors + local expansion (gms_sh_grad_expand) next to an "
                          "all-reduce of the remaining 6.6 MB; packed: ONE all-gather of [small gradients | factors], summed locally; "
                          "auto = a short timed run of the step with each, the fastest wins (all three times are reported)")
+    ap.add_argument("--no-fused-k0", action="store_true",
+                    help="keep the mesh -> Gaussian step (K0) an eager launch of its own.  Default at one view per step on a single-mesh "
+                         "model: update_alpha() / prepare_scaling_rot() defer it and render() derives the Gaussians inside the rasterizer's "
+                         "preprocess thread (games_hip.model.HipMeshMixin.hip_defer_k0; same calls, same image, same gradients)")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -443,7 +447,13 @@ def main():
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
         del big, flat
 
+    from games_hip.model import HipMeshMixin, HipFlameMixin
+    fused_k0 = (not args.no_fused_k0 and args.mode == "train" and isinstance(model, HipMeshMixin) and not isinstance(model, HipFlameMixin))
+
     def make_step(vps, reduce_grads, sh_mode=None):
+        # K0 inside the preprocess thread: one view per step (several views would each redo the mesh backward), no gradient exchange
+        # hooked on get_xyz
+        model.hip_defer_k0 = bool(fused_k0 and vps == 1 and not (reduce_grads and distributed))
         sh_mode = sh_mode_default if sh_mode is None else sh_mode
         sh_factor = sh_mode == "factor"
         """One step = K0 forward (once: the parameters are the same for all its views) + vps x (render fwd + bwd) on this rank's
@@ -784,6 +794,8 @@ def main():
                        "views_per_step": world * vps, "views_per_rank_per_step": vps,
                        "parallelism": (f"view-parallel x{world}, {vps} view(s) per rank per step, one gradient all-reduce "
                                        f"per step") if world > 1 else "single view",
+                       "k0": ("inside the rasterizer's preprocess thread (update_alpha / prepare_scaling_rot deferred: games_hip.model.HipMeshMixin.hip_defer_k0)"
+                              if getattr(model, "hip_defer_k0", False) else "its own launch"),
                        "step": (f"K0 fwd + {vps} x (render fwd + bwd)" if vps > 1 else "K0 fwd + render fwd + bwd")
                                + (" + gradient all-reduce" if distributed else "")
                                + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")

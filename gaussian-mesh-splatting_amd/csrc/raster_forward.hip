@@ -64,6 +64,7 @@ struct PreArgs {
     uint32_t *zero_cmax;     // [T] per-tile colour maxima (ImageState::tile_cmax), cleared here for the micro-tile launches of this frame
     int T;
     GmsMeshArgs mesh;        // K0 instantiation only: centre / scale / rotation / opacity are derived from the mesh in the thread
+    float *k0_xyz, *k0_scale, *k0_rot, *k0_opac;   // ... and stored here for the backward (training frames; NULL: forward-only frame)
 };
 
 // SH -> RGB (before +0.5/clamp) for one channel from the coefficient row r[k*3+c] held in registers;
@@ -152,6 +153,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         for (int q = i; q < a.T; q += (int)gridDim.x * BLOCK) a.zero_cursor[q] = 0u;
     if (MODE != 2 && a.zero_cmax)
         for (int q = i; q < a.T; q += (int)gridDim.x * BLOCK) a.zero_cmax[q] = 0u;
+    if (K0 && a.mesh.prezero)          // the [V,3] buffer the mesh backward accumulates into (what spare blocks of mesh_fwd clear)
+        for (int64_t q = i; q < a.mesh.prezero_count; q += (int64_t)gridDim.x * BLOCK) a.mesh.prezero[q] = 0.f;
 
     // Fast path: every global load of this thread is issued before anything is computed, so the
     // position / scale / rotation / opacity / SH round trips overlap instead of chaining.
@@ -233,6 +236,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
             s_in[0] = sp.scale[0]; s_in[1] = sp.scale[1]; s_in[2] = sp.scale[2];
             q_in = make_float4(sp.q[0], sp.q[1], sp.q[2], sp.q[3]);
             op_in = sp.opacity;
+            if (a.k0_xyz) {          // training frame: what mesh_fwd would have written, for gms_rasterize_backward / the model's attributes
+                a.k0_xyz[3 * (size_t)i] = px; a.k0_xyz[3 * (size_t)i + 1] = py; a.k0_xyz[3 * (size_t)i + 2] = pz;
+                a.k0_scale[3 * (size_t)i] = s_in[0]; a.k0_scale[3 * (size_t)i + 1] = s_in[1]; a.k0_scale[3 * (size_t)i + 2] = s_in[2];
+                *reinterpret_cast<float4 *>(a.k0_rot + 4 * (size_t)i) = q_in;
+                a.k0_opac[i] = op_in;
+            }
             view_transform(a.view, px, py, pz, vx, vy, vz); vis = vz > NEAR_Z;
         }
     } else if (valid) {
@@ -1440,6 +1449,11 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         // the thread of a Gaussian reads faces / vertices / _alpha through the same tables as the K0 launch: same checks
         const int32_t mrc = check_mesh_args(mesh, false);
         if (mrc != GMS_OK) return mrc;
+        const int outs = (A->mesh_out_xyz != nullptr) + (A->mesh_out_scaling_act != nullptr) + (A->mesh_out_rotation_unit != nullptr) + (A->mesh_out_opacity_act != nullptr);
+        if (outs != 0 && (outs != 4 || (((uintptr_t)A->mesh_out_rotation_unit) & 15u))) {
+            set_error("gms_rasterize_forward: mesh_out_* must be all NULL (forward-only frame) or all set (rotation_unit 16-byte aligned)");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
         if (mesh->P != (int64_t)P || !mesh->vertices || !mesh->faces || !mesh->_alpha || !mesh->_scale || !mesh->_opacity ||
             (mesh->splats_per_face <= 0 && !mesh->splat_face) || !A->shs || !A->shs_rest || A->M != 16 || A->D != 3 || A->colors_precomp ||
             A->cov3D_precomp || (((uintptr_t)A->shs) & 15u) || (((uintptr_t)A->shs_rest) & 15u)) {
@@ -1525,7 +1539,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     pa.scales = A->scales; pa.rots = A->rotations; pa.cov3Dp = A->cov3D_precomp; pa.view = A->viewmatrix;
     pa.proj = A->projmatrix; pa.campos = A->campos; pa.mod = A->scale_modifier; pa.tanx = A->tan_fovx;
     pa.tany = A->tan_fovy; pa.aa = A->antialiasing; pa.radii = A->radii; pa.visible = A->visible; pa.geom = geom; pa.tile_count = img.tile_count;
-    if (mesh) { pa.mesh = *mesh; pa.means3D = nullptr; pa.opac = nullptr; pa.scales = nullptr; pa.rots = nullptr; pa.cov3Dp = nullptr; }
+    if (mesh) {
+        pa.mesh = *mesh; pa.means3D = nullptr; pa.opac = nullptr; pa.scales = nullptr; pa.rots = nullptr; pa.cov3Dp = nullptr;
+        pa.k0_xyz = A->mesh_out_xyz; pa.k0_scale = A->mesh_out_scaling_act; pa.k0_rot = A->mesh_out_rotation_unit; pa.k0_opac = A->mesh_out_opacity_act;
+    }
     // Inline tile scan (see emit_instances_kernel): on the capacity-hint path, when the segment length is known up front and the
     // tile table fits the emit blocks' LDS.  GMS_INLINE_SCAN=0 keeps the separate tile_scan launch.
     static int inline_env = -1;

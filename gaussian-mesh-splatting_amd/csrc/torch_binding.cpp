@@ -96,11 +96,14 @@ struct Forward {
     int64_t num_rendered = 0, num_units = 0, capacity = 0;
     Tensor color, radii, invdepth, geom, binning, image;
 };
+// what a frame rendered straight from a mesh stores for its backward (GmsRasterForwardArgs.mesh_out_*, ABI 6)
+struct MeshOut { Tensor xyz, scaling_act, rotation_unit, opacity_act; };
 
 Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh_, const Tensor &sh_rest_, const Tensor &colors_,
                      const Tensor &opac_, const Tensor &scales_, const Tensor &rots_, const Tensor &cov_, const Tensor &view_,
                      const Tensor &proj_, const Tensor &campos_, int64_t H, int64_t W, double tanx, double tany, double mod, int64_t D,
-                     bool prefiltered, bool aa, bool debug, const Tensor &visible, bool use_hint, const GmsMeshArgs *mesh = nullptr)
+                     bool prefiltered, bool aa, bool debug, const Tensor &visible, bool use_hint, const GmsMeshArgs *mesh = nullptr,
+                     const MeshOut *mesh_out = nullptr)
 {
     // (`mesh`: the forward-only frame straight from a mesh, gmsplat.h; `means3D_` then only carries the device and P -- the SH DC tensor)
     require_gpu(means3D_); require_gpu(bg_); require_gpu(view_); require_gpu(proj_); require_gpu(campos_);
@@ -157,6 +160,10 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
     a.no_host_wait = capturing ? 1 : 0;
     a.mesh = mesh;
     if (mesh) { a.means3D = nullptr; a.opacities = nullptr; a.scales = nullptr; a.rotations = nullptr; }
+    if (mesh && mesh_out) {
+        a.mesh_out_xyz = mf(mesh_out->xyz); a.mesh_out_scaling_act = mf(mesh_out->scaling_act);
+        a.mesh_out_rotation_unit = mf(mesh_out->rotation_unit); a.mesh_out_opacity_act = mf(mesh_out->opacity_act);
+    }
     const int64_t n = gms_rasterize_forward(&a, stream_of(means3D));
     TORCH_CHECK(!(geom.failed || binning.failed || image.failed), "scratch allocation failed (out of device memory?)");
     check_rc(n, "gms_rasterize_forward");
@@ -574,6 +581,118 @@ std::vector<Tensor> mesh_to_gaussians(const Tensor &vertices, const Tensor &face
                          at::GradMode::is_enabled() && vertices.requires_grad());
 }
 
+// ---------------------------------------------------------------------------------------------- training frame straight from the mesh
+// train.py:100-108 with the K0 launch of train.py:154-157 folded into the rasterizer's preprocess thread (GmsRasterForwardArgs.mesh +
+// mesh_out_*, ABI 6): ONE autograd node from (vertices, _alpha, _scale, _opacity, SH) to the image.  Forward: no K0 launch -- the
+// preprocess thread derives its Gaussian from the face and stores xyz / activated scale / unit quaternion / sigmoid opacity (44 bytes
+// per Gaussian instead of K0's 84 written + 44 read back).  Backward: gms_rasterize_backward on those four tensors, then
+// gms_mesh_to_gaussians_backward on its gradients -- the same two kernels groups as the two-node graph, one node's worth of host work.
+class RenderMeshFn : public torch::autograd::Function<RenderMeshFn> {
+public:
+    static variable_list forward(AutogradContext *ctx, Tensor vertices_, Tensor faces, Tensor alpha_, Tensor scale_, Tensor opacity_,
+                                 Tensor sh_dc, Tensor sh_rest, Tensor means2D, int64_t mode, int64_t spf, Tensor splat_face, Tensor bg,
+                                 Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W, double tanx, double tany, double mod,
+                                 bool aa, bool debug, bool vertex_grad, bool will_backward)
+    {
+        ctx->set_materialize_grads(false);
+        require_gpu(vertices_); require_gpu(alpha_); require_gpu(scale_); require_gpu(opacity_); require_gpu(sh_dc); require_gpu(sh_rest);
+        TORCH_CHECK(faces.scalar_type() == torch::kInt64 && faces.is_contiguous() && faces.is_cuda(), "faces must be a contiguous int64 device tensor");
+        const auto dev = vertices_.device();
+        c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
+        Tensor v = f32c(vertices_), al = f32c(alpha_), sc = f32c(scale_), op = f32c(opacity_), dc = f32c(sh_dc), rest = f32c(sh_rest);
+        const int64_t P = sc.numel();
+        TORCH_CHECK(al.numel() == 3 * P && op.numel() == P && dc.size(0) == P && rest.size(0) == P, "render_mesh: P mismatch");
+        TORCH_CHECK(dc.dim() == 3 && dc.size(1) == 1 && rest.dim() == 3 && rest.size(1) == 15, "render_mesh needs split degree-3 SH storage ([P,1,3] + [P,15,3])");
+        TORCH_CHECK(faces.dim() == 2 && faces.size(1) == 3, "faces must have dimensions (num_faces, 3)");
+        TORCH_CHECK(v.dim() == 2 && v.size(1) == 3, "vertices must have dimensions (num_vertices, 3)");
+        if (spf > 0) { TORCH_CHECK(faces.size(0) * spf == P, "render_mesh: ", faces.size(0), " faces x ", spf, " splats per face != ", P, " Gaussians"); }
+        else { TORCH_CHECK(splat_face.defined() && splat_face.numel() == P, "render_mesh: non-uniform splat counts need splat_face [P]"); }
+        auto fopt = torch::TensorOptions().dtype(torch::kFloat).device(dev);
+        MeshOut mo{torch::empty({P, 3}, fopt), torch::empty({P, 3}, fopt), torch::empty({P, 4}, fopt), torch::empty_like(op)};
+        Tensor vgrad;
+        if (will_backward && vertex_grad) vgrad = torch::empty_like(v);
+        if (will_backward) {          // the backward's outputs, allocated while the host is ahead of the GPU (see RasterizeFn)
+            Backward pre = alloc_backward(mo.xyz, mo.opacity_act, dc, rest, Tensor());
+            const Tensor *ts[9] = {&pre.dmeans2D, &pre.dcolors, &pre.dopacity, &pre.dmeans3D, &pre.dcov3D, &pre.dsh, &pre.dsh_rest, &pre.dscales, &pre.drots};
+            for (int k = 0; k < 9; k++)
+                if (ts[k]->defined()) ctx->saved_data[std::string("pre") + char('0' + k)] = *ts[k];
+            ctx->saved_data["pre"] = true;
+        }
+        Tensor sf = (splat_face.defined() && splat_face.numel()) ? splat_face.to(torch::kInt).contiguous() : Tensor();
+        GmsMeshArgs m = mesh_args(v, faces, al, sc, mode, spf, Tensor(), sf, true, op);
+        m.prezero = mf(vgrad); m.prezero_count = vgrad.defined() ? vgrad.numel() : 0;
+        Tensor stand_in = dc.view({P, 3});          // (forward_core reads the device and the count from its first tensor argument)
+        Forward f = forward_core(bg, stand_in, dc, rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
+                                 3, false, aa, debug, Tensor(), true, &m, &mo);
+        ctx->save_for_backward({v, faces, al, sc, op, sf.defined() ? sf : torch::empty({0}, fopt), vgrad.defined() ? vgrad : torch::empty({0}, fopt),
+                                mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, dc, rest, f.radii, f.geom, f.binning, f.image,
+                                f32c(bg.to(dev)), f32c(view.to(dev)), f32c(proj.to(dev)), f32c(campos.to(dev))});
+        ctx->saved_data["R"] = f.num_rendered; ctx->saved_data["units"] = f.num_units; ctx->saved_data["cap"] = f.capacity;
+        ctx->saved_data["tanx"] = tanx; ctx->saved_data["tany"] = tany; ctx->saved_data["mod"] = mod; ctx->saved_data["aa"] = aa;
+        ctx->saved_data["debug"] = debug; ctx->saved_data["H"] = H; ctx->saved_data["W"] = W; ctx->saved_data["mode"] = mode;
+        ctx->saved_data["spf"] = spf; ctx->saved_data["used"] = false;
+        // the stored Gaussians are by-products for the model's attributes: gradients reach the mesh parameters through THIS node
+        ctx->mark_non_differentiable({f.radii, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act});
+        return {f.color, f.radii, f.invdepth, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act};
+    }
+
+    static variable_list backward(AutogradContext *ctx, variable_list grads)
+    {
+        auto s = ctx->get_saved_variables();
+        const Tensor &v = s[0], &faces = s[1], &al = s[2], &sc = s[3], &op = s[4];
+        Tensor sf = s[5].numel() ? s[5] : Tensor();
+        const Tensor &xyz = s[7], &sact = s[8], &runit = s[9], &oact = s[10], &dc = s[11], &rest = s[12];
+        const Tensor &radii = s[13], &geom = s[14], &binning = s[15], &image = s[16], &bg = s[17], &view = s[18], &proj = s[19], &campos = s[20];
+        const auto dev = v.device();
+        c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
+        const int64_t H = ctx->saved_data["H"].toInt(), W = ctx->saved_data["W"].toInt();
+        Tensor gcol = grads[0].defined() ? grads[0] : torch::zeros({3, H, W}, xyz.options());
+        Backward pre;
+        const bool have_pre = ctx->saved_data.count("pre") > 0;
+        if (have_pre) {
+            Tensor *ts[9] = {&pre.dmeans2D, &pre.dcolors, &pre.dopacity, &pre.dmeans3D, &pre.dcov3D, &pre.dsh, &pre.dsh_rest, &pre.dscales, &pre.drots};
+            for (int k = 0; k < 9; k++) {
+                const std::string key = std::string("pre") + char('0' + k);
+                if (ctx->saved_data.count(key)) { *ts[k] = ctx->saved_data[key].toTensor(); ctx->saved_data.erase(key); }
+            }
+            ctx->saved_data.erase("pre");
+        }
+        Backward b = backward_core(bg, xyz, radii, Tensor(), oact, sact, runit, ctx->saved_data["mod"].toDouble(), Tensor(), view, proj,
+                                   ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest, 3, campos, geom,
+                                   ctx->saved_data["R"].toInt(), ctx->saved_data["cap"].toInt(), ctx->saved_data["units"].toInt(), binning, image,
+                                   ctx->saved_data["aa"].toBool(), ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
+        // ... and through the mesh -> Gaussian parameterization (fused activations: gradients w.r.t. exp / normalize / sigmoid outputs)
+        Tensor d_vertices;
+        bool prezeroed = false;
+        if (s[6].numel() && !ctx->saved_data["used"].toBool()) { d_vertices = s[6]; prezeroed = true; ctx->saved_data["used"] = true; }
+        else d_vertices = torch::empty_like(v);
+        Tensor d_alpha = torch::empty_like(al), d_scale = torch::empty_like(sc), d_opacity = torch::empty_like(op);
+        GmsMeshArgs a = mesh_args(v, faces, al, sc, ctx->saved_data["mode"].toInt(), ctx->saved_data["spf"].toInt(), Tensor(), sf, true, op);
+        a.vertex_grad_prezeroed = prezeroed;
+        if (a.splats_per_face <= 0) {
+            // (non-uniform splat counts: the per-face part of the mesh backward walks CSR offsets this node does not carry)
+            TORCH_CHECK(false, "render_mesh backward: non-uniform splat counts take the two-node graph (mesh_to_gaussians + rasterize)");
+        }
+        check_rc(gms_mesh_to_gaussians_backward(&a, cf(b.dmeans3D), cf(b.dscales), cf(b.drots), cf(b.dopacity), mf(d_vertices), mf(d_alpha),
+                                                mf(d_scale), mf(d_opacity), stream_of(v)), "gms_mesh_to_gaussians_backward");
+        Tensor none;
+        return {d_vertices, none, d_alpha, d_scale, d_opacity, b.dsh, b.dsh_rest, b.dmeans2D,
+                none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+    }
+};
+
+std::vector<Tensor> render_mesh(const Tensor &vertices, const Tensor &faces, const Tensor &_alpha, const Tensor &_scale, const Tensor &_opacity,
+                                const Tensor &sh_dc, const Tensor &sh_rest, const Tensor &means2D, int64_t mode, int64_t spf, const Tensor &splat_face,
+                                const Tensor &bg, const Tensor &view, const Tensor &proj, const Tensor &campos, int64_t H, int64_t W, double tanx,
+                                double tany, double mod, bool aa, bool debug)
+{
+    const bool will_backward = at::GradMode::is_enabled() &&
+        (vertices.requires_grad() || _alpha.requires_grad() || _scale.requires_grad() || _opacity.requires_grad() || sh_dc.requires_grad() ||
+         sh_rest.requires_grad() || means2D.requires_grad());
+    return RenderMeshFn::apply(vertices, faces, _alpha, _scale, _opacity, sh_dc, sh_rest, means2D, mode, spf, splat_face, bg, view, proj, campos, H, W,
+                               tanx, tany, mod, aa, debug, vertices.requires_grad(), will_backward);
+}
+
 // ---------------------------------------------------------------------------------------------- fused L1 + SSIM
 class L1SsimFn : public torch::autograd::Function<L1SsimFn> {
 public:
@@ -660,6 +779,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize", &rasterize, "differentiable rasterization (autograd node in C++)", nogil());
     m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization", nogil());
     m.def("render_mesh_forward", &render_mesh_forward, "forward-only frame straight from a mesh (K0 inside the preprocess thread)", nogil());
+    m.def("render_mesh", &render_mesh, "differentiable frame straight from a mesh: [image, radii, invdepth, xyz, scaling_act, rotation_unit, opacity_act]", nogil());
     m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]", nogil());
     m.def("adam_step", &adam_step, nogil());
     m.def("set_keep_buffers", &set_keep_buffers, "keep references to the last forward's scratch tensors (diagnostics only)");

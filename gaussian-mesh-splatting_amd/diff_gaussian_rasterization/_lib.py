@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
-GMS_ABI_VERSION = 5
+GMS_ABI_VERSION = 6
 GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
 ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
 
@@ -34,7 +34,9 @@ class RasterForwardArgs(C.Structure):
         ("binning_alloc", ALLOC_FN), ("binning_ctx", C.c_void_p),
         ("image_alloc", ALLOC_FN), ("image_ctx", C.c_void_p),
         ("binning_capacity_hint", C.c_int64), ("visible", C.c_void_p), ("num_units_out", C.c_void_p), ("no_host_wait", C.c_int32),
-        ("mesh", C.c_void_p),          # ABI 5: const GmsMeshArgs * (forward-only frame straight from a mesh) or NULL
+        ("mesh", C.c_void_p),          # ABI 5: const GmsMeshArgs * (frame straight from a mesh) or NULL
+        # ABI 6: what the fused frame derived, stored for the backward (all NULL: a forward-only frame)
+        ("mesh_out_xyz", C.c_void_p), ("mesh_out_scaling_act", C.c_void_p), ("mesh_out_rotation_unit", C.c_void_p), ("mesh_out_opacity_act", C.c_void_p),
     ]
 
 

@@ -51,8 +51,33 @@ class _HipGetters:
     """get_scaling / get_rotation / get_opacity / get_features on the fused outputs; each falls back to the
     reference's formula when `_scaling` / `_rotation` / `_opacity` is not the tensor the fused value came from."""
 
+    # ---- deferred K0 (HipMeshMixin.hip_defer_k0): the derived attributes are materialised when somebody asks for them
+    def _hip_materialize(self):
+        pass
+
+    def _hip_frame_value(self, k):
+        """While K0 is deferred and nothing is being differentiated (an evaluation pass between two training steps), the getters
+        serve what the last training frame derived -- if the inputs have not changed since -- instead of launching K0."""
+        fr = self.__dict__.get("_hip_frame")
+        if fr is None or not self.__dict__.get("_hip_pending") or torch.is_grad_enabled():
+            return None
+        vertices, faces, _alpha, _scale = self._hip_inputs()
+        return fr[0][k] if fr[1] == _stamp(vertices, faces, _alpha, _scale, self._opacity) else None
+
+    @property
+    def get_xyz(self):
+        v = self._hip_frame_value(0)
+        if v is not None:
+            return v
+        self._hip_materialize()
+        return self._xyz
+
     @property
     def get_scaling(self):
+        v = self._hip_frame_value(1)
+        if v is not None:
+            return v
+        self._hip_materialize()
         act = self.__dict__.get("_hip_activated")
         if act is not None and act[0] is self._scaling:
             return act[2]
@@ -60,6 +85,10 @@ class _HipGetters:
 
     @property
     def get_rotation(self):
+        v = self._hip_frame_value(2)
+        if v is not None:
+            return v
+        self._hip_materialize()
         act = self.__dict__.get("_hip_activated")
         if act is not None and act[1] is self._rotation:
             return act[3]
@@ -67,6 +96,10 @@ class _HipGetters:
 
     @property
     def get_opacity(self):
+        v = self._hip_frame_value(3)
+        if v is not None:
+            return v
+        self._hip_materialize()
         cached = self.__dict__.get("_hip_opacity")
         if cached is not None and cached[0] is self._opacity and cached[1] == self._opacity._version:
             return cached[2]
@@ -87,6 +120,37 @@ class HipMeshMixin(_HipGetters):
 
     alpha_mode = "relu"
     _hip_scale_attr = "_scale"
+
+    # ---- deferred K0 (opt-in; games_hip/train.py and bench.py switch it on).  train.py:154-157 calls update_alpha() /
+    # prepare_scaling_rot() after every optimizer step and the next thing that happens is render() (train.py:100): with
+    # `hip_defer_k0 = True` the two calls only mark the derived attributes stale, and `games_hip.render.render` renders the frame
+    # STRAIGHT FROM THE MESH -- the face -> Gaussian arithmetic runs inside the rasterizer's preprocess thread, which also stores
+    # xyz / activated scale / unit quaternion / sigmoid opacity for the backward (GmsRasterForwardArgs.mesh_out_*, ABI 6): no K0
+    # launch, 84 + 44 bytes per Gaussian less HBM traffic, ONE autograd node from the mesh parameters to the image.  Anything
+    # else that asks for the derived values -- the property getters, save_ply, the reference's own render() -- materialises them
+    # first with the K0 launch, so every reader sees current values; only code that reads the RAW attributes (`_xyz`,
+    # `_scaling`, `_rotation`, `alpha`) directly between an optimizer step and the next render would see the previous step's,
+    # which is why the mode is opt-in (the reference's train.py has no such reader: train.py:100-157).
+    hip_defer_k0 = False
+
+    def _hip_defer_now(self):
+        return (self.hip_defer_k0 and torch.is_grad_enabled() and self.__dict__.get("_hip_tri_external") is None
+                and "_xyz" in self.__dict__ and "_scaling" in self.__dict__)          # (the first K0 of a model's life is always eager)
+
+    def _hip_materialize(self):
+        if self.__dict__.pop("_hip_pending", None):
+            keep, self.hip_defer_k0 = self.hip_defer_k0, False
+            try:
+                self.update_alpha()
+                self.prepare_scaling_rot()
+            finally:
+                self.hip_defer_k0 = keep
+
+    def _hip_fused_frame(self, xyz, scaling_act, rotation_unit, opacity_act):
+        """What a training frame rendered straight from the mesh derived (games_hip.render): served by the getters while the
+        inputs are unchanged, so that e.g. an evaluation pass right after a training step launches no K0 either."""
+        vertices, faces, _alpha, _scale = self._hip_inputs()
+        self.__dict__["_hip_frame"] = ((xyz, scaling_act, rotation_unit, opacity_act), _stamp(vertices, faces, _alpha, _scale, self._opacity))
 
     # ---- inputs of the op (overridden by the FLAME mixin, whose vertices come out of the FLAME layer)
     def _hip_inputs(self):
@@ -110,6 +174,10 @@ class HipMeshMixin(_HipGetters):
         return alpha, xyz
 
     def update_alpha(self):
+        if self._hip_defer_now():
+            self.__dict__["_hip_pending"] = True          # render() will derive the Gaussians inside the rasterizer (see hip_defer_k0)
+            return
+        self.__dict__.pop("_hip_pending", None)
         alpha, xyz = self._hip_run()
         self.alpha = alpha
         self._xyz = xyz
@@ -139,6 +207,8 @@ class HipMeshMixin(_HipGetters):
         self.__dict__["_hip_tri_external"] = value
 
     def prepare_scaling_rot(self, *unused):
+        if self.__dict__.get("_hip_pending") and self._hip_defer_now():
+            return
         tri = self.__dict__.get("_hip_tri_external")
         cached = self.__dict__.get("_hip_cached")
         vertices, faces, _alpha, _scale = self._hip_inputs()
@@ -160,6 +230,7 @@ class HipMeshMixin(_HipGetters):
         """The reference's save_ply (gaussian_mesh_model.py:189-207) reads `triangles` out of the instance
         `__dict__`; here it is a lazily gathered property, so materialise it there first (update_alpha keeps it
         fresh from then on)."""
+        self._hip_materialize()
         self.__dict__["triangles"] = self.triangles
         return super().save_ply(path)
 
@@ -186,6 +257,9 @@ class HipFlameMixin(HipMeshMixin):
         self._xyz = xyz
         self.__dict__.pop("_hip_tri", None)
         self.__dict__["_hip_tri_external"] = None
+
+    def _hip_defer_now(self):       # (the FLAME layer runs in update_alpha: K0 stays an eager launch)
+        return False
 
     def save_ply(self, path):       # GaussianFlameModel.save_ply does not read `triangles`
         return super(HipMeshMixin, self).save_ply(path)

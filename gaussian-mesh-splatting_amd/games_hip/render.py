@@ -73,7 +73,57 @@ def _zero_points(xyz: torch.Tensor) -> torch.Tensor:
     return z.detach().requires_grad_(True)
 
 
+def _fused_training_ok(pc, pipe, override_color) -> bool:
+    """Can this DIFFERENTIATED frame be rendered straight from the mesh (games_hip.model.HipMeshMixin.hip_defer_k0)?  The model
+    deferred its K0 (update_alpha() since the last optimizer step, nothing has asked for the derived values), uniform splats per
+    face, split degree-3 SH storage at full degree, the rasterizer's native SH / cov3D stages."""
+    import os
+    import diff_gaussian_rasterization as dgr
+    if not (hasattr(pc, "__dict__") and pc.__dict__.get("_hip_pending")) or not torch.is_grad_enabled():
+        return False
+    if dgr._C is None or not hasattr(dgr._C, "render_mesh") or os.environ.get("GMS_TRAIN_FUSED", "1") == "0":
+        return False
+    if override_color is not None or pipe.compute_cov3D_python or pipe.convert_SHs_python:
+        return False
+    a, fr, dc, op = getattr(pc, "_alpha", None), getattr(pc, "_features_rest", None), getattr(pc, "_features_dc", None), getattr(pc, "_opacity", None)
+    if not (torch.is_tensor(a) and a.dim() == 3 and a.is_cuda and torch.is_tensor(fr) and fr.dim() == 3 and fr.shape[1] == 15 and torch.is_tensor(dc)):
+        return False
+    P = int(a.shape[0] * a.shape[1])
+    sc = getattr(pc, getattr(pc, "_hip_scale_attr", "_scale"), None)
+    return (int(pc.active_sh_degree) == 3 and torch.is_tensor(op) and op.numel() == P and torch.is_tensor(sc) and sc.numel() == P
+            and dc.is_contiguous() and fr.is_contiguous() and dc.shape[0] == P and torch.is_tensor(getattr(pc, "faces", None)))
+
+
+def _render_training_frame_from_mesh(viewpoint_camera, pc, pipe, bg_color, scaling_modifier):
+    """train.py:100 on a model whose K0 is deferred: ONE C++ autograd node from (vertices, _alpha, _scale, _opacity, SH) to the image
+    (`_C.render_mesh`; GmsRasterForwardArgs.mesh + mesh_out_*).  Same image and gradients as the two-node graph (tests/test_gpu_fused_training.py)."""
+    import diff_gaussian_rasterization as dgr
+    from .mesh_op import ALPHA_MODES
+    vertices, faces, _alpha, _scale = pc._hip_inputs()
+    if faces.dtype != torch.int64 or not faces.is_contiguous():
+        faces = faces.long().contiguous()
+    P = int(_alpha.shape[0] * _alpha.shape[1])
+    key = (_alpha.device, (P, 3), torch.float32)
+    z = _zero_cache.get(key)
+    if z is None:
+        if len(_zero_cache) >= 8:
+            _zero_cache.clear()
+        z = _zero_cache[key] = torch.zeros((P, 3), dtype=torch.float32, device=_alpha.device)
+    screenspace_points = z.detach().requires_grad_(True)
+    H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
+    image, radii, invdepth, xyz, scaling_act, rotation_unit, opacity_act = dgr._C.render_mesh(
+        vertices, faces, _alpha, _scale, pc._opacity, pc._features_dc, pc._features_rest, screenspace_points,
+        ALPHA_MODES[getattr(pc, "alpha_mode", "relu")], int(_alpha.shape[1]), dgr._empty(_alpha.device), bg_color,
+        viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, H, W,
+        math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5), float(scaling_modifier), bool(pipe.antialiasing),
+        bool(pipe.debug))
+    pc._hip_fused_frame(xyz, scaling_act, rotation_unit, opacity_act)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii, "depth": invdepth}
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    if _fused_training_ok(pc, pipe, override_color):
+        return _render_training_frame_from_mesh(viewpoint_camera, pc, pipe, bg_color, scaling_modifier)
     xyz = pc.get_xyz
     # the reference writes `torch.zeros_like(...) + 0` and retain_grad() (renderer/gaussian_renderer/__init__.py:33-37): a
     # 3.6 MB fill + an elementwise kernel per render for a tensor whose VALUES nobody reads (the rasterizer only hands a

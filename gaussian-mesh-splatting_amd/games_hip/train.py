@@ -58,6 +58,11 @@ def training(gaussians, train_cameras: Sequence, opt: OptimizationParamsMesh, pi
         render_fn = render
     if loss_fn is None:
         from .loss import l1_ssim_loss as loss_fn
+    # K0 deferred into the rasterizer's preprocess thread while the restated render() is in use (games_hip.model.HipMeshMixin.hip_defer_k0;
+    # GMS_TRAIN_FUSED=0 keeps the eager launch): update_alpha() / prepare_scaling_rot() below then only mark the model stale
+    import os as _os
+    if hasattr(gaussians, "hip_defer_k0") and render is None and _os.environ.get("GMS_TRAIN_FUSED", "1") != "0":
+        gaussians.hip_defer_k0 = True
     viewpoint_stack = None
     reported: List[float] = []
     report_at = set(int(i) for i in report_iterations)

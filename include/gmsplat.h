@@ -46,8 +46,10 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 5   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
-                             4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset */
+#define GMS_ABI_VERSION 6   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
+                             4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset;
+                             5: GmsRasterForwardArgs.mesh (forward-only frame straight from a mesh);
+                             6: GmsRasterForwardArgs.mesh_out_* (the fused frame exports what the backward needs: training frames too) */
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -124,8 +126,19 @@ typedef struct GmsRasterForwardArgs {
      * activated scale and unit quaternion, sigmoid opacity: the arithmetic of gms_mesh_to_gaussians_forward with fused_activations,
      * bit for bit) and `means3D`, `opacities`, `scales`, `rotations` are ignored (may be NULL): the K0 launch and the 84 bytes per
      * Gaussian it writes disappear.  Needs mesh->P == P, mesh->_opacity, split degree-3 SH storage (shs + shs_rest, M = 16, D = 3)
-     * and no precomputed colours / covariances.  A frame rendered this way cannot be handed to gms_rasterize_backward. */
+     * and no precomputed colours / covariances.  `mesh->prezero` / `prezero_count` are honoured as in gms_mesh_to_gaussians_forward (the
+     * [V,3] buffer the mesh backward will accumulate into is cleared by this launch). */
     const struct GmsMeshArgs *mesh;
+    /* ABI 6 -- TRAINING frames straight from the mesh (train.py:100-108 with the K0 launch of train.py:154-157 folded into the
+     * preprocess thread).  All four NULL: a forward-only frame, which cannot be handed to gms_rasterize_backward (nothing holds its
+     * Gaussians).  All four set: the preprocess thread also stores what it derived -- exactly the xyz / scaling_activated /
+     * rotation_unit / opacity_activated outputs of gms_mesh_to_gaussians_forward, bit for bit -- 44 bytes per Gaussian instead of K0's
+     * 84 + the 44 this kernel would read back.  The caller then runs gms_rasterize_backward with those four tensors as means3D / scales
+     * / rotations / opacities and feeds its gradients to gms_mesh_to_gaussians_backward (fused_activations = 1). */
+    float *mesh_out_xyz;           /* [P,3] */
+    float *mesh_out_scaling_act;   /* [P,3] */
+    float *mesh_out_rotation_unit; /* [P,4] */
+    float *mesh_out_opacity_act;   /* [P]   */
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */

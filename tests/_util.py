@@ -357,7 +357,7 @@ def small_entry_report(gh, go64, reals, K=None, skip_rows=None):
         with np.errstate(divide="ignore", invalid="ignore"):
             ratio = np.where(noise > 0, (err - slack) / noise, np.where(err > slack, np.inf, 0.0))[band]
         rep[k] = dict(band=int(band.sum()), violations=int(viol.sum()), worst_ratio=float(ratio.max()),
-                      median_rel=float(np.median((err / np.abs(t))[band])), size=int(t.size))
+                      median_rel=float(np.median(err[band] / np.abs(t[band]))), size=int(t.size))
     return rep
 
 
