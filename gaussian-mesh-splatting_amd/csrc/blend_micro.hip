@@ -433,6 +433,8 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, q);
     else micro_tloc_unit<NE>(g, u, S, phase, q);
     ph.value(6, u.seg == 0 ? 1ull : 2ull);
+    ph.value(7, ((unsigned long long)u.idx << 40) | ((unsigned long long)(u.end - u.beg) << 28) | ((unsigned long long)u.nseg << 14) | (unsigned long long)u.seg);
+    ph.value(2, (unsigned long long)(g.tile_offset[u.tile + 1] - g.tile_offset[u.tile]));
     ph.mark(5);
 }
 
@@ -451,6 +453,8 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     micro_fwd_unit<NE>(g, o, u, S, q);
     ph.value(6, u.seg == u.nseg - 1 ? 3ull : 4ull);
+    ph.value(7, ((unsigned long long)u.idx << 40) | ((unsigned long long)(u.end - u.beg) << 28) | ((unsigned long long)u.nseg << 14) | (unsigned long long)u.seg);
+    ph.value(2, (unsigned long long)(g.tile_offset[u.tile + 1] - g.tile_offset[u.tile]));
     ph.mark(5);
 }
 
@@ -703,6 +707,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             }
         }
     }
+    ph.value(7, ((unsigned long long)u.idx << 40) | ((unsigned long long)(u.end - u.beg) << 28) | ((unsigned long long)u.nseg << 14) | (unsigned long long)u.seg);
     ph.mark(5);
 }
 

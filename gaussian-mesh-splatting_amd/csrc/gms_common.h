@@ -42,9 +42,12 @@ struct GeomState {
     SplatRec *rec;      // [P]
     float *depth;       // [P]
     uint8_t *clamped;   // [P] bit c set => colour channel c was clamped at 0
+    ushort4 *rect;      // [P] tile rectangle [minx, maxx) x [miny, maxy) as (minx, miny, maxx, maxy); all zero for a culled Gaussian.
+                        //     What emit_instances reads (with `depth`: 12 bytes per Gaussian) instead of the pixel centre out of the
+                        //     48-byte record, whose every cache line it had to fetch for 8 bytes (round 6: 25 -> 13 MB of HBM traffic)
     static __host__ __device__ size_t bytes(size_t P)
     {
-        return align_up(P * sizeof(SplatRec), 256) + align_up(P * 4, 256) + align_up(P, 256);
+        return align_up(P * sizeof(SplatRec), 256) + align_up(P * 4, 256) + align_up(P, 256) + align_up(P * sizeof(ushort4), 256);
     }
     static __host__ __device__ GeomState carve(void *base, size_t P)
     {
@@ -52,7 +55,8 @@ struct GeomState {
         char *p = (char *)base;
         g.rec = (SplatRec *)p; p += align_up(P * sizeof(SplatRec), 256);
         g.depth = (float *)p;  p += align_up(P * 4, 256);
-        g.clamped = (uint8_t *)p;
+        g.clamped = (uint8_t *)p; p += align_up(P, 256);
+        g.rect = (ushort4 *)p;
         return g;
     }
 };

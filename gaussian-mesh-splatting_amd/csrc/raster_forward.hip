@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         return;
     }
     if (valid && !vis) a.radii[i] = 0;
+    if (valid) a.geom.rect[i] = vis ? make_ushort4((unsigned short)minx, (unsigned short)miny, (unsigned short)maxx, (unsigned short)maxy)
+                                    : make_ushort4(0, 0, 0, 0);          // (the rectangle the tile counts below were taken over)
     if (valid && a.visible) a.visible[i] = vis ? 1 : 0;
     if (vis && MODE == 1) {   // geometry launch: everything but the colour words
         float ex, ey;
@@ -822,17 +824,15 @@ __global__ void __launch_bounds__(BLOCK) emit_instances_kernel(int P, int gx, in
     const int i = (int)emit_idx * BLOCK + threadIdx.x;
     // (the three loads are independent: the pixel centre and the depth of a culled Gaussian are stale words that nothing reads --
     // loading them only after `r > 0` was known put a second memory round trip into a kernel that waits 85 % of its cycles)
-    const int r = i < P ? radii[i] : 0;
-    const float2 pxy = i < P ? *reinterpret_cast<const float2 *>(geom.rec + i) : make_float2(0.f, 0.f);
+    // (two independent loads, 12 bytes per Gaussian: the tile rectangle preprocess_fwd counted over -- all zero for a culled Gaussian --
+    //  and the depth; rounds 1-5 read the radius and the pixel centre, i.e. every cache line of the 48-byte records for 8 bytes each)
+    const ushort4 rc = i < P ? geom.rect[i] : make_ushort4(0, 0, 0, 0);
     const uint32_t dbits = i < P ? __float_as_uint(geom.depth[i]) : 0u;
-    int minx = 0, miny = 0, maxx = 0, maxy = 0;
-    uint64_t key = 0;
-    if (r > 0) {
-        tile_rect(pxy.x, pxy.y, (float)r, gx, gy, minx, miny, maxx, maxy);
-        key = ((uint64_t)dbits << 32) | (uint32_t)i;
-    }
+    const int minx = rc.x, miny = rc.y, maxx = rc.z, maxy = rc.w;
     const int rw = maxx - minx;
-    const int area = r > 0 ? rw * (maxy - miny) : 0;
+    const int area = rw * (maxy - miny);
+    const uint64_t key = area > 0 ? (((uint64_t)dbits << 32) | (uint32_t)i) : 0ull;
+    (void)radii; (void)gy;
     const bool small = area <= SMALL_AREA;
     const int lane = threadIdx.x & 63;
     int cx = minx, cy = miny;

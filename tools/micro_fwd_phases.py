@@ -45,6 +45,11 @@ for k, n in names.items():
     print(f"  {n:30s} {int(m.sum()) // 4:5d} blocks  staging mean {a.mean():5.2f} p90 {np.percentile(a, 90):5.2f}   walk mean {w.mean():5.2f} p90 {np.percentile(w, 90):5.2f} max {w.max():5.2f} us"
           f"   share of wave-time: staging {100 * a.sum() / (en - st)[live].sum():4.1f} % walk {100 * w.sum() / (en - st)[live].sum():4.1f} %")
 blk = np.nonzero(live.all(axis=0))[0]
+if os.environ.get("GMS_PHASES_DUMP"):          # per-block records for offline scheduling studies (tools/unit_order_study.py)
+    w7 = b[0, blk, 7]
+    np.savez_compressed(os.environ["GMS_PHASES_DUMP"], block=blk, kind=kind[0, blk], start=st[:, blk].min(axis=0), staged=mid[:, blk].max(axis=0),
+                        end=en[:, blk].max(axis=0), unit=(w7 >> 40) & 0xffffff, entries=(w7 >> 28) & 0xfff, nseg=(w7 >> 14) & 0x3fff, seg=w7 & 0x3fff,
+                        tile_entries=b[0, blk, 2])
 bd = en[:, blk].max(axis=0) - st[:, blk].min(axis=0)
 wk = (en - mid)[:, blk]
 print(f"blocks: duration mean {bd.mean():.1f} p50 {np.percentile(bd, 50):.1f} p90 {np.percentile(bd, 90):.1f} max {bd.max():.1f} us; "

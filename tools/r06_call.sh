@@ -21,7 +21,7 @@ fwdphases) # per-wave stamps of micro_head (GMS_DBG 2048) and micro_fwd (4096) o
   T=$1; shift
   X=$PWD/gaussian-mesh-splatting_amd/lib_exp
   for B in 2048 4096; do
-    env "$@" LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=$B timeout 300 python tools/micro_fwd_phases.py > gpurun_out/${T}_micro_fwd_phases_$B.txt 2>&1
+    env "$@" GMS_PHASES_DUMP=gpurun_out/${T}_blocks_$B.npz LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=$B timeout 300 python tools/micro_fwd_phases.py > gpurun_out/${T}_micro_fwd_phases_$B.txt 2>&1
     tail -12 gpurun_out/${T}_micro_fwd_phases_$B.txt | cut -c1-330
   done ;;
 *) echo "unknown step $S"; exit 2 ;;
