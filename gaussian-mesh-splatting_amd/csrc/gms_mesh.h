@@ -144,14 +144,33 @@ __device__ __forceinline__ void barycentric(int mode, const float *raw, float al
 // What the rasterizer is handed for one splat (the fused property getters of scene/gaussian_model.py:95-115): centre, activated
 // scale, unit quaternion, sigmoid opacity.  The statements are the ones mesh_fwd_kernel executes, in its order.
 struct SplatParams { float xyz[3], scale[3], q[4], opacity; };
+// ... in two halves, so that a caller with other loads in flight can order them: `splat_inputs_load` issues the splat's own loads (face
+// indices, raw barycentrics, scale, raw opacity: ONE round trip), `splat_from_inputs` gathers the three vertices (the second, dependent
+// round trip) and computes.  preprocess_fwd's K0 instantiation puts the first half IN FRONT of its SH rows' LDS-DMA copies: loads return in
+// order, and behind the DMA the vertex gather could not even be issued before 11.5 KB per wave had landed (round 6).
+struct SplatInputs { int64_t i0, i1, i2; float raw[3], sc, op_raw; bool has_op; };
+__device__ __forceinline__ void splat_inputs_load(const GmsMeshArgs &a, int64_t p, SplatInputs &in)
+{
+    in.has_op = a._opacity != nullptr;
+    in.op_raw = in.has_op ? a._opacity[p] : 0.f;
+    const int f = splat_to_face(a, p);
+    in.i0 = a.faces[3 * (size_t)f]; in.i1 = a.faces[3 * (size_t)f + 1]; in.i2 = a.faces[3 * (size_t)f + 2];
+    in.raw[0] = a._alpha[3 * p]; in.raw[1] = a._alpha[3 * p + 1]; in.raw[2] = a._alpha[3 * p + 2];
+    in.sc = a._scale[p];
+}
+__device__ __forceinline__ void splat_from_inputs(const GmsMeshArgs &a, const SplatInputs &in, SplatParams &o);
 __device__ __forceinline__ void splat_from_face(const GmsMeshArgs &a, int64_t p, SplatParams &o)
 {
+    SplatInputs in;
+    splat_inputs_load(a, p, in);
+    splat_from_inputs(a, in, o);
+}
+__device__ __forceinline__ void splat_from_inputs(const GmsMeshArgs &a, const SplatInputs &in, SplatParams &o)
+{
 #pragma clang fp contract(off)
-    o.opacity = a._opacity ? 1.f / (1.f + expf(-a._opacity[p])) : 0.f;
-    const int f = splat_to_face(a, p);
-    V3 t0, t1, t2;
-    load_face(a, f, t0, t1, t2);
-    const float raw[3] = {a._alpha[3 * p], a._alpha[3 * p + 1], a._alpha[3 * p + 2]};
+    o.opacity = in.has_op ? 1.f / (1.f + expf(-in.op_raw)) : 0.f;
+    const V3 t0 = ldv(a.vertices, (size_t)in.i0), t1 = ldv(a.vertices, (size_t)in.i1), t2 = ldv(a.vertices, (size_t)in.i2);
+    const float raw[3] = {in.raw[0], in.raw[1], in.raw[2]};
     float al[3], rsum;
     barycentric(a.alpha_mode, raw, al, rsum);
     o.xyz[0] = al[0] * t0.x + al[1] * t1.x + al[2] * t2.x;
@@ -159,7 +178,7 @@ __device__ __forceinline__ void splat_from_face(const GmsMeshArgs &a, int64_t p,
     o.xyz[2] = al[0] * t0.z + al[1] * t1.z + al[2] * t2.z;
     Frame fr;
     face_frame(t0, t1, t2, fr);
-    const float sc = a._scale[p];
+    const float sc = in.sc;
     o.scale[0] = fmaxf(sc * EPS, 0.f) + EPS; o.scale[1] = fmaxf(sc * fr.s1, 0.f) + EPS; o.scale[2] = fmaxf(sc * fr.s2, 0.f) + EPS;
     float q[4];
     rot_to_quat(fr, q, nullptr);

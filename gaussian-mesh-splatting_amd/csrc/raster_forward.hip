@@ -166,6 +166,8 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     float s_in[3] = {0.f, 0.f, 0.f};
     float4 q_in = make_float4(1.f, 0.f, 0.f, 0.f);
     float op_in = 0.f;
+    SplatInputs k0in = {};
+    if (K0 && valid) splat_inputs_load(a.mesh, (int64_t)i, k0in);          // (in front of the SH rows' DMA: see gms_mesh.h)
     if (SHDEG >= 0) {
         const int g0 = blockIdx.x * BLOCK + wave * WAVE;
         const int rows = min(WAVE, a.P - g0);
@@ -231,7 +233,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
     if (K0) {
         if (valid) {
             SplatParams sp;
-            splat_from_face(a.mesh, (int64_t)i, sp);
+            splat_from_inputs(a.mesh, k0in, sp);
             px = sp.xyz[0]; py = sp.xyz[1]; pz = sp.xyz[2];
             s_in[0] = sp.scale[0]; s_in[1] = sp.scale[1]; s_in[2] = sp.scale[2];
             q_in = make_float4(sp.q[0], sp.q[1], sp.q[2], sp.q[3]);
