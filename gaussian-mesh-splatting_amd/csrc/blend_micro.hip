@@ -166,9 +166,57 @@ __device__ __forceinline__ float dpp_mov(float v)
 // partner lanes AND halves the number of live registers, 29 VALU in all.  Partners: lane ^ 8 (row_ror:8), 7 - lane within
 // the half row (row_half_mirror), lane ^ 2, lane ^ 1 (quad_perm).  Result: lane i of the row holds the row total of
 //   i = 0: v0   8: v5   4: v3   12: v8   2: v1   10: v6   6: v4   14: v9   odd i < 8: v2   odd i > 8: v7
+#ifndef GMS_REDUCE_BANKMASK
+#define GMS_REDUCE_BANKMASK 1
+#endif
+// One stage of the transposing reduction for a pair of values (a, b): the lanes whose stage bit is clear end up with a + a[partner], the
+// others with b + b[partner].  The stage bit is constant over a DPP BANK (four lanes) for the first two stages -- lane bit 3 (banks 2, 3)
+// with row_ror:8, lane bit 2 (banks 1, 3) with row_half_mirror -- so two DPP adds with complementary bank masks write the two halves
+// -- a disabled bank keeps what the register holds -- instead of two v_cndmask selects and one DPP add: the kernel is bound by VALU issue
+// (tools/valu_bench.hip: plain 1.2 ns, DPP 1.76 ns per wave-instruction) and the selects were a third of the reduction.  Same sums bit for
+// bit (a + b == b + a).  The s_nop covers the two wait states a DPP read needs behind the VALU write of its source.
+#define GMS_BANK_PAIR(D, A, B, CTRL, LO, HI)                                                                                          \
+    "v_add_f32_dpp " D ", " A ", " A " " CTRL " row_mask:0xf bank_mask:" LO "\n\tv_add_f32_dpp " D ", " B ", " B " " CTRL " row_mask:0xf bank_mask:" HI "\n\t"
+// five pairs (v[k], v[k + 5]) over row_ror:8: lanes 0-7 keep the sums of v[k], lanes 8-15 those of v[k + 5].  NINE: v[9] (the
+// inverse-depth weight) does not exist -- the lanes that would carry its sums (8-15 of u[4], then lane 14) are never stored, so the
+// instruction that forms them is left out and those lanes hold whatever the register held.
+template <bool NINE>
+__device__ __forceinline__ void bank_stage_ror8(const float *v, float (&u)[5])
+{
+    if (NINE)
+        asm volatile("s_nop 1\n\t"
+                     GMS_BANK_PAIR("%0", "%5", "%10", "row_ror:8", "0x3", "0xc") GMS_BANK_PAIR("%1", "%6", "%11", "row_ror:8", "0x3", "0xc")
+                     GMS_BANK_PAIR("%2", "%7", "%12", "row_ror:8", "0x3", "0xc") GMS_BANK_PAIR("%3", "%8", "%13", "row_ror:8", "0x3", "0xc")
+                     "v_add_f32_dpp %4, %9, %9 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                     : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+    else
+        asm volatile("s_nop 1\n\t"
+                     GMS_BANK_PAIR("%0", "%5", "%10", "row_ror:8", "0x3", "0xc") GMS_BANK_PAIR("%1", "%6", "%11", "row_ror:8", "0x3", "0xc")
+                     GMS_BANK_PAIR("%2", "%7", "%12", "row_ror:8", "0x3", "0xc") GMS_BANK_PAIR("%3", "%8", "%13", "row_ror:8", "0x3", "0xc")
+                     GMS_BANK_PAIR("%4", "%9", "%14", "row_ror:8", "0x3", "0xc")
+                     : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4])
+                     : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]));
+}
+// two pairs (a0, b0), (a1, b1) over row_half_mirror: lanes with bit 2 clear keep the sums of a, the others those of b
+__device__ __forceinline__ void bank_stage_half_mirror(float a0, float b0, float a1, float b1, float &w0, float &w1)
+{
+    asm volatile("s_nop 1\n\t"
+                 GMS_BANK_PAIR("%0", "%2", "%3", "row_half_mirror", "0x5", "0xa") GMS_BANK_PAIR("%1", "%4", "%5", "row_half_mirror", "0x5", "0xa")
+                 : "=&v"(w0), "=&v"(w1) : "v"(a0), "v"(b0), "v"(a1), "v"(b1));
+}
+
+template <bool NINE = false>
 __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, bool b1, bool b0)
 {
     float u[5];
+#if GMS_REDUCE_BANKMASK
+    bank_stage_ror8<NINE>(v, u);
+    float w0, w1;
+    bank_stage_half_mirror(u[0], u[3], u[1], u[4], w0, w1);
+    const float w2 = u[2] + dpp_mov<0x141>(u[2]);
+    (void)b3; (void)b2;
+#else
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         const float keep = b3 ? v[k + 5] : v[k], send = b3 ? v[k] : v[k + 5];
@@ -177,6 +225,7 @@ __device__ __forceinline__ float row_reduce10(const float *v, bool b3, bool b2, 
     const float w0 = (b2 ? u[3] : u[0]) + dpp_mov<0x141>(b2 ? u[0] : u[3]);
     const float w1 = (b2 ? u[4] : u[1]) + dpp_mov<0x141>(b2 ? u[1] : u[4]);
     const float w2 = u[2] + dpp_mov<0x141>(u[2]);
+#endif
     const float x0 = (b1 ? w1 : w0) + dpp_mov<0x4E>(b1 ? w0 : w1);
     const float x1 = w2 + dpp_mov<0x4E>(w2);
     return (b0 ? x1 : x0) + dpp_mov<0xB1>(b0 ? x0 : x1);
@@ -658,7 +707,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
                 bwd_step<INVD>(st8, act[e], r1[e], q2, dx[e], dy[e], G[e], al[e], dp0, dp1, dp2, dinvd, Tfinal_bgdot, v[e]);
             }
 #pragma unroll
-            for (int e = 0; e < NE; e++) y[e] = row_reduce10(v[e], b3, b2, b1, b0);
+            for (int e = 0; e < NE; e++) y[e] = row_reduce10<!INVD>(v[e], b3, b2, b1, b0);
         }
         // a row with no active pixel for an entry sums exact zeros: nothing to add (and its entry byte may be stale)
         if (FIXED) {

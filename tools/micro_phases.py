@@ -59,6 +59,11 @@ nz = tr > 0
 print(f"trips per wave: mean {tr.mean():.1f} p50 {np.percentile(tr, 50):.0f} p90 {np.percentile(tr, 90):.0f} max {tr.max()}; "
       f"walk time per trip {1e3 * walk[nz].sum() / tr[nz].sum():.0f} ns = {2.4 * 1e3 * walk[nz].sum() / tr[nz].sum():.0f} cycles at 2.4 GHz")
 blk = np.nonzero(live.all(axis=0))[0]
+if os.environ.get("GMS_PHASES_DUMP"):          # per-block records for offline scheduling studies (tools/unit_order_study.py)
+    w7 = b[0, blk, 7]
+    np.savez_compressed(os.environ["GMS_PHASES_DUMP"], block=blk, kind=np.full(len(blk), 5), start=t[:, blk, 0].min(axis=0), staged=t[:, blk, 2].max(axis=0),
+                        end=t[:, blk, 5].max(axis=0), unit=(w7 >> 40) & 0xffffff, entries=(w7 >> 28) & 0xfff, nseg=(w7 >> 14) & 0x3fff, seg=w7 & 0x3fff,
+                        tile_entries=np.zeros(len(blk)), trips=trips[:, blk].max(axis=0), trips_sum=trips[:, blk].sum(axis=0))
 bt = t[:, blk, :]
 bdur = bt[:, :, 5].max(axis=0) - bt[:, :, 0].min(axis=0)
 wmax = (bt[:, :, 3] - bt[:, :, 2]).max(axis=0)

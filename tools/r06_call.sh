@@ -15,7 +15,7 @@ test)      # parity subset + headline: bash tools/r06_call.sh test TAG [pytest a
 phases)    # per-wave phase stamps of micro_bwd on the EXPERIMENTS build (tools/build_experiments.sh): bash tools/r06_call.sh phases TAG [ENV...]
   T=$1; shift
   X=$PWD/gaussian-mesh-splatting_amd/lib_exp
-  env "$@" LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=1024 timeout 300 python tools/micro_phases.py > gpurun_out/${T}_micro_bwd_phases.txt 2>&1
+  env "$@" GMS_PHASES_DUMP=gpurun_out/${T}_blocks_bwd.npz LD_LIBRARY_PATH=$X:$LD_LIBRARY_PATH GMSPLAT_LIB=$X/libgmsplat.so GMS_DBG=1024 timeout 300 python tools/micro_phases.py > gpurun_out/${T}_micro_bwd_phases.txt 2>&1
   tail -14 gpurun_out/${T}_micro_bwd_phases.txt | cut -c1-300 ;;
 fwdphases) # per-wave stamps of micro_head (GMS_DBG 2048) and micro_fwd (4096) on the EXPERIMENTS build: bash tools/r06_call.sh fwdphases TAG
   T=$1; shift
