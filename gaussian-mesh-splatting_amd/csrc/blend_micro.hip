@@ -675,6 +675,7 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     int fcx, fcy, fkind;
     fx_field_kind(afield, fcx, fcy, fkind);
     const int fxbase = fx_field_base(fx, fcx, fcy, fkind);          // (the lane's field: a constant of the unit)
+    const FxScale fxs = fx_prepare(fx_scale_exp(fxbase, 126u));      // ... and with it the lane's scale 2^k and saturation bound
 
     // back to front: the trip at list position pos handles entry pos of every row's list that reaches it
     for (int g0 = (int)(((maxtop + NE - 1u) / NE) * NE) - NE; g0 >= 0; g0 -= NE) {
@@ -714,7 +715,8 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             long long val[NE];
 #pragma unroll
             for (int e = 0; e < NE; e++)          // (a pair is only ever active on a positive opacity: its bits >> 23 are its exponent)
-                val[e] = fx_from_float(y[e], fx_scale_exp(fxbase, (FX_ENTRY_OPACITY && fkind == 0) ? __float_as_uint(r1[e].y) >> 23 : 126u));
+                val[e] = FX_ENTRY_OPACITY ? fx_from_float(y[e], fx_scale_exp(fxbase, fkind == 0 ? __float_as_uint(r1[e].y) >> 23 : 126u))
+                                          : fx_from_float(y[e], fxs);
             // (adding without the test for zero was measured: 141 us against 133 -- the zeros of the idle rows are atomics too)
 #pragma unroll
             for (int e = 0; e < NE; e++)

@@ -276,6 +276,24 @@ __device__ __forceinline__ long long fx_from_float(float y, int k)
     const float ys = __builtin_amdgcn_fmed3f(y * __uint_as_float((uint32_t)(k + 127) << 23), -1125899906842624.f, 1125899906842624.f);
     return __double_as_longlong((double)ys + MAGIC) - __double_as_longlong(MAGIC);
 }
+// The same conversion with the lane's scale prepared once (the walk of micro_bwd: k is a constant of the lane and unit): the clamp is taken
+// on y itself against 2^(50 - k) and the scaling rides in the f64 FMA that adds the magic number -- v_med3, v_cvt_f64_f32, v_fma_f64 and the
+// integer add on the high word: one VALU instruction fewer per table add in a kernel bound by VALU issue (round 6).  Bit-identical to
+// fx_from_float: y 2^k is exact in float and in double alike, so the one rounding is the FMA's in both (tests/test_gpu_fixed_point.py).
+struct FxScale { double two_k; float y_max; };
+__device__ __forceinline__ FxScale fx_prepare(int k)
+{
+    FxScale s;
+    s.two_k = __longlong_as_double((long long)(k + 1023) << 52);
+    s.y_max = __uint_as_float((uint32_t)(min(50 - k, 127) + 127) << 23);          // 2^(50 - k): |y| beyond it saturates (k >= -100 -> exponent <= 150: clamped to float's range)
+    return s;
+}
+__device__ __forceinline__ long long fx_from_float(float y, const FxScale &s)
+{
+    const double MAGIC = 6755399441055744.0;
+    const float yc = __builtin_amdgcn_fmed3f(y, -s.y_max, s.y_max);
+    return __double_as_longlong(__builtin_fma((double)yc, s.two_k, MAGIC)) - __double_as_longlong(MAGIC);
+}
 
 // (exact in double, one rounding to float)
 __device__ __forceinline__ float fx_to_float(long long v, int k) { return (float)ldexp((double)v, -k); }

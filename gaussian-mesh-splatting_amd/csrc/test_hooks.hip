@@ -54,9 +54,11 @@ __global__ void __launch_bounds__(256) test_fx_kernel(int n, const float *y, con
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const long long v = fx_from_float(y[i], k[i]);
-    fixed[i] = v;
-    back[i] = fx_to_float(v, k[i]);
+    // the walk's form (scale prepared once per lane, clamp on y, scaling inside the f64 FMA) must give the bits of the plain form
+    const long long v0 = fx_from_float(y[i], k[i]);
+    const long long v = fx_from_float(y[i], fx_prepare(k[i]));
+    fixed[i] = v == v0 ? v : (long long)0x8000000000000000ull;          // (a sentinel no test value produces)
+    back[i] = fx_to_float(v0, k[i]);
 }
 
 }  // namespace gms
