@@ -239,14 +239,17 @@ __device__ __forceinline__ void bwd_step(BwdState &s, bool act, const float4 &r1
     const float rcp1ma = __builtin_amdgcn_rcpf(om);            // 1 - alpha >= 0.01; rcp(1) == 1
     s.T = s.T * rcp1ma;                                        // transmittance in front of this splat
     const float w = alpha * s.T;
-    float dL_dalpha = (r1.z - s.acc0) * dp0 + (r1.w - s.acc1) * dp1 + (r2.x - s.acc2) * dp2;
-    if (INVD) dL_dalpha += (r2.y - s.accd) * dinvd;
+    const float d0 = r1.z - s.acc0, d1 = r1.w - s.acc1, d2 = r2.x - s.acc2, dd = INVD ? r2.y - s.accd : 0.f;
+    float dL_dalpha = d0 * dp0 + d1 * dp1 + d2 * dp2;
+    if (INVD) dL_dalpha += dd * dinvd;
     dL_dalpha = dL_dalpha * s.T - Tfinal_bgdot * rcp1ma;
-    // colour composited behind the NEXT (nearer) splat
-    s.acc0 = alpha * r1.z + om * s.acc0;
-    s.acc1 = alpha * r1.w + om * s.acc1;
-    s.acc2 = alpha * r2.x + om * s.acc2;
-    if (INVD) s.accd = alpha * r2.y + om * s.accd;
+    // colour composited behind the NEXT (nearer) splat: alpha c + (1 - alpha) behind, evaluated as behind + alpha (c - behind) -- one FMA on
+    // the difference the line above already holds instead of a multiply and an FMA per channel (round 6: the walk is bound by VALU issue;
+    // the same convex combination, rounded once instead of twice)
+    s.acc0 = __fmaf_rn(alpha, d0, s.acc0);
+    s.acc1 = __fmaf_rn(alpha, d1, s.acc1);
+    s.acc2 = __fmaf_rn(alpha, d2, s.acc2);
+    if (INVD) s.accd = __fmaf_rn(alpha, dd, s.accd);
     v[6] = w * dp0; v[7] = w * dp1; v[8] = w * dp2; v[9] = INVD ? w * dinvd : 0.f;
     const float q = Gop * dL_dalpha;
     const float qx = q * dx, qy = q * dy;
