@@ -279,6 +279,10 @@ def parse_args(argv=None):
                     help="keep the mesh -> Gaussian step (K0) an eager launch of its own.  Default at one view per step on a single-mesh "
                          "model: update_alpha() / prepare_scaling_rot() defer it and render() derives the Gaussians inside the rasterizer's "
                          "preprocess thread (games_hip.model.HipMeshMixin.hip_defer_k0; same calls, same image, same gradients)")
+    ap.add_argument("--no-defer-counts", action="store_true",
+                    help="read the frame's instance count back inside the forward (the blocking form).  Default in train mode on one rank: "
+                         "diff_gaussian_rasterization.set_deferred_counts(True) -- the count is read at the start of the backward, the host runs "
+                         "ahead of the GPU by the loss; an overflowed frame raises there and the step is redone (counted on the line)")
     ap.add_argument("--optimizer", default="none", choices=["none", "fused_adam", "torch_adam"],
                     help="none: gradients are dropped after the (all-reduced) backward, the headline step; fused_adam / torch_adam: "
                          "also run optimizer.step() of the reference's training_setup() (train.py:147) with lr scaled to ~0 so "
@@ -447,6 +451,11 @@ def main():
         allreduce_bytes = 4 * (sum(b.numel() for b in big) + flat.numel())
         del big, flat
 
+    import diff_gaussian_rasterization as dgr
+    deferred_overflows = [0]
+    defer_counts = (not args.no_defer_counts and args.mode == "train" and not distributed and dgr._C is not None and not dgr.deterministic())
+    if defer_counts:
+        dgr.set_deferred_counts(True)
     from games_hip.model import HipMeshMixin, HipFlameMixin
     fused_k0 = (not args.no_fused_k0 and args.mode == "train" and isinstance(model, HipMeshMixin) and not isinstance(model, HipFlameMixin))
 
@@ -467,7 +476,28 @@ def main():
         reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed and packed is None) else None
         exchange = ShFactorExchange(model._features_dc, model._features_rest, world, force=force_ddp, average=False) if (reducer is not None and sh_factor) else None
 
+        host_sleep_s = 1e-6 * float(os.environ.get("GMS_BENCH_HOST_SLEEP_US", "0"))      # throttled-host experiment: busy host time per step
+
         def step():
+            try:
+                step_once()
+            except RuntimeError as e:          # a deferred frame outgrew its buffers: redo the step with the blocking form
+                if dgr.DEFERRED_OVERFLOW not in str(e):
+                    raise
+                deferred_overflows[0] += 1
+                for p in params:
+                    p.grad = None
+                dgr.set_deferred_counts(False)
+                try:
+                    step_once()
+                finally:
+                    dgr.set_deferred_counts(True)
+            if host_sleep_s > 0.0:
+                t_end = time.perf_counter() + host_sleep_s
+                while time.perf_counter() < t_end:
+                    pass
+
+        def step_once():
             if packed is not None:
                 packed.enable()
             if exchange is not None:
@@ -786,6 +816,8 @@ def main():
                         "max": round(1000.0 * max(regions) / args.steps, 4),
                         "note": "every region: exactly --steps steps between barrier + synchronize on both sides; value = the median region"},
             "host_wait_us_per_step": round(host_wait_us_per_step, 1),
+            "count_readback": ("deferred to the start of the backward (diff_gaussian_rasterization.set_deferred_counts); steps redone after an "
+                               f"overflow: {deferred_overflows[0]}") if defer_counts else "inside the forward (blocking)",
             "config": {"workload": f"{desc['text']}, SH degree 3, {size}x{size}, orbit camera k=(rank*views+v)%8, white bg",
                        "model": desc["model"], "gaussians": P, "faces": F, "image": [size, size], "instances_N": N,
                        "interactions": interactions, "interactions_kind": stats.get("interactions_kind"),

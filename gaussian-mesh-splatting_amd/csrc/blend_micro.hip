@@ -734,8 +734,24 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
     ph.mark(4);
     if ((uint32_t)threadIdx.x < cn) uid[threadIdx.x] = my_id;          // (over the record tails, which no walk reads any more)
     __syncthreads();
-    // flush: sixteen entries per step, ten lanes per entry on the ten fields of its 64-byte record (one cache line)
-    {
+    // flush.  Float-atomics mode: NF consecutive lanes per entry, one per field of its 64-byte record (one cache line), BLOCK / NF entries
+    // per step -- 28 (27 lanes of 256 idle) instead of the 16 of a 16-lanes-per-entry layout whose lanes NF..15 had nothing to add: ten
+    // steps instead of sixteen for a full unit (round 6: the launch is bound by VALU issue and this loop ran on every wave).
+    if (FIXED && !DET) {
+        constexpr int EPS = BLOCK / NF;                       // entries per step
+        const int f = (int)threadIdx.x % NF;
+        int cx, cy, kind;
+        fx_field_kind(f, cx, cy, kind);
+        const int kexp = fx_scale_exp(fx_field_base(fx, cx, cy, kind), 126u);
+        if ((int)threadIdx.x < EPS * NF) {
+            for (uint32_t e = threadIdx.x / NF; e < cn; e += EPS) {
+                const long long sv = fxt[e * (uint32_t)NF + (uint32_t)f];
+                if (sv != 0ll)
+                    unsafeAtomicAdd(a.accum + (size_t)uid[e] * GRAD_STRIDE + f,
+                                    fx_to_float(sv, FX_ENTRY_OPACITY && kind == 0 ? fx_scale_exp(fx_field_base(fx, cx, cy, kind), __float_as_uint(S.rb[e].y) >> 23) : kexp));
+            }
+        }
+    } else {
         const int f = threadIdx.x & 15;
         int cx, cy, kind;
         fx_field_kind(f, cx, cy, kind);

@@ -26,6 +26,7 @@
 #include <stdio.h>
 
 #include <stdlib.h>
+#include <mutex>
 
 #include "gms_blend.h"
 #include "gms_mesh.h"
@@ -1304,14 +1305,16 @@ __global__ void mark_visible_kernel(int P, const float *means3D, const float *vi
 
 // pinned, device-visible read-back slot, one per host thread: 64-bit words {call sequence number : N}, {.. : deepest tile},
 // {.. : work units}
-static int32_t *pinned_slot()
+// (slot 0: the blocking forward; slots 1 .. DEFER_SLOTS: the ring of the deferred read-back, gms_rasterize_forward_counts)
+constexpr int DEFER_SLOTS = 16, SLOT_WORDS = 16;
+static int32_t *pinned_slot(int index = 0)
 {
     static thread_local int32_t *slot = nullptr;
     if (!slot) {
-        if (hipHostMalloc((void **)&slot, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) slot = nullptr;
-        else { for (int k = 0; k < 16; k++) slot[k] = 0; }
+        if (hipHostMalloc((void **)&slot, 64 * (1 + DEFER_SLOTS), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) slot = nullptr;
+        else { for (int k = 0; k < SLOT_WORDS * (1 + DEFER_SLOTS); k++) slot[k] = 0; }
     }
-    return slot;
+    return slot ? slot + SLOT_WORDS * index : nullptr;
 }
 
 // Wait until the tile_scan kernel of call `seq` has published N.  The host spins on the pinned slot (the kernel
@@ -1426,6 +1429,21 @@ extern "C" size_t gms_image_counts_offset(int32_t w, int32_t h)
     return (size_t)(reinterpret_cast<char *>(s.scan_out) - base);
 }
 static thread_local int64_t t_last_launched_units = 0;
+// Launch-size hints learnt from earlier frames, per (host thread, device, stream, W, H, P)
+struct FrameState { int device; hipStream_t stream; int W, H, P; uint32_t deepest_seen, units_hint; };
+static thread_local std::vector<FrameState> t_frames;
+// what a redeemed ticket learnt about a frame (gms_rasterize_forward_counts, possibly on another host thread): picked up by the next forward
+// of the same (device, stream, W, H, P)
+struct HintMail { int device; hipStream_t stream; int W, H, P; uint32_t deepest, units; };
+static std::mutex g_mail_mu;
+static std::vector<HintMail> g_mail;
+static FrameState *frame_state(int device, hipStream_t stream, int W, int H, int P)
+{
+    for (auto &f : t_frames) if (f.device == device && f.stream == stream && f.W == W && f.H == H && f.P == P) return &f;
+    if (t_frames.size() >= 64) t_frames.erase(t_frames.begin());
+    t_frames.push_back({device, stream, W, H, P, 0u, 0u});
+    return &t_frames.back();
+}
 extern "C" int64_t gms_last_launched_units(void) { return t_last_launched_units; }
 static thread_local int32_t t_last_used_micro = 0;
 extern "C" int32_t gms_last_used_micro(void) { return t_last_used_micro; }
@@ -1524,13 +1542,18 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     img.tile_count = ctr->buf;
     // Launch-size hints learnt from earlier frames, per (device, stream, W, H, P): two scenes of different size
     // interleaved on one thread (or one scene on two devices) do not disturb each other's hints
-    struct FrameState { int device; hipStream_t stream; int W, H, P; uint32_t deepest_seen, units_hint; };
-    static thread_local std::vector<FrameState> t_frames;
-    FrameState *fs = nullptr;
-    for (auto &f : t_frames) if (f.device == device && f.stream == stream && f.W == W && f.H == H && f.P == P) fs = &f;
-    if (!fs) {
-        if (t_frames.size() >= 64) t_frames.erase(t_frames.begin());
-        t_frames.push_back({device, stream, W, H, P, 0u, 0u}); fs = &t_frames.back();
+    FrameState *fs = frame_state(device, stream, W, H, P);
+    {
+        std::lock_guard<std::mutex> lk(g_mail_mu);
+        for (size_t k = 0; k < g_mail.size(); k++) {
+            const HintMail &m = g_mail[k];
+            if (m.device == device && m.stream == stream && m.W == W && m.H == H && m.P == P) {
+                fs->deepest_seen = m.deepest;
+                fs->units_hint = max(m.units, (uint32_t)(0.97 * fs->units_hint));
+                g_mail.erase(g_mail.begin() + (long)k);
+                break;
+            }
+        }
     }
     uint32_t &deepest_seen = fs->deepest_seen;      // deepest tile of the previous frame of this shape
     uint32_t &units_hint = fs->units_hint;          // slowly decaying maximum of its work-unit counts (views differ)
@@ -1617,7 +1640,11 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
 #undef GMS_PRE_M
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_fwd");
     const uint32_t L = seg_len_min();         // sizes and carving; the frame's own L is chosen by the scan (scan_out[3])
-    int32_t *slot = pinned_slot();
+    // deferred read-back (gmsplat.h, count_ticket_out): this frame's counts go to the next slot of the thread's ring and nobody waits here
+    const bool defer = A->count_ticket_out != nullptr && A->binning_capacity_hint > 0 && !A->no_host_wait;
+    static thread_local uint32_t defer_counter = 0;
+    const int slot_index = defer ? 1 + (int)(defer_counter++ % (uint32_t)DEFER_SLOTS) : 0;
+    int32_t *slot = pinned_slot(slot_index);
     if (!slot) { set_error("hipHostMalloc for the read-back slot failed"); return GMS_ERR_HIP; }
     // The launches-only form never reads the slot: its launches publish nothing, so a captured graph does not hold this thread's
     // slot and a stale sequence number (a replay would otherwise overwrite a count an eager call on another stream has just received).
@@ -1725,6 +1752,19 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (A->num_units_out) *A->num_units_out = 0;
         return (int64_t)cap;
     }
+    if (defer) {
+        // launches + the device's store of the counts into the ring slot; the caller redeems the ticket before its backward
+        const uint64_t cap = (uint64_t)A->binning_capacity_hint;
+        void *bin_mem = A->binning_alloc(A->binning_ctx, BinningState::bytes((size_t)cap, (size_t)T, L, micro_mode()));
+        if (!bin_mem) { set_error("binning allocation callback returned NULL"); return GMS_ERR_ALLOC; }
+        const int32_t rc = enqueue_tail(bin_mem, cap, false);
+        if (rc != GMS_OK) return rc;
+        t_last_launched_units = (int64_t)launched_units;
+        A->count_ticket_out[0] = (int64_t)(uintptr_t)slot;          // (pinned, process-wide: any thread may poll it)
+        A->count_ticket_out[1] = (int64_t)seq;
+        if (A->num_units_out) *A->num_units_out = 0;
+        return (int64_t)cap;
+    }
     if (A->binning_capacity_hint > 0) {
         // optimistic path: enqueue the whole tail before looking at N (no pipeline bubble)
         const uint64_t cap = (uint64_t)A->binning_capacity_hint;
@@ -1765,6 +1805,46 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
         if (rc != GMS_OK) return rc;
     }
     if (A->num_units_out) *A->num_units_out = (int64_t)units_seen;
+    return N;
+}
+
+extern "C" int64_t gms_rasterize_forward_counts(const int64_t *ticket, int32_t width, int32_t height, int32_t P, int64_t *num_units_out,
+                                                int64_t *deepest_tile_out, void *stream_)
+{
+    gms::TraceRange trace_range("gms_rasterize_forward_counts");
+    hipStream_t stream = (hipStream_t)stream_;
+    set_error("%s", "");
+    if (!ticket || ticket[0] == 0 || ticket[1] <= 0 || ticket[1] > 0x7fffffffll) {
+        set_error("gms_rasterize_forward_counts: not a ticket of a deferred forward");
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    int32_t *slot = reinterpret_cast<int32_t *>((uintptr_t)ticket[0]);
+    const int32_t seq = (int32_t)ticket[1];
+    // a slot that already carries a LATER call's tag was reused: more than DEFER_SLOTS tickets of the forward thread were outstanding
+    const unsigned long long tag0 = __atomic_load_n(reinterpret_cast<const unsigned long long *>(slot), __ATOMIC_ACQUIRE) >> 32;
+    if (tag0 != 0ull && (int32_t)(uint32_t)tag0 - seq > 0) {
+        set_error("gms_rasterize_forward_counts: ticket expired (more than %d deferred forwards outstanding on the forward's host thread)", DEFER_SLOTS);
+        return GMS_ERR_INVALID_ARGUMENT;
+    }
+    int64_t N = 0;
+    const int32_t rc = wait_for_count(slot, seq, stream, &N);
+    if (rc != GMS_OK) return rc;
+    const uint32_t units = unit_count(slot), deepest = deepest_tile(slot);
+    int device = 0;
+    GMS_HIP_CHECK(hipGetDevice(&device));
+    {
+        std::lock_guard<std::mutex> lk(g_mail_mu);
+        bool found = false;
+        for (auto &m : g_mail)
+            if (m.device == device && m.stream == stream && m.W == width && m.H == height && m.P == P) { m.deepest = deepest; m.units = units; found = true; }
+        if (!found) {
+            if (g_mail.size() >= 64) g_mail.erase(g_mail.begin());
+            g_mail.push_back({device, stream, width, height, P, deepest, units});
+        }
+    }
+    t_last_deepest = deepest;
+    if (num_units_out) *num_units_out = (int64_t)units;
+    if (deepest_tile_out) *deepest_tile_out = (int64_t)deepest;
     return N;
 }
 

@@ -94,8 +94,20 @@ std::atomic<bool> g_keep_buffers{false};
 
 struct Forward {
     int64_t num_rendered = 0, num_units = 0, capacity = 0;
+    int64_t ticket[2] = {0, 0}, launched_units = 0;      // deferred read-back (set_deferred_counts): the counts are redeemed at the start of the backward
     Tensor color, radii, invdepth, geom, binning, image;
 };
+// Deferred read-back of the instance count (gmsplat.h, count_ticket_out): opt-in, because an overflowed frame can
+// only be REPORTED at the start of its backward (the loss has been computed on an incomplete image by then): the backward raises
+// "GMS_DEFERRED_OVERFLOW" and the training loop redoes the step (games_hip/train.py, bench.py); the reference's own loop cannot.
+static std::atomic<int> g_defer_counts{-1};
+bool deferred_counts()
+{
+    int v = g_defer_counts.load();
+    if (v < 0) { const char *e = getenv("GMS_DEFER_COUNTS"); int expected = -1; g_defer_counts.compare_exchange_strong(expected, (e && atoi(e) != 0) ? 1 : 0); v = g_defer_counts.load(); }
+    return v != 0;
+}
+void set_deferred_counts(bool on) { g_defer_counts.store(on ? 1 : 0); }
 // what a frame rendered straight from a mesh stores for its backward (GmsRasterForwardArgs.mesh_out_*, ABI 6)
 struct MeshOut { Tensor xyz, scaling_act, rotation_unit, opacity_act; };
 
@@ -103,7 +115,7 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
                      const Tensor &opac_, const Tensor &scales_, const Tensor &rots_, const Tensor &cov_, const Tensor &view_,
                      const Tensor &proj_, const Tensor &campos_, int64_t H, int64_t W, double tanx, double tany, double mod, int64_t D,
                      bool prefiltered, bool aa, bool debug, const Tensor &visible, bool use_hint, const GmsMeshArgs *mesh = nullptr,
-                     const MeshOut *mesh_out = nullptr)
+                     const MeshOut *mesh_out = nullptr, bool may_defer = false)
 {
     // (`mesh`: the forward-only frame straight from a mesh, gmsplat.h; `means3D_` then only carries the device and P -- the SH DC tensor)
     require_gpu(means3D_); require_gpu(bg_); require_gpu(view_); require_gpu(proj_); require_gpu(campos_);
@@ -164,20 +176,44 @@ Forward forward_core(const Tensor &bg_, const Tensor &means3D_, const Tensor &sh
         a.mesh_out_xyz = mf(mesh_out->xyz); a.mesh_out_scaling_act = mf(mesh_out->scaling_act);
         a.mesh_out_rotation_unit = mf(mesh_out->rotation_unit); a.mesh_out_opacity_act = mf(mesh_out->opacity_act);
     }
+    int64_t ticket[2] = {0, 0};
+    const bool defer = may_defer && hint > 0 && !capturing && P > 0 && deferred_counts();
+    if (defer) a.count_ticket_out = ticket;
     const int64_t n = gms_rasterize_forward(&a, stream_of(means3D));
     TORCH_CHECK(!(geom.failed || binning.failed || image.failed), "scratch allocation failed (out of device memory?)");
     check_rc(n, "gms_rasterize_forward");
     f.num_rendered = n; f.num_units = num_units;
     f.capacity = (hint > 0 && n <= hint) ? hint : (n > 0 ? n : 1);
     f.geom = geom.t; f.binning = binning.t; f.image = image.t;
+    if (defer) { f.ticket[0] = ticket[0]; f.ticket[1] = ticket[1]; f.launched_units = gms_last_launched_units(); f.num_rendered = -1; f.capacity = hint; }
     {
         std::lock_guard<std::mutex> lk(g_mu);
         int64_t &c = g_capacity[key];
-        if (!capturing) c = std::max(n, (int64_t)(0.97 * (double)c));      // (a captured call returns the capacity, not a count)
+        if (!capturing && !defer) c = std::max(n, (int64_t)(0.97 * (double)c));      // (a captured / deferred call returns the capacity, not a count)
         g_last.num_rendered = n; g_last.num_units = num_units; g_last.hint = hint; g_last.P = P; g_last.W = (int)W; g_last.H = (int)H;
         if (g_keep_buffers.load()) { g_last.radii = f.radii; g_last.image = f.image; g_last.binning = f.binning; g_last.geom = f.geom; }
     }
     return f;
+}
+
+// Start of a backward whose forward deferred its counts: wait for them (they arrived long ago on a GPU-bound loop), check that the frame
+// fitted what it was launched for, feed the capacity hint.  Returns {instances, work units}.
+std::pair<int64_t, int64_t> redeem_counts(const int64_t *ticket, int64_t capacity, int64_t launched_units, const Tensor &like, int64_t W, int64_t H, int64_t P)
+{
+    int64_t units = 0, deepest = 0;
+    const int64_t n = gms_rasterize_forward_counts(ticket, (int32_t)W, (int32_t)H, (int32_t)P, &units, &deepest, stream_of(like));
+    check_rc(n, "gms_rasterize_forward_counts");
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        int64_t &c = g_capacity[std::make_tuple((int)like.device().index(), (int)W, (int)H, P)];
+        c = std::max(n, (int64_t)(0.97 * (double)c));
+        g_last.num_rendered = n; g_last.num_units = units;
+    }
+    TORCH_CHECK(n <= capacity && units <= launched_units,
+                "GMS_DEFERRED_OVERFLOW: the frame held ", n, " instances / ", units, " work units but was launched for ", capacity, " / ", launched_units,
+                " (deferred read-back of the instance count: diff_gaussian_rasterization.set_deferred_counts): its image is incomplete -- "
+                "redo this step (the capacity hint has been raised; or render it with set_deferred_counts(False))");
+    return {n, units};
 }
 
 struct Backward { Tensor dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dsh_rest, dscales, drots; };
@@ -336,7 +372,8 @@ public:
             ctx->saved_data["pre"] = true;
         }
         Forward f = forward_core(bg, means3D, sh, sh_rest, colors, opacities, scales, rotations, cov3D, view, proj, campos, H, W, tanx,
-                                 tany, mod, D, prefiltered, aa, debug, visible_out, use_hint);
+                                 tany, mod, D, prefiltered, aa, debug, visible_out, use_hint, nullptr, nullptr, will_backward && use_hint);
+        ctx->saved_data["ticket0"] = f.ticket[0]; ctx->saved_data["ticket1"] = f.ticket[1]; ctx->saved_data["launched"] = f.launched_units;
         const auto dev = means3D.device();
         ctx->save_for_backward({f32c(means3D), f32c(sh), f32c(sh_rest), f32c(colors), f32c(opacities), f32c(scales), f32c(rotations),
                                 f32c(cov3D), f.radii, f.geom, f.binning, f.image, f32c(bg.to(dev)), f32c(view.to(dev)),
@@ -366,10 +403,17 @@ public:
             }
             ctx->saved_data.erase("pre");
         }
+        int64_t R = ctx->saved_data["R"].toInt(), units = ctx->saved_data["units"].toInt();
+        if (ctx->saved_data["ticket0"].toInt() != 0) {
+            c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(means3D.device());
+            const int64_t ticket[2] = {ctx->saved_data["ticket0"].toInt(), ctx->saved_data["ticket1"].toInt()};
+            std::tie(R, units) = redeem_counts(ticket, ctx->saved_data["cap"].toInt(), ctx->saved_data["launched"].toInt(), means3D, W, H, means3D.size(0));
+            ctx->saved_data["ticket0"] = (int64_t)0; ctx->saved_data["R"] = R; ctx->saved_data["units"] = units;      // (a second backward through a retained graph)
+        }
         Backward b = backward_core(bg, means3D, radii, colors, opac, scales, rots, ctx->saved_data["mod"].toDouble(), cov, view, proj,
                                    ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], sh, sh_rest,
-                                   ctx->saved_data["D"].toInt(), campos, geom, ctx->saved_data["R"].toInt(), ctx->saved_data["cap"].toInt(),
-                                   ctx->saved_data["units"].toInt(), binning, image, ctx->saved_data["aa"].toBool(),
+                                   ctx->saved_data["D"].toInt(), campos, geom, R, ctx->saved_data["cap"].toInt(),
+                                   units, binning, image, ctx->saved_data["aa"].toBool(),
                                    ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
         Tensor none;
         if (sh.defined() && sh.numel() > 0) b.dcolors = none;          // (factorised mode: the factor is not a gradient of `colors`)
@@ -623,7 +667,8 @@ public:
         m.prezero = mf(vgrad); m.prezero_count = vgrad.defined() ? vgrad.numel() : 0;
         Tensor stand_in = dc.view({P, 3});          // (forward_core reads the device and the count from its first tensor argument)
         Forward f = forward_core(bg, stand_in, dc, rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
-                                 3, false, aa, debug, Tensor(), true, &m, &mo);
+                                 3, false, aa, debug, Tensor(), true, &m, &mo, will_backward);
+        ctx->saved_data["ticket0"] = f.ticket[0]; ctx->saved_data["ticket1"] = f.ticket[1]; ctx->saved_data["launched"] = f.launched_units;
         ctx->save_for_backward({v, faces, al, sc, op, sf.defined() ? sf : torch::empty({0}, fopt), vgrad.defined() ? vgrad : torch::empty({0}, fopt),
                                 mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, dc, rest, f.radii, f.geom, f.binning, f.image,
                                 f32c(bg.to(dev)), f32c(view.to(dev)), f32c(proj.to(dev)), f32c(campos.to(dev))});
@@ -657,9 +702,15 @@ public:
             }
             ctx->saved_data.erase("pre");
         }
+        int64_t R = ctx->saved_data["R"].toInt(), units = ctx->saved_data["units"].toInt();
+        if (ctx->saved_data["ticket0"].toInt() != 0) {
+            const int64_t ticket[2] = {ctx->saved_data["ticket0"].toInt(), ctx->saved_data["ticket1"].toInt()};
+            std::tie(R, units) = redeem_counts(ticket, ctx->saved_data["cap"].toInt(), ctx->saved_data["launched"].toInt(), xyz, W, H, xyz.size(0));
+            ctx->saved_data["ticket0"] = (int64_t)0; ctx->saved_data["R"] = R; ctx->saved_data["units"] = units;
+        }
         Backward b = backward_core(bg, xyz, radii, Tensor(), oact, sact, runit, ctx->saved_data["mod"].toDouble(), Tensor(), view, proj,
                                    ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest, 3, campos, geom,
-                                   ctx->saved_data["R"].toInt(), ctx->saved_data["cap"].toInt(), ctx->saved_data["units"].toInt(), binning, image,
+                                   R, ctx->saved_data["cap"].toInt(), units, binning, image,
                                    ctx->saved_data["aa"].toBool(), ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
         // ... and through the mesh -> Gaussian parameterization (fused activations: gradients w.r.t. exp / normalize / sigmoid outputs)
         Tensor d_vertices;
@@ -789,6 +840,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("take_sh_factors", &take_sh_factors, py::arg("device") = -1);
     m.def("sh_grad_expand", &sh_grad_expand, "dsh (+)= sum_v Y(dir_v) (x) factor_v over the [V,P+1,3] factors", nogil());
     m.def("last_stats", &last_stats);
+    m.def("set_deferred_counts", &set_deferred_counts, "read the frame's instance count back at the start of the backward instead of inside the forward (opt-in)");
+    m.def("deferred_counts", &deferred_counts);
     m.def("set_capacity", &set_capacity);
     m.def("clear_capacity", &clear_capacity);
     m.def("abi_version", []() { return (int64_t)gms_abi_version(); });

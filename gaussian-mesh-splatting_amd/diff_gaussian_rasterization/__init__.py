@@ -143,6 +143,27 @@ def deterministic() -> bool:
     return bool(_lib.load().gms_get_deterministic())
 
 
+DEFERRED_OVERFLOW = "GMS_DEFERRED_OVERFLOW"
+
+
+def set_deferred_counts(on: bool) -> None:
+    """Deferred read-back of the frame's instance count (include/gmsplat.h, count_ticket_out).  Off (default): every
+    differentiated forward waits for the count inside the call, as the upstream binding's blocking `num_rendered` read-back does, and re-runs
+    a frame that outgrew its buffers.  On: the forward only enqueues and the count is read at the START OF THE BACKWARD -- the host thread
+    runs ahead of the GPU by the loss and everything up to `backward()`, which is what keeps a slow or shared host from stalling the GPU.
+    The price: a frame that outgrew the capacity hint (1.25 x the recent maximum) can only be REPORTED then, its image is already
+    incomplete: the backward raises RuntimeError containing `DEFERRED_OVERFLOW` and the caller redoes the step (games_hip.train.training
+    and bench.py do; the reference's train.py cannot, hence opt-in).  Frames rendered under no_grad are never deferred.  Also:
+    GMS_DEFER_COUNTS=1 in the environment."""
+    if _C is None:
+        raise NotImplementedError("the deferred read-back needs the _C extension module (GMS_BINDING=ctypes drives the blocking form)")
+    _C.set_deferred_counts(bool(on))
+
+
+def deferred_counts() -> bool:
+    return bool(_C is not None and _C.deferred_counts())
+
+
 def set_sh_factor_mode(on: bool) -> None:
     """Factorised SH gradient for multi-view steps (include/gmsplat.h, gms_sh_grad_expand).  While on, a backward on the SH path
     writes NO dL/dsh (the `shs` gradient is None): it queues a [P+1,3] tensor -- rows 0..P-1 the clamp-masked dL/dcolour of that

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
-GMS_ABI_VERSION = 6
+GMS_ABI_VERSION = 7
 GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
 ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
 
@@ -37,6 +37,7 @@ class RasterForwardArgs(C.Structure):
         ("mesh", C.c_void_p),          # ABI 5: const GmsMeshArgs * (frame straight from a mesh) or NULL
         # ABI 6: what the fused frame derived, stored for the backward (all NULL: a forward-only frame)
         ("mesh_out_xyz", C.c_void_p), ("mesh_out_scaling_act", C.c_void_p), ("mesh_out_rotation_unit", C.c_void_p), ("mesh_out_opacity_act", C.c_void_p),
+        ("count_ticket_out", C.c_void_p),          # ABI 7: host int64*, deferred read-back of the frame's counts (gms_rasterize_forward_counts)
     ]
 
 
@@ -96,7 +97,7 @@ class AdamTensor(C.Structure):
 # every symbol include/gmsplat.h declares
 EXPORTS = (
     "gms_rasterize_forward", "gms_rasterize_backward", "gms_mark_visible", "gms_mesh_to_gaussians_forward",
-    "gms_mesh_to_gaussians_backward", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
+    "gms_mesh_to_gaussians_backward", "gms_rasterize_forward_counts", "gms_abi_version", "gms_last_error", "gms_geom_bytes", "gms_image_bytes",
     "gms_binning_bytes", "gms_profile_enable", "gms_profile_reset", "gms_profile_read", "gms_profile_kernel_name",
     "gms_knn_workspace_bytes", "gms_knn_mean_dist2", "gms_l1_ssim_partials", "gms_l1_ssim_forward",
     "gms_l1_ssim_backward", "gms_adam_step", "gms_wait_stats", "gms_last_deepest_tile", "gms_image_n_contrib_offset",

@@ -82,7 +82,29 @@ def training(gaussians, train_cameras: Sequence, opt: OptimizationParamsMesh, pi
         image = render_pkg["render"]
         gt_image = viewpoint_cam.original_image.to(image.device)
         loss = loss_fn(image, gt_image, opt.lambda_dssim)
-        loss.backward()
+        try:
+            loss.backward()
+        except RuntimeError as e:
+            # deferred read-back of the instance count (diff_gaussian_rasterization.set_deferred_counts): the frame outgrew its buffers and
+            # that could only be seen now.  Redo the step with the blocking form (the capacity hint has been raised meanwhile).
+            import diff_gaussian_rasterization as _dgr
+            if _dgr.DEFERRED_OVERFLOW not in str(e):
+                raise
+            for group in gaussians.optimizer.param_groups:
+                for p_ in group["params"]:
+                    p_.grad = None
+            _dgr.set_deferred_counts(False)
+            try:
+                if hasattr(gaussians, "update_alpha"):
+                    gaussians.update_alpha()
+                if hasattr(gaussians, "prepare_scaling_rot"):
+                    gaussians.prepare_scaling_rot()
+                render_pkg = render_fn(viewpoint_cam, gaussians, pipe, bg)
+                image = render_pkg["render"]
+                loss = loss_fn(image, gt_image, opt.lambda_dssim)
+                loss.backward()
+            finally:
+                _dgr.set_deferred_counts(True)
         with torch.no_grad():
             if iteration in report_at:
                 reported.append(float(loss.detach()))

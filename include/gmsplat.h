@@ -46,10 +46,12 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 6   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
+#define GMS_ABI_VERSION 7   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
                              4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset;
                              5: GmsRasterForwardArgs.mesh (forward-only frame straight from a mesh);
-                             6: GmsRasterForwardArgs.mesh_out_* (the fused frame exports what the backward needs: training frames too) */
+                             6: GmsRasterForwardArgs.mesh_out_* (the fused frame exports what the backward needs: training frames too);
+                             7: GmsRasterForwardArgs.count_ticket_out + gms_rasterize_forward_counts (the instance count is read back at the
+                                START OF THE BACKWARD instead of inside the forward) */
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -139,10 +141,27 @@ typedef struct GmsRasterForwardArgs {
     float *mesh_out_scaling_act;   /* [P,3] */
     float *mesh_out_rotation_unit; /* [P,4] */
     float *mesh_out_opacity_act;   /* [P]   */
+    /* ABI 7 -- DEFERRED read-back of the frame's counts (replaces the blocking `num_rendered` read-back the upstream binding does inside its
+     * forward).  Optional HOST pointer; non-NULL + binning_capacity_hint > 0 + no_host_wait
+     * == 0: the call enqueues the whole pipeline, has the device publish this frame's counts to one of sixteen pinned slots of the calling
+     * host thread, stores a TWO-WORD ticket here ({slot, sequence number}) and RETURNS WITHOUT WAITING (return value = the capacity, as with
+     * no_host_wait).  The host can then run ahead of the GPU by the loss and everything else up to the backward.  Before the backward the
+     * caller redeems the ticket with gms_rasterize_forward_counts() -- from ANY host thread: torch runs backward passes on its own thread --
+     * which waits for the counts (long since there on a GPU-bound loop); the caller must compare them with what the frame was launched for --
+     * instances <= capacity, work units <= gms_last_launched_units() taken right after the forward -- because nothing re-runs an overflowed
+     * frame in this form: its image is incomplete and its backward must not be trusted.  At most sixteen tickets of a forward thread may be
+     * outstanding. */
+    int64_t *count_ticket_out;      /* -> int64_t[2] */
 } GmsRasterForwardArgs;
 
 /* Returns the number of (Gaussian, tile) instances rendered (>= 0) or a negative error code. */
 int64_t gms_rasterize_forward(const GmsRasterForwardArgs *args, void *stream);
+/* Redeem the two-word ticket of a deferred forward (GmsRasterForwardArgs.count_ticket_out): waits until the device has published the frame's
+ * counts, returns the number of instances (>= 0) or a negative error code (an expired ticket: more than sixteen were outstanding), stores
+ * the frame's work units / deepest tile, and leaves the launch-size hints of this (device, stream, width, height, P) for the next forward of
+ * that shape, as a blocking forward would have.  Any host thread. */
+int64_t gms_rasterize_forward_counts(const int64_t *ticket, int32_t width, int32_t height, int32_t P, int64_t *num_units_out,
+                                     int64_t *deepest_tile_out, void *stream);
 /* Blocks (work units) the compositing launches of the calling thread's most recent gms_rasterize_forward were sized for. */
 int64_t gms_last_launched_units(void);
 /* Which compositing implementation the calling thread's most recent gms_rasterize_forward launched: 1 = the micro-tile kernels

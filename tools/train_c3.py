@@ -89,6 +89,12 @@ def main():
     at = sorted(set([1] + list(range(args.psnr_every, args.iterations + 1, args.psnr_every)) + [args.iterations]))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    import diff_gaussian_rasterization as dgr
+    # the count of every training frame is read at the start of its backward (opt-in; the loop redoes a step whose
+    # frame overflowed); GMS_DEFER_COUNTS=0 keeps the blocking read-back inside the forward
+    deferred = os.environ.get("GMS_DEFER_COUNTS", "1") != "0" and not dgr.deterministic() and dgr._C is not None
+    if deferred:
+        dgr.set_deferred_counts(True)
     training(student, cams, opt, pipe, bg, report=report, report_iterations=at)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0 - eval_s[0]
@@ -100,7 +106,7 @@ def main():
         "workload": f"{args.workload}: {student.get_xyz.shape[0]} Gaussians, {size}x{size}, {args.views} orbit targets from a teacher",
         "iterations": args.iterations, "seconds": round(el, 3), "iters_per_s": round(args.iterations / el, 1),
         "ms_per_iter": round(1000 * el / args.iterations, 4), "evaluation_seconds_excluded": round(eval_s[0], 3),
-        "active_sh_degree_end": student.active_sh_degree, "deterministic_mode": bool(dgr.deterministic()),
+        "active_sh_degree_end": student.active_sh_degree, "deterministic_mode": bool(dgr.deterministic()), "count_readback": "deferred" if deferred else "blocking",
         "psnr_before": [round(p, 2) for p in before], "psnr_after": [round(p, 2) for p in after],
         "psnr_mean_before": round(sum(before) / len(before), 2), "psnr_mean_after": round(sum(after) / len(after), 2),
         "trajectory": trajectory, "distinct_instance_counts_sampled": len(n_seen),
