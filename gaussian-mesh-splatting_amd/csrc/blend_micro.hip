@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(BLOCK) micro_finalize_kernel(BlendGrid g, Blen
     float *st0 = g.seg_state + (size_t)g.mseg_first[tile] * SEG_FLOATS;
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, T = 1.f;
     uint32_t last = 0;
-    constexpr int U = 4;          // four segments per step, every load issued before the first use
+    constexpr int U = 8;          // eight segments per step, every load issued before the first use (four: 10.0 us; the deepest tile of the headline frame has 27)
     for (int k0 = 0; k0 < nseg; k0 += U) {
         float te[U], c0[U], c1[U], c2[U], dd[U], la[U];
 #pragma unroll
@@ -384,6 +384,13 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
         // prefix product of the segments in front, four independent loads per step (same left-to-right order)
         const float *tl = g.seg_state + (size_t)u.slot0 * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
         int k = 0;
+        for (; k + 8 <= u.seg; k += 8) {          // (eight loads in flight; the product keeps its left-to-right order)
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) t[j] = tl[(size_t)(k + j) * SEG_FLOATS];
+#pragma unroll
+            for (int j = 0; j < 8; j++) T = T * t[j];
+        }
         for (; k + 4 <= u.seg; k += 4) {
             const float t0 = tl[(size_t)k * SEG_FLOATS], t1 = tl[(size_t)(k + 1) * SEG_FLOATS];
             const float t2 = tl[(size_t)(k + 2) * SEG_FLOATS], t3 = tl[(size_t)(k + 3) * SEG_FLOATS];
@@ -634,17 +641,18 @@ __global__ void __launch_bounds__(BLOCK) micro_bwd_kernel(BlendGrid g, BlendBwdA
             st8.T = te;
             float S0 = 0.f, S1 = 0.f, S2 = 0.f, SD = 0.f;
             bool stop = false;
-            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += 4) {
-                float tk[4], c0[4], c1[4], c2[4], dd[4];
+            constexpr int RU = 8;          // later segments per step, every load issued before the first use (4: a chain of up to seven rounds in the deepest tile)
+            for (int k0 = u.seg + 1; k0 < u.nseg; k0 += RU) {
+                float tk[RU], c0[RU], c1[RU], c2[RU], dd[RU];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < RU; j++) {
                     const float *sk = g.seg_state + (size_t)(u.slot0 + min(k0 + j, u.nseg - 1)) * SEG_FLOATS;
                     tk[j] = sk[SEG_TEND * TILE_PIX + p.tid]; c0[j] = sk[SEG_C0 * TILE_PIX + p.tid];
                     c1[j] = sk[SEG_C1 * TILE_PIX + p.tid]; c2[j] = sk[SEG_C2 * TILE_PIX + p.tid];
                     dd[j] = INVD ? sk[SEG_D * TILE_PIX + p.tid] : 0.f;
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < RU; j++) {
                     if (k0 + j >= u.nseg || tk[j] < 0.f) stop = true;
                     if (!stop) { S0 += c0[j]; S1 += c1[j]; S2 += c2[j]; SD += dd[j]; }
                 }
