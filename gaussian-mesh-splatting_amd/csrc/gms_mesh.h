@@ -187,4 +187,182 @@ __device__ __forceinline__ void splat_from_inputs(const GmsMeshArgs &a, const Sp
     o.q[0] = q[0] / n; o.q[1] = q[1] / n; o.q[2] = q[2] / n; o.q[3] = q[3] / n;
 }
 
+// ------------------------------------------------------------------ backward through the face frame (mesh_to_gaussians.hip, raster_backward.hip)
+// what the splats of a face hand to the face: gradients w.r.t. the quaternion, the two tangent scales and (through alpha) the corners
+struct FaceGrad { float dq[4]; float ds1, ds2; V3 dt0, dt1, dt2; };
+
+// differentiate quaternion + frame once per face and scatter into the three vertices
+// returns d loss / d (t0, t1, t2) of the face in out[9]
+__device__ __forceinline__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float out[9])
+{
+    // ---- quaternion -> dL/dR (columns v0, v1, v2)
+    float q[4];
+    QuatSel qs;
+    rot_to_quat(fr, q, &qs);
+    if (a.fused_activations) {   // gradient arrived w.r.t. q / |q|: project out the radial part, scale by 1/|q|
+        const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        const float u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+        const float d = u[0] * G.dq[0] + u[1] * G.dq[1] + u[2] * G.dq[2] + u[3] * G.dq[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) G.dq[k] = (G.dq[k] - u[k] * d) / n;
+    }
+    const float den = 2.0f * fmaxf(qs.a, 0.1f);
+    float gc[4];
+    float dden = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float gk = qs.sign * G.dq[k];
+        gc[k] = gk / den;
+        dden -= gk * qs.cand[k] / (den * den);
+    }
+    // a enters through den (if a > 0.1) and through cand[sel] = a^2
+    const float gsel = qs.sel == 0 ? gc[0] : qs.sel == 1 ? gc[1] : qs.sel == 2 ? gc[2] : gc[3];
+    float da = (qs.a > 0.1f ? 2.f * dden : 0.f) + 2.f * qs.a * gsel;
+    const float dx = (qs.xsel > 0.f) ? da / (2.f * qs.a) : 0.f;   // a = sqrt(x), zero subgradient at x <= 0
+    float d00 = 0, d01 = 0, d02 = 0, d10 = 0, d11 = 0, d12 = 0, d20 = 0, d21 = 0, d22 = 0;
+    switch (qs.sel) {
+    case 0:
+        d00 += dx; d11 += dx; d22 += dx;
+        d21 += gc[1]; d12 -= gc[1]; d02 += gc[2]; d20 -= gc[2]; d10 += gc[3]; d01 -= gc[3];
+        break;
+    case 1:
+        d00 += dx; d11 -= dx; d22 -= dx;
+        d21 += gc[0]; d12 -= gc[0]; d10 += gc[2]; d01 += gc[2]; d02 += gc[3]; d20 += gc[3];
+        break;
+    case 2:
+        d00 -= dx; d11 += dx; d22 -= dx;
+        d02 += gc[0]; d20 -= gc[0]; d10 += gc[1]; d01 += gc[1]; d12 += gc[3]; d21 += gc[3];
+        break;
+    default:
+        d00 -= dx; d11 -= dx; d22 += dx;
+        d10 += gc[0]; d01 -= gc[0]; d20 += gc[1]; d02 += gc[1]; d21 += gc[2]; d12 += gc[2];
+        break;
+    }
+    // m[i][j] = v_j[i]
+    V3 g0 = {d00, d10, d20}, g1 = {d01, d11, d21}, g2 = {d02, d12, d22};
+
+    // ---- scales
+    float g_v1n = G.ds1 * 0.5f;                       // s1 = v1n / 2
+    V3 g_v2i = (G.ds2 * 0.5f) * fr.v2;                // s2 = <v2i, v2> / 2
+    g2 = g2 + (G.ds2 * 0.5f) * fr.v2i;
+
+    // ---- v2 = w / (|w| + eps)
+    const float nwe = fr.nw + EPS;
+    V3 gw = (1.f / nwe) * g2;
+    if (fr.nw > 0.f) gw = gw - ((dot(g2, fr.w) / (nwe * nwe)) / fr.nw) * fr.w;
+    // w = v2i - <v2i,v0> v0 - <v2i,v1> v1
+    const float c0 = dot(fr.v2i, fr.v0), c1 = dot(fr.v2i, fr.v1);
+    const float gw0 = dot(gw, fr.v0), gw1 = dot(gw, fr.v1);
+    g_v2i = g_v2i + ((gw - gw0 * fr.v0) - gw1 * fr.v1);
+    g0 = g0 - (c0 * gw + gw0 * fr.v2i);
+    g1 = g1 - (c1 * gw + gw1 * fr.v2i);
+
+    // ---- v1 = u1 / v1n, v1n = |u1| + eps
+    V3 g_u1 = (1.f / fr.v1n) * g1;
+    if (fr.n1 > 0.f) g_u1 = g_u1 + ((g_v1n - dot(g1, fr.u1) / (fr.v1n * fr.v1n)) / fr.n1) * fr.u1;
+
+    // ---- v0 = N / (|N| + eps), N = (t1 - t0) x (t2 - t0)
+    const float nNe = fr.nN + EPS;
+    V3 gN = (1.f / nNe) * g0;
+    if (fr.nN > 0.f) gN = gN - ((dot(g0, fr.N) / (nNe * nNe)) / fr.nN) * fr.N;
+    const V3 e1 = fr.t1 - fr.t0, e2 = fr.t2 - fr.t0;
+    const V3 g_e1 = cross(e2, gN), g_e2 = cross(gN, e1);
+
+    // ---- back to the triangle
+    const V3 g_mean = (-1.f / 3.f) * (g_u1 + g_v2i);
+    V3 dt0 = G.dt0 + g_mean - (g_e1 + g_e2);
+    V3 dt1 = G.dt1 + g_mean + g_u1 + g_e1;
+    V3 dt2 = G.dt2 + g_mean + g_v2i + g_e2;
+    out[0] = dt0.x; out[1] = dt0.y; out[2] = dt0.z;
+    out[3] = dt1.x; out[4] = dt1.y; out[5] = dt1.z;
+    out[6] = dt2.x; out[7] = dt2.y; out[8] = dt2.z;
+}
+
+
+// Everything the mesh backward does for ONE splat whose incoming gradients are in REGISTERS (round 6: the tail of preprocess_bwd when the
+// frame was rendered straight from the mesh -- no dL/dxyz / dL/dscale / dL/drot / dL/dopacity tensors, no mesh_bwd launch).  fused_activations
+// semantics (gradients w.r.t. exp / normalize / sigmoid outputs).  The face's part is LINEAR in what its splats hand it, so every splat
+// backpropagates its own share through the frame and adds it to the three corners' gradients (9 float atomics per splat instead of 9 per
+// face: taken for <= 4 splats per face; dL_dvertices must be all zero on entry).  The per-splat outputs are plain stores, the formulas those
+// of bwd_splat_body / splat_contrib.
+__device__ __forceinline__ void splat_backward_from_registers(const GmsMeshArgs &a, int64_t p, const float g_xyz[3], const float g_scale[3],
+                                                              const float g_rot[4], float g_opac, float *dL_dvertices, float *dL_dalpha,
+                                                              float *dL_dscale, float *dL_d_opacity)
+{
+    {   // sigmoid backward: g * (1 - y) * y
+        const float y = 1.f / (1.f + expf(-a._opacity[p]));
+        dL_d_opacity[p] = g_opac * (1.f - y) * y;
+    }
+    const int f = splat_to_face(a, p);
+    const int64_t i0 = a.faces[3 * (size_t)f], i1 = a.faces[3 * (size_t)f + 1], i2 = a.faces[3 * (size_t)f + 2];
+    const V3 t0 = ldv(a.vertices, (size_t)i0), t1 = ldv(a.vertices, (size_t)i1), t2 = ldv(a.vertices, (size_t)i2);
+    const float raw[3] = {a._alpha[3 * p], a._alpha[3 * p + 1], a._alpha[3 * p + 2]};
+    float al[3], rsum;
+    barycentric(a.alpha_mode, raw, al, rsum);
+    const V3 g = {g_xyz[0], g_xyz[1], g_xyz[2]};
+    const float da[3] = {dot(g, t0), dot(g, t1), dot(g, t2)};
+    const float s = da[0] * al[0] + da[1] * al[1] + da[2] * al[2];
+    if (a.alpha_mode == GMS_ALPHA_RELU) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dalpha[3 * p + k] = raw[k] > 0.f ? (da[k] - s) / rsum : 0.f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dL_dalpha[3 * p + k] = al[k] * (da[k] - s);
+    }
+    Frame fr;
+    face_frame(t0, t1, t2, fr);
+    const float sc = a._scale[p];
+    const float sj[3] = {EPS, fr.s1, fr.s2};
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (sc * sj[j] > 0.f) acc += g_scale[j] * sj[j];
+    dL_dscale[p] = acc;
+    FaceGrad G = {};
+    G.dt0 = al[0] * g; G.dt1 = al[1] * g; G.dt2 = al[2] * g;
+    G.dq[0] = g_rot[0]; G.dq[1] = g_rot[1]; G.dq[2] = g_rot[2]; G.dq[3] = g_rot[3];
+    if (sc * fr.s1 > 0.f) G.ds1 = g_scale[1] * sc;
+    if (sc * fr.s2 > 0.f) G.ds2 = g_scale[2] * sc;
+    float out[9];
+    face_backward(a, f, fr, G, out);
+    // The splats of a face are consecutive lanes (uniform splat count, <= 4).  The FIRST lane of a face's run inside this wave collects
+    // the run's nine sums (9 atomics per splat on the same three corners in the same instruction: 146 us against 56 for the two
+    // launches; one set per run: 59).  A face split between two waves leaves two partial runs: the sum is linear.  Where the run is a
+    // whole face of three splats, the sums go back out so that the run's three lanes add x, y, z of ONE corner per instruction -- one
+    // cache-line operation at the L2 instead of three, which is what these atomics cost (without them: 44 us).
+    // (ds_bpermute: every lane of the wave takes part; the caller's only exit before this point is `i >= P`.)
+    const int lane = (int)(threadIdx.x & 63);
+    const int S = a.splats_per_face;                     // (the caller admits 1 .. 4 only)
+    const int in_face = (int)(p % S);
+    const int r = in_face < lane ? in_face : lane;       // position inside the run (a run that began in the previous wave starts at lane 0)
+    int tail = S - 1 - in_face;                          // lanes of the run after this one
+    if (tail > 63 - lane) tail = 63 - lane;
+    if ((int64_t)tail > a.P - 1 - p) tail = (int)(a.P - 1 - p);
+    float sum[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) sum[k] = out[k];
+#pragma unroll
+    for (int d = 1; d <= 3; d++) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const float o = __shfl_down(out[k], d);
+            if (d <= tail) sum[k] += o;                  // (only the run's first lane, which sees all of it, uses its sum)
+        }
+    }
+    const bool whole3 = S == 3 && r + tail == 2;
+    const int64_t vi[3] = {i0, i1, i2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float v1 = __shfl_up(sum[3 * k + 1], 1), v2 = __shfl_up(sum[3 * k + 2], 2);
+        const float v = r == 0 ? sum[3 * k] : r == 1 ? v1 : v2;
+        if (whole3 && v != 0.f) unsafeAtomicAdd(dL_dvertices + 3 * (size_t)vi[k] + r, v);
+    }
+    if (whole3 || r != 0) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            if (sum[3 * k + c] != 0.f) unsafeAtomicAdd(dL_dvertices + 3 * (size_t)vi[k] + c, sum[3 * k + c]);
+}
+
 }  // namespace gms

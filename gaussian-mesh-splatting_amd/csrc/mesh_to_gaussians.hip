@@ -110,8 +110,6 @@ __global__ void __launch_bounds__(BLOCK) mesh_bwd_splat_kernel(GmsMeshArgs a, co
 }
 
 // ------------------------------------------------------------------ backward, per face
-struct FaceGrad { float dq[4]; float ds1, ds2; V3 dt0, dt1, dt2; };
-
 __device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, const Frame &fr, const float *dL_dxyz,
                                               const float *dL_dscaling, const float *dL_drot, FaceGrad &G)
 {
@@ -126,93 +124,6 @@ __device__ __forceinline__ void splat_contrib(const GmsMeshArgs &a, int64_t p, c
     const float u1 = sc * fr.s1, u2 = sc * fr.s2;
     if (u1 > 0.f) G.ds1 += dL_dscaling[3 * p + 1] * sc * (a.fused_activations ? 1.f : 1.f / (u1 + EPS));
     if (u2 > 0.f) G.ds2 += dL_dscaling[3 * p + 2] * sc * (a.fused_activations ? 1.f : 1.f / (u2 + EPS));
-}
-
-// differentiate quaternion + frame once per face and scatter into the three vertices
-// returns d loss / d (t0, t1, t2) of the face in out[9]
-__device__ void face_backward(const GmsMeshArgs &a, int f, const Frame &fr, FaceGrad &G, float out[9])
-{
-    // ---- quaternion -> dL/dR (columns v0, v1, v2)
-    float q[4];
-    QuatSel qs;
-    rot_to_quat(fr, q, &qs);
-    if (a.fused_activations) {   // gradient arrived w.r.t. q / |q|: project out the radial part, scale by 1/|q|
-        const float n = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
-        const float u[4] = {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
-        const float d = u[0] * G.dq[0] + u[1] * G.dq[1] + u[2] * G.dq[2] + u[3] * G.dq[3];
-#pragma unroll
-        for (int k = 0; k < 4; k++) G.dq[k] = (G.dq[k] - u[k] * d) / n;
-    }
-    const float den = 2.0f * fmaxf(qs.a, 0.1f);
-    float gc[4];
-    float dden = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const float gk = qs.sign * G.dq[k];
-        gc[k] = gk / den;
-        dden -= gk * qs.cand[k] / (den * den);
-    }
-    // a enters through den (if a > 0.1) and through cand[sel] = a^2
-    const float gsel = qs.sel == 0 ? gc[0] : qs.sel == 1 ? gc[1] : qs.sel == 2 ? gc[2] : gc[3];
-    float da = (qs.a > 0.1f ? 2.f * dden : 0.f) + 2.f * qs.a * gsel;
-    const float dx = (qs.xsel > 0.f) ? da / (2.f * qs.a) : 0.f;   // a = sqrt(x), zero subgradient at x <= 0
-    float d00 = 0, d01 = 0, d02 = 0, d10 = 0, d11 = 0, d12 = 0, d20 = 0, d21 = 0, d22 = 0;
-    switch (qs.sel) {
-    case 0:
-        d00 += dx; d11 += dx; d22 += dx;
-        d21 += gc[1]; d12 -= gc[1]; d02 += gc[2]; d20 -= gc[2]; d10 += gc[3]; d01 -= gc[3];
-        break;
-    case 1:
-        d00 += dx; d11 -= dx; d22 -= dx;
-        d21 += gc[0]; d12 -= gc[0]; d10 += gc[2]; d01 += gc[2]; d02 += gc[3]; d20 += gc[3];
-        break;
-    case 2:
-        d00 -= dx; d11 += dx; d22 -= dx;
-        d02 += gc[0]; d20 -= gc[0]; d10 += gc[1]; d01 += gc[1]; d12 += gc[3]; d21 += gc[3];
-        break;
-    default:
-        d00 -= dx; d11 -= dx; d22 += dx;
-        d10 += gc[0]; d01 -= gc[0]; d20 += gc[1]; d02 += gc[1]; d21 += gc[2]; d12 += gc[2];
-        break;
-    }
-    // m[i][j] = v_j[i]
-    V3 g0 = {d00, d10, d20}, g1 = {d01, d11, d21}, g2 = {d02, d12, d22};
-
-    // ---- scales
-    float g_v1n = G.ds1 * 0.5f;                       // s1 = v1n / 2
-    V3 g_v2i = (G.ds2 * 0.5f) * fr.v2;                // s2 = <v2i, v2> / 2
-    g2 = g2 + (G.ds2 * 0.5f) * fr.v2i;
-
-    // ---- v2 = w / (|w| + eps)
-    const float nwe = fr.nw + EPS;
-    V3 gw = (1.f / nwe) * g2;
-    if (fr.nw > 0.f) gw = gw - ((dot(g2, fr.w) / (nwe * nwe)) / fr.nw) * fr.w;
-    // w = v2i - <v2i,v0> v0 - <v2i,v1> v1
-    const float c0 = dot(fr.v2i, fr.v0), c1 = dot(fr.v2i, fr.v1);
-    const float gw0 = dot(gw, fr.v0), gw1 = dot(gw, fr.v1);
-    g_v2i = g_v2i + ((gw - gw0 * fr.v0) - gw1 * fr.v1);
-    g0 = g0 - (c0 * gw + gw0 * fr.v2i);
-    g1 = g1 - (c1 * gw + gw1 * fr.v2i);
-
-    // ---- v1 = u1 / v1n, v1n = |u1| + eps
-    V3 g_u1 = (1.f / fr.v1n) * g1;
-    if (fr.n1 > 0.f) g_u1 = g_u1 + ((g_v1n - dot(g1, fr.u1) / (fr.v1n * fr.v1n)) / fr.n1) * fr.u1;
-
-    // ---- v0 = N / (|N| + eps), N = (t1 - t0) x (t2 - t0)
-    const float nNe = fr.nN + EPS;
-    V3 gN = (1.f / nNe) * g0;
-    if (fr.nN > 0.f) gN = gN - ((dot(g0, fr.N) / (nNe * nNe)) / fr.nN) * fr.N;
-    const V3 e1 = fr.t1 - fr.t0, e2 = fr.t2 - fr.t0;
-    const V3 g_e1 = cross(e2, gN), g_e2 = cross(gN, e1);
-
-    // ---- back to the triangle
-    const V3 g_mean = (-1.f / 3.f) * (g_u1 + g_v2i);
-    V3 dt0 = G.dt0 + g_mean - (g_e1 + g_e2);
-    V3 dt1 = G.dt1 + g_mean + g_u1 + g_e1;
-    V3 dt2 = G.dt2 + g_mean + g_v2i + g_e2;
-    out[0] = dt0.x; out[1] = dt0.y; out[2] = dt0.z;
-    out[3] = dt1.x; out[4] = dt1.y; out[5] = dt1.z;
-    out[6] = dt2.x; out[7] = dt2.y; out[8] = dt2.z;
 }
 
 __device__ __forceinline__ void face_splat_range(const GmsMeshArgs &a, int f, int64_t &b, int64_t &e)

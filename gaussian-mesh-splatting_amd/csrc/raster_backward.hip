@@ -17,6 +17,7 @@
 // sqrt(det0/det)) and dL/dscale carrying the scale_modifier factor; both are inert in GaMeS training (antialiasing off,
 // modifier 1.0).  DESIGN.md section 2 lists them.
 #include "gms_blend.h"
+#include "gms_mesh.h"
 #include "gms_common.h"
 #include "gms_project.h"
 
@@ -39,6 +40,8 @@ struct PreBwdArgs {
     float *dL_dmeans3D, *dL_dcov3D, *dL_dsh, *dL_dsh_rest, *dL_dscales, *dL_drots;
     float *dL_dcolor_sh;    // SH path, factorised mode: clamp-masked dL/dcolour [P,3] INSTEAD of the SH gradient rows
     int campos_row;         // factorised mode: also write the camera centre into row P of dL_dcolor_sh
+    GmsMeshArgs mesh;       // MESH instantiation: the frame was rendered straight from this mesh; the thread carries its gradients on through K0
+    float *mesh_dvertices, *mesh_dalpha, *mesh_dscale, *mesh_dopacity;
 };
 
 // SH backward for one Gaussian.  The coefficient row is read from the lane's LDS row as float4
@@ -113,6 +116,7 @@ __device__ __forceinline__ void stage_sh_rows_b(const float *shs, int g0, int ro
     }
 }
 
+template <bool MESH>
 __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a, int pre_bwd_linear)
 {
     __shared__ __attribute__((aligned(16))) float sh_lds[4 * WAVE * SH_PITCH_B];
@@ -439,13 +443,20 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a, int
         }
     }
     if (!valid) return;
-    a.dL_dopacity[i] = dop;
+    if (MESH) {
+        // the frame came straight from the mesh (gmsplat.h, ABI 8): on through the face -> Gaussian parameterization from registers
+        const float gs[3] = {dscale[0], dscale[1], dscale[2]}, gq[4] = {drot[0], drot[1], drot[2], drot[3]};
+        splat_backward_from_registers(a.mesh, (int64_t)i, dmean, gs, gq, dop, a.mesh_dvertices, a.mesh_dalpha, a.mesh_dscale, a.mesh_dopacity);
+    } else {
+        a.dL_dopacity[i] = dop;
+    }
     a.dL_dmean2D[3 * (size_t)i] = acc_mx; a.dL_dmean2D[3 * (size_t)i + 1] = acc_my; a.dL_dmean2D[3 * (size_t)i + 2] = 0.f;
     if (a.dL_dcolors) { a.dL_dcolors[3 * (size_t)i] = acc_col[0]; a.dL_dcolors[3 * (size_t)i + 1] = acc_col[1]; a.dL_dcolors[3 * (size_t)i + 2] = acc_col[2]; }
     if (a.dL_dcolor_sh && a.campos_row && i == 0) {
         a.dL_dcolor_sh[3 * (size_t)a.P] = a.campos[0]; a.dL_dcolor_sh[3 * (size_t)a.P + 1] = a.campos[1]; a.dL_dcolor_sh[3 * (size_t)a.P + 2] = a.campos[2];
     }
     if (a.dL_dcolor_sh) { a.dL_dcolor_sh[3 * (size_t)i] = dcol_sh[0]; a.dL_dcolor_sh[3 * (size_t)i + 1] = dcol_sh[1]; a.dL_dcolor_sh[3 * (size_t)i + 2] = dcol_sh[2]; }
+    if (MESH) return;
     a.dL_dmeans3D[3 * (size_t)i] = dmean[0]; a.dL_dmeans3D[3 * (size_t)i + 1] = dmean[1]; a.dL_dmeans3D[3 * (size_t)i + 2] = dmean[2];
     if (a.cov3Dp) {
         if (a.dL_dcov3D)
@@ -594,13 +605,24 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     const int P = A->P, W = A->width, H = A->height;
     if (P == 0) return GMS_OK;
     const bool sr = A->scales && A->rotations;
+    const GmsMeshArgs *mesh = A->mesh;
+    if (mesh) {
+        const int32_t mrc = check_mesh_args(mesh, false);
+        if (mrc != GMS_OK) return mrc;
+        if (mesh->P != (int64_t)P || mesh->splats_per_face <= 0 || mesh->splats_per_face > 4 || !mesh->_opacity || !sr || A->cov3D_precomp ||
+            !A->mesh_dL_dvertices || !A->mesh_dL_dalpha || !A->mesh_dL_dscale || !A->mesh_dL_d_opacity || det_mode()) {
+            set_error("gms_rasterize_backward: the mesh backward inside preprocess_bwd needs a complete GmsMeshArgs (P equal, 1-4 splats per face, "
+                      "_opacity), the scales + rotations path, all four mesh_dL_* outputs, and is not available in deterministic mode");
+            return GMS_ERR_INVALID_ARGUMENT;
+        }
+    }
     if (!A->means3D || !A->opacities || !A->radii || !A->geom_buffer || !A->binning_buffer || !A->image_buffer ||
-        !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || !A->dL_dopacity || (A->colors_precomp && !A->dL_dcolors) ||
-        !A->dL_dmeans3D || (A->sh_factor_mode != 0 && A->sh_factor_mode != 1) || (A->sh_factor_mode && (!A->shs || !A->dL_dcolors)) ||
+        !A->dL_dout_color || !A->dL_dmeans2D || !A->grad_accum || (!mesh && !A->dL_dopacity) || (A->colors_precomp && !A->dL_dcolors) ||
+        (!mesh && !A->dL_dmeans3D) || (A->sh_factor_mode != 0 && A->sh_factor_mode != 1) || (A->sh_factor_mode && (!A->shs || !A->dL_dcolors)) ||
         (A->factor_campos_row && !A->sh_factor_mode) ||
         (A->shs && !A->sh_factor_mode && !A->dL_dsh) || (A->shs_rest && ((!A->sh_factor_mode && !A->dL_dsh_rest) || A->M != 16)) ||
         ((A->shs == nullptr) == (A->colors_precomp == nullptr)) ||
-        (sr == (A->cov3D_precomp != nullptr)) || (sr && (!A->dL_dscales || !A->dL_drotations)) ||
+        (sr == (A->cov3D_precomp != nullptr)) || (sr && !mesh && (!A->dL_dscales || !A->dL_drotations)) ||
         (A->cov3D_precomp && !A->dL_dcov3D)) {
         set_error("gms_rasterize_backward: null or inconsistent pointer arguments");
         return GMS_ERR_INVALID_ARGUMENT;
@@ -648,7 +670,7 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
         if (fault_mode() == 1)      // negative control: sum(q dx^2) of every 1000th Gaussian off by 2e-3
             fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->grad_accum, P, GRAD_STRIDE, GRAD_CA, 1000, 1.002f);
     }
-    PreBwdArgs p;
+    PreBwdArgs p{};
     p.P = P; p.D = A->D; p.M = A->M; p.W = W; p.H = H;
     p.means3D = A->means3D; p.shs = A->shs; p.shs_rest = A->shs_rest; p.colors = A->colors_precomp; p.opac = A->opacities; p.scales = A->scales;
     p.rots = A->rotations; p.cov3Dp = A->cov3D_precomp; p.view = A->viewmatrix; p.proj = A->projmatrix; p.campos = A->campos;
@@ -660,7 +682,12 @@ extern "C" int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *A, void *
     if (pre_linear < 0) { const char *e = getenv("GMS_PRE_BWD_LINEAR"); pre_linear = e ? (atoi(e) != 0) : 1; }
     const int lin_ok = pre_linear && A->shs && A->shs_rest && A->D == 3 && (((uintptr_t)A->shs) & 15u) == 0 && (((uintptr_t)A->shs_rest) & 15u) == 0 &&
                        (A->sh_factor_mode || ((((uintptr_t)A->dL_dsh) & 15u) == 0 && (((uintptr_t)A->dL_dsh_rest) & 15u) == 0));
-    GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p, lin_ok));
+    if (mesh) {
+        p.mesh = *mesh; p.mesh_dvertices = A->mesh_dL_dvertices; p.mesh_dalpha = A->mesh_dL_dalpha; p.mesh_dscale = A->mesh_dL_dscale; p.mesh_dopacity = A->mesh_dL_d_opacity;
+        GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<true><<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p, lin_ok));
+    } else {
+        GMS_LAUNCH(GMS_K_PREPROCESS_BWD, stream, preprocess_bwd_kernel<false><<<(unsigned)((P + BLOCK - 1) / BLOCK), BLOCK, 0, stream>>>(p, lin_ok));
+    }
     GMS_KERNEL_CHECK(A->debug, stream, "preprocess_bwd");
     if (fault_mode() == 4 && A->dL_dscales)      // negative control: dL/dscale.x of every 1000th Gaussian off by 2e-3
         fault_scale_kernel<<<(unsigned)((P / 1000 + 256) / 256), 256, 0, stream>>>(A->dL_dscales, P, 3, 0, 1000, 1.002f);

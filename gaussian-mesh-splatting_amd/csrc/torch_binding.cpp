@@ -108,6 +108,15 @@ bool deferred_counts()
     return v != 0;
 }
 void set_deferred_counts(bool on) { g_defer_counts.store(on ? 1 : 0); }
+// the mesh backward inside preprocess_bwd for frames rendered straight from the mesh (GmsRasterBackwardArgs.mesh, ABI 8); on by default
+static std::atomic<int> g_fused_mesh_bwd{-1};
+bool fused_mesh_backward()
+{
+    int v = g_fused_mesh_bwd.load();
+    if (v < 0) { const char *e = getenv("GMS_TRAIN_FUSED_BWD"); int expected = -1; g_fused_mesh_bwd.compare_exchange_strong(expected, (e && atoi(e) == 0) ? 0 : 1); v = g_fused_mesh_bwd.load(); }
+    return v != 0;
+}
+void set_fused_mesh_backward(bool on) { g_fused_mesh_bwd.store(on ? 1 : 0); }
 // what a frame rendered straight from a mesh stores for its backward (GmsRasterForwardArgs.mesh_out_*, ABI 6)
 struct MeshOut { Tensor xyz, scaling_act, rotation_unit, opacity_act; };
 
@@ -217,6 +226,8 @@ std::pair<int64_t, int64_t> redeem_counts(const int64_t *ticket, int64_t capacit
 }
 
 struct Backward { Tensor dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dsh_rest, dscales, drots; };
+// outputs of the mesh backward when it runs inside preprocess_bwd (GmsRasterBackwardArgs.mesh, ABI 8)
+struct MeshGrads { Tensor d_vertices, d_alpha, d_scale, d_opacity; };
 
 // The gradient outputs of a backward call.  The autograd fast path allocates them in FORWARD, before the C call (there the
 // host runs ahead of the GPU and then waits for the instance count anyway), so that between "N has arrived" and "blend_bwd is
@@ -254,7 +265,8 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
                        const Tensor &scales, const Tensor &rots, double mod, const Tensor &cov, const Tensor &view, const Tensor &proj,
                        double tanx, double tany, const Tensor &dL_dcolor_, const Tensor &dL_dinvd_, const Tensor &sh, const Tensor &sh_rest,
                        int64_t D, const Tensor &campos, const Tensor &geom, int64_t R, int64_t capacity, int64_t num_units,
-                       const Tensor &binning, const Tensor &image, bool aa, bool debug, const Backward *prealloc = nullptr)
+                       const Tensor &binning, const Tensor &image, bool aa, bool debug, const Backward *prealloc = nullptr,
+                       const GmsMeshArgs *mesh = nullptr, const MeshGrads *mesh_grads = nullptr)
 {
     const auto dev = means3D.device();
     c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(dev);
@@ -292,6 +304,10 @@ Backward backward_core(const Tensor &bg, const Tensor &means3D, const Tensor &ra
     a.dL_dmeans3D = mf(b.dmeans3D); a.dL_dcov3D = mf(b.dcov3D); a.dL_dsh = mf(b.dsh); a.dL_dsh_rest = mf(b.dsh_rest);
     a.dL_dscales = mf(b.dscales); a.dL_drotations = mf(b.drots);
     a.grad_accum_rezero = 1; a.num_units = num_units;
+    if (mesh && mesh_grads) {
+        a.mesh = mesh; a.mesh_dL_dvertices = mf(mesh_grads->d_vertices); a.mesh_dL_dalpha = mf(mesh_grads->d_alpha);
+        a.mesh_dL_dscale = mf(mesh_grads->d_scale); a.mesh_dL_d_opacity = mf(mesh_grads->d_opacity);
+    }
     a.sh_factor_mode = (has_sh && b.dcolors.defined()) ? 1 : 0;
     a.factor_campos_row = (a.sh_factor_mode && b.dcolors.size(0) == P + 1) ? 1 : 0;      // row P = the camera centre
     if (a.sh_factor_mode) {
@@ -708,11 +724,6 @@ public:
             std::tie(R, units) = redeem_counts(ticket, ctx->saved_data["cap"].toInt(), ctx->saved_data["launched"].toInt(), xyz, W, H, xyz.size(0));
             ctx->saved_data["ticket0"] = (int64_t)0; ctx->saved_data["R"] = R; ctx->saved_data["units"] = units;
         }
-        Backward b = backward_core(bg, xyz, radii, Tensor(), oact, sact, runit, ctx->saved_data["mod"].toDouble(), Tensor(), view, proj,
-                                   ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest, 3, campos, geom,
-                                   R, ctx->saved_data["cap"].toInt(), units, binning, image,
-                                   ctx->saved_data["aa"].toBool(), ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr);
-        // ... and through the mesh -> Gaussian parameterization (fused activations: gradients w.r.t. exp / normalize / sigmoid outputs)
         Tensor d_vertices;
         bool prezeroed = false;
         if (s[6].numel() && !ctx->saved_data["used"].toBool()) { d_vertices = s[6]; prezeroed = true; ctx->saved_data["used"] = true; }
@@ -720,6 +731,22 @@ public:
         Tensor d_alpha = torch::empty_like(al), d_scale = torch::empty_like(sc), d_opacity = torch::empty_like(op);
         GmsMeshArgs a = mesh_args(v, faces, al, sc, ctx->saved_data["mode"].toInt(), ctx->saved_data["spf"].toInt(), Tensor(), sf, true, op);
         a.vertex_grad_prezeroed = prezeroed;
+        // The mesh backward INSIDE preprocess_bwd (ABI 8): the thread of a Gaussian carries its gradients on through the face -> Gaussian
+        // parameterization from registers -- no dL/dxyz / dL/dscale / dL/drot / dL/dopacity tensors, no mesh_bwd launch.  Needs the vertex
+        // gradient buffer the forward cleared, 1-4 splats per face, float-atomics mode.  GMS_TRAIN_FUSED_BWD=0 keeps the two launches.
+        const bool fused_bwd = fused_mesh_backward() && prezeroed && a.splats_per_face > 0 && a.splats_per_face <= 4 && !gms_get_deterministic() && !g_sh_factor.load();
+        MeshGrads mg{d_vertices, d_alpha, d_scale, d_opacity};
+        Backward b = backward_core(bg, xyz, radii, Tensor(), oact, sact, runit, ctx->saved_data["mod"].toDouble(), Tensor(), view, proj,
+                                   ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest, 3, campos, geom,
+                                   R, ctx->saved_data["cap"].toInt(), units, binning, image,
+                                   ctx->saved_data["aa"].toBool(), ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr,
+                                   fused_bwd ? &a : nullptr, fused_bwd ? &mg : nullptr);
+        if (fused_bwd) {
+            Tensor none;
+            return {d_vertices, none, d_alpha, d_scale, d_opacity, b.dsh, b.dsh_rest, b.dmeans2D,
+                    none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+        }
+        // ... else through the mesh -> Gaussian parameterization as a launch of its own (fused activations: gradients w.r.t. exp / normalize / sigmoid outputs)
         if (a.splats_per_face <= 0) {
             // (non-uniform splat counts: the per-face part of the mesh backward walks CSR offsets this node does not carry)
             TORCH_CHECK(false, "render_mesh backward: non-uniform splat counts take the two-node graph (mesh_to_gaussians + rasterize)");
@@ -842,6 +869,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("last_stats", &last_stats);
     m.def("set_deferred_counts", &set_deferred_counts, "read the frame's instance count back at the start of the backward instead of inside the forward (opt-in)");
     m.def("deferred_counts", &deferred_counts);
+    m.def("set_fused_mesh_backward", &set_fused_mesh_backward, "frames rendered straight from a mesh: run the mesh backward inside preprocess_bwd (default on)");
+    m.def("fused_mesh_backward", &fused_mesh_backward);
     m.def("set_capacity", &set_capacity);
     m.def("clear_capacity", &clear_capacity);
     m.def("abi_version", []() { return (int64_t)gms_abi_version(); });

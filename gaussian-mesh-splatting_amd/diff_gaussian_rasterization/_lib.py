@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GMSPLAT_LIB", os.path.join(os.path.dirname(_HERE), "l
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
-GMS_ABI_VERSION = 7
+GMS_ABI_VERSION = 8
 GMS_ALPHA_RELU, GMS_ALPHA_SOFTMAX = 0, 1
 ERRORS = {-1: "invalid argument", -2: "scratch allocation failed", -3: "HIP runtime error", -4: "capacity"}
 
@@ -59,6 +59,8 @@ class RasterBackwardArgs(C.Structure):
         ("dL_dmeans3D", C.c_void_p), ("dL_dcov3D", C.c_void_p), ("dL_dsh", C.c_void_p), ("dL_dsh_rest", C.c_void_p),
         ("dL_dscales", C.c_void_p), ("dL_drotations", C.c_void_p), ("grad_accum_rezero", C.c_int32), ("num_units", C.c_int64),
         ("factor_campos_row", C.c_int32), ("sh_factor_mode", C.c_int32),
+        # ABI 8: the mesh backward inside preprocess_bwd (frames rendered straight from a mesh)
+        ("mesh", C.c_void_p), ("mesh_dL_dvertices", C.c_void_p), ("mesh_dL_dalpha", C.c_void_p), ("mesh_dL_dscale", C.c_void_p), ("mesh_dL_d_opacity", C.c_void_p),
     ]
 
 

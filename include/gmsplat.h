@@ -46,12 +46,13 @@
 extern "C" {
 #endif
 
-#define GMS_ABI_VERSION 7   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
+#define GMS_ABI_VERSION 8   /* 3: GmsRasterBackwardArgs gained factor_campos_row + sh_factor_mode (explicit mode flag), GMS_K_COUNT 17;
                              4: GmsRasterForwardArgs gained no_host_wait (stream-capturable forward), gms_image_counts_offset;
                              5: GmsRasterForwardArgs.mesh (forward-only frame straight from a mesh);
                              6: GmsRasterForwardArgs.mesh_out_* (the fused frame exports what the backward needs: training frames too);
                              7: GmsRasterForwardArgs.count_ticket_out + gms_rasterize_forward_counts (the instance count is read back at the
-                                START OF THE BACKWARD instead of inside the forward) */
+                                START OF THE BACKWARD instead of inside the forward);
+                             8: GmsRasterBackwardArgs.mesh + mesh_dL_* (the mesh backward inside preprocess_bwd for frames rendered from a mesh) */
 
 /* error codes (negative return values) */
 #define GMS_OK 0
@@ -219,6 +220,20 @@ typedef struct GmsRasterBackwardArgs {
      * dL_dcolors is not touched.  1: factorised mode -- dL_dcolors is required and written, dL_dsh / dL_dsh_rest are not.
      * (ABI 2 switched on `dL_dcolors != NULL`; an explicit flag cannot be set by accident through a reused scratch pointer.) */
     int32_t sh_factor_mode;
+    /* ABI 8 -- the backward of a frame that was rendered STRAIGHT FROM A MESH (GmsRasterForwardArgs.mesh + mesh_out_*): with `mesh` set (the
+     * GmsMeshArgs of the forward; means3D / scales / rotations / opacities = the four tensors the forward stored) the thread of a Gaussian,
+     * once it holds dL/dxyz, dL/dscale, dL/drotation, dL/dopacity in registers, carries them on through the face -> Gaussian
+     * parameterization itself: dL/d_alpha, dL/d_scale, dL/d_opacity are stored, its share of the face's corner gradients is added to
+     * mesh_dL_dvertices (which must be ALL ZERO on entry: GmsMeshArgs.prezero of the forward) -- the arithmetic of
+     * gms_mesh_to_gaussians_backward with fused_activations, without the 44 bytes per Gaussian in between and without its launch.
+     * dL_dmeans3D / dL_dscales / dL_drotations / dL_dopacity are then NOT written (may be NULL).  Uniform splats per face, at most 4 (every
+     * splat adds to its face's three corners); not in deterministic mode (which sums corner gradients in a fixed order: use
+     * gms_mesh_to_gaussians_backward). */
+    const struct GmsMeshArgs *mesh;
+    float *mesh_dL_dvertices;         /* [V,3], zero on entry, accumulated with float atomics */
+    float *mesh_dL_dalpha;            /* [P,3] */
+    float *mesh_dL_dscale;            /* [P]   */
+    float *mesh_dL_d_opacity;         /* [P]   */
 } GmsRasterBackwardArgs;
 
 int32_t gms_rasterize_backward(const GmsRasterBackwardArgs *args, void *stream);

@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 PARAMS = ("vertices", "_alpha", "_scale", "_opacity", "_features_dc", "_features_rest")
 
 
-def _model(name="small"):
+def _model(name="small", splats=None):
     from games_hip.model import HipGaussianMeshModel
-    return HipGaussianMeshModel.from_scene(syn.mesh_scene(name), "cuda")
+    return HipGaussianMeshModel.from_scene(syn.mesh_scene(name, splats=splats), "cuda")
 
 
 def _step(model, cam, bg, defer):
@@ -125,3 +125,31 @@ def test_training_loop_walks_the_same_trajectory_with_and_without_the_deferred_k
     assert getattr(mb, "hip_defer_k0", False) is True
     for n in PARAMS:
         assert torch.equal(a[n], b[n]), n
+
+
+@pytest.mark.parametrize("splats", [1, 2, 3, 4])
+@pytest.mark.parametrize("size", [128, 203])
+def test_mesh_backward_inside_preprocess_bwd_equals_the_mesh_backward_launch(size, splats):
+    """ABI 8 (GmsRasterBackwardArgs.mesh): the thread of a Gaussian carries dL/dxyz / dL/dscale / dL/drot / dL/dopacity on through the
+    face -> Gaussian parameterization from registers.  Same gradients as preprocess_bwd + mesh_bwd_fused up to the order of the float
+    atomics on the vertices (the splats of a face are summed inside their wave first; a face of three splats that lies inside one wave
+    adds x, y, z of a corner from its three lanes, any other run from its first lane: 1 .. 4 splats per face put the faces at every
+    offset against the waves); deterministic mode keeps the two launches."""
+    import diff_gaussian_rasterization as dgr
+    model = _model(splats=splats)
+    cam = syn.orbit_camera(3, width=size, height=size - 7).to("cuda")
+    bg = torch.tensor([0.2, 0.9, 0.4], device="cuda")
+    _step(model, cam, bg, False)
+    was = dgr._C.fused_mesh_backward()
+    try:
+        dgr._C.set_fused_mesh_backward(False)
+        img0, _, g0 = _step(model, cam, bg, True)
+        dgr._C.set_fused_mesh_backward(True)
+        img1, _, g1 = _step(model, cam, bg, True)
+    finally:
+        dgr._C.set_fused_mesh_backward(was)
+        model.hip_defer_k0 = False
+    assert torch.equal(img1, img0)
+    for k in g0:
+        scale = float(g0[k].abs().max())
+        assert scale > 0 and float((g1[k] - g0[k]).abs().max()) <= 2e-5 * scale + 1e-12, (k, float((g1[k] - g0[k]).abs().max()), scale)

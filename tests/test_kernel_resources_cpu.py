@@ -42,6 +42,8 @@ def test_occupancies_design_md_argues_from(table):
     assert flt["occ"] == 6 and flt["lds"] < bwd["lds"]
     for name in ("micro_head_kernel<4>", "micro_fwd_kernel<4>"):        # forward compositing: at the wave limit
         assert table[name]["occ"] == 8 and table[name]["vgpr"] <= 64, name
-    pre = table["preprocess_bwd_kernel"]
+    pre = table["preprocess_bwd_kernel<false>"]
     assert pre["occ"] == 3 and pre["lds"] == 53248                      # 52 KB of SH rows: three blocks per CU
+    fused = table["preprocess_bwd_kernel<true>"]                         # ... with the mesh backward in its tail (ABI 8): the same three
+    assert fused["occ"] == 3 and fused["lds"] == pre["lds"] and fused.get("scratch", 0) == 0
     assert table["mesh_bwd_fused_kernel"]["occ"] == 5                   # (4 with the SLP vectoriser's packed operands: round 6, Makefile NOSLP)
