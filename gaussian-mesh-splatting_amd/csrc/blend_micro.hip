@@ -336,6 +336,63 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
     return id;
 }
 
+// ---- The compositing step of the forward walks, predicated through EXEC (round 6).
+// The long lists decide when these launches end, and a wave issues one instruction per ~2.7 ns whatever its kind: the compiler's form of
+// `if (valid && !done && power <= 0 && alpha >= 1/255) { ... if (T' < 1e-4) done = true; else { composite } }` is 27 instructions per entry
+// (v_cmp into SGPR pairs, s_and / s_or / s_xor chains, saveexec + branch + restore); this one is 17 (tloc: 7): the three tests narrow EXEC
+// themselves (v_cmpx), the stop rule removes its lanes, the body runs under what is left.  The per-lane state that says "this row still
+// walks" is the signed `rem` = list entries left INCLUDING this trip's (<= 0: the list is over, the pixel lies outside the image or was
+// dead on entry; REM_STOPPED: the stop rule fired); entry E of the trip is live iff E < rem, and a trip ends with rem -= NE.  `last` is
+// recorded as E - rem (= index - count: the caller adds the count back).  Same arithmetic in the same order as the plain form.
+constexpr uint32_t LAST_NONE = 0x7fffffffu;
+constexpr int REM_STOPPED = -0x40000000;
+template <int E>
+__device__ __forceinline__ void fwd_step_exec(float pw, float al, float cr, float cg, float cb, float cd, float &T, float &C0, float &C1, float &C2,
+                                              float &Dp, int &rem, uint32_t &last)
+{
+    uint64_t sv; float tmp, w;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_i32_e32 vcc, %[e], %[rem]\n\t"
+                 "v_cmpx_ge_f32_e32 vcc, 0, %[pw]\n\t"
+                 "v_cmpx_le_f32_e32 vcc, %[amin], %[al]\n\t"
+                 "v_sub_f32_e32 %[tmp], 1.0, %[al]\n\t"
+                 "v_mul_f32_e32 %[tmp], %[T], %[tmp]\n\t"
+                 "v_cmp_ngt_f32_e32 vcc, %[tmin], %[tmp]\n\t"          // NOT (T' < 1e-4): the lanes that composite this entry
+                 "v_cndmask_b32_e32 %[rem], %[stopped], %[rem], vcc\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "v_mul_f32_e32 %[w], %[al], %[T]\n\t"
+                 "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+                 "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+                 "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+                 "v_fmac_f32_e32 %[Dp], %[cd], %[w]\n\t"
+                 "v_mov_b32_e32 %[T], %[tmp]\n\t"
+                 "v_sub_u32_e32 %[last], %[e], %[rem]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [tmp] "=&v"(tmp), [w] "=&v"(w), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp),
+                   [rem] "+v"(rem), [last] "+v"(last)
+                 : [e] "n"(E), [pw] "v"(pw), [al] "v"(al), [amin] "s"(ALPHA_MIN), [tmin] "s"(T_MIN), [stopped] "v"(REM_STOPPED), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [cd] "v"(cd)
+                 : "vcc");
+}
+template <int E>
+__device__ __forceinline__ void tloc_step_exec(float pw, float al, float &Tl, int rem)
+{
+    uint64_t sv; float tmp;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_i32_e32 vcc, %[e], %[rem]\n\t"
+                 "v_cmpx_ge_f32_e32 vcc, 0, %[pw]\n\t"
+                 "v_cmpx_le_f32_e32 vcc, %[amin], %[al]\n\t"
+                 "v_sub_f32_e32 %[tmp], 1.0, %[al]\n\t"
+                 "v_mul_f32_e32 %[Tl], %[Tl], %[tmp]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [tmp] "=&v"(tmp), [Tl] "+v"(Tl)
+                 : [e] "n"(E), [pw] "v"(pw), [al] "v"(al), [amin] "s"(ALPHA_MIN), [rem] "v"(rem)
+                 : "vcc");
+}
+template <int NE, int E = 0> struct StepUnroll {
+    template <class F> static __device__ __forceinline__ void run(F &&f) { f(std::integral_constant<int, E>{}); StepUnroll<NE, E + 1>::run(f); }
+};
+template <int NE> struct StepUnroll<NE, NE> { template <class F> static __device__ __forceinline__ void run(F &&) {} };
+
 template <int NE>
 __device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const Unit &u, const UnitRecs &S, int phase, int q)
 {
@@ -347,24 +404,23 @@ __device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const Unit &
     const uint32_t maxcnt = max4rows(cnt);
     float Tl = 1.f;
     (void)phase;
+    int rem = p.inside ? (int)cnt : 0;
     for (uint32_t t = 0; t < maxcnt; t += NE) {
         // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
-        if (__all(Tl < T_MIN || !p.inside || t >= cnt)) break;
+        if (__builtin_amdgcn_ballot_w64(rem > 0 && !(Tl < T_MIN)) == 0ull) break;
         const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
-        float al[NE], pw[NE]; bool val[NE];
+        float al[NE], pw[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t ent = (ep >> (8 * e)) & 0xffu;
             const float4 r0 = S.ra[ent];
             const float2 r1 = *reinterpret_cast<const float2 *>(&S.rb[ent]);
             const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-            val[e] = t + e < cnt;
             pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
             al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
         }
-#pragma unroll
-        for (int e = 0; e < NE; e++)
-            if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
+        StepUnroll<NE>::run([&](auto e) { tloc_step_exec<decltype(e)::value>(pw[decltype(e)::value], al[decltype(e)::value], Tl, rem); });
+        rem -= NE;
     }
     *dst = Tl;
 }
@@ -400,14 +456,14 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
     }
     const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    bool done = !p.inside || dead_on_entry;
+    uint32_t last_rel = LAST_NONE;                                        // (index - count of the last entry composited: fwd_step_exec)
+    int rem = (!p.inside || dead_on_entry) ? 0 : (int)cnt;               // entries this row still has to look at (fwd_step_exec)
 
     for (uint32_t t = 0; t < maxcnt; t += NE) {
-        if (__all(done || t >= cnt)) break;
+        if (__builtin_amdgcn_ballot_w64(rem > 0) == 0ull) break;
         // NE entries of every row per trip: independent alpha evaluations, sequential compositing
         const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
-        float al[NE], pw[NE]; bool val[NE]; float2 cg[NE], cb[NE];
+        float al[NE], pw[NE]; float2 cg[NE], cb[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t ent = (ep >> (8 * e)) & 0xffu;
@@ -415,24 +471,17 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
             cb[e] = S.rc[ent];
             cg[e] = make_float2(r1.z, r1.w);
             const float dx = r0.x - p.xf, dy = r0.y - p.yf;
-            val[e] = t + e < cnt;
             pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
             al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
         }
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
-            const float testT = T * (1.f - al[e]);
-            if (act && testT < T_MIN) { done = true; act = false; }
-            if (act) {
-                const float w = al[e] * T;
-                C0 += cg[e].x * w; C1 += cg[e].y * w; C2 += cb[e].x * w;
-                Dp += cb[e].y * w;
-                T = testT;
-                last = posbase + t + (uint32_t)e + 1u;
-            }
-        }
+        StepUnroll<NE>::run([&](auto e) {
+            constexpr int E = decltype(e)::value;
+            fwd_step_exec<E>(pw[E], al[E], cg[E].x, cg[E].y, cb[E].x, cb[E].y, T, C0, C1, C2, Dp, rem, last_rel);
+        });
+        rem -= NE;
     }
+    const bool done = !p.inside || dead_on_entry || rem < REM_STOPPED / 2;      // (the plain form's `done`: outside, dead on entry or stopped)
+    const uint32_t last = last_rel == LAST_NONE ? 0u : posbase + cnt + 1u + last_rel;
     if (u.nseg == 1) {
         if (p.inside) {
             const size_t pid = (size_t)p.yi * g.W + p.xi, HW = (size_t)g.W * g.H;
