@@ -251,18 +251,25 @@ __device__ __forceinline__ void set_tail(float2 &d, float b, float invd) { d = m
 __device__ __forceinline__ void set_tail(float &d, float b, float) { d = b; }
 __device__ __forceinline__ float2 get_tail(const float2 &d) { return d; }
 __device__ __forceinline__ float2 get_tail(const float &d) { return make_float2(d, 0.f); }
-template <bool WITHD, int LM = LMAX>
+// WIDE (the forward launches, which have the LDS to spare): the tail at the 16-byte pitch of the other two arrays, so that one shifted
+// entry byte addresses all three reads of a walk step (two address instructions fewer per entry; the walks cost what they issue)
+struct __attribute__((aligned(16))) WideTail { float2 v; float2 unused; };
+__device__ __forceinline__ void set_tail(WideTail &d, float b, float invd) { d.v = make_float2(b, invd); }
+__device__ __forceinline__ float2 get_tail(const WideTail &d) { return d.v; }
+template <bool WITHD, bool WIDE> struct RecTailSel { using type = typename RecTail<WITHD>::type; };
+template <> struct RecTailSel<true, true> { using type = WideTail; };
+template <bool WITHD, int LM = LMAX, bool WIDE = false>
 struct UnitRecsT {
     static constexpr int CAP = LM;      // entries the image holds (the frame's segment length must not exceed it)
     float4 ra[LM];             // pix.x, pix.y, conic A, conic B
     float4 rb[LM];             // conic C, opacity', r, g
-    typename RecTail<WITHD>::type rc[LM];
+    typename RecTailSel<WITHD, WIDE>::type rc[LM];
     uint8_t list[16][LM];      // per 4x4 block: the entries that reach it, in list (depth) order
     uint16_t ocnt[16];         // list lengths, longest first
     uint8_t order[16];         // ... and whose they are
     uint8_t wcnt4[16][4];      // staging: per block, the hits of each of the four waves (<= 64): one dword per block
 };
-using UnitRecs = UnitRecsT<true>;
+using UnitRecs = UnitRecsT<true, LMAX, true>;      // (the forward launches)
 
 template <int NE> __device__ __forceinline__ uint32_t list_load(const uint8_t *lst, uint32_t pos);
 template <> __device__ __forceinline__ uint32_t list_load<1>(const uint8_t *lst, uint32_t pos) { return lst[pos]; }
@@ -275,8 +282,8 @@ template <> __device__ __forceinline__ uint32_t list_load<4>(const uint8_t *lst,
 // `cmax_out` (forward launches): the largest |colour component| of the unit's splats is folded into the tile's maximum
 // (ImageState::tile_cmax; one integer atomic per wave), which the backward needs to bound the colour behind a splat.
 // Returns the Gaussian id of the thread's entry.
-template <bool FILTER, bool WITHD, int LM>
-__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD, LM> &S, const SplatRec *rec, uint32_t *cmax_out)
+template <bool FILTER, bool WITHD, int LM, bool WIDE>
+__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD, LM, WIDE> &S, const SplatRec *rec, uint32_t *cmax_out)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
@@ -401,14 +408,13 @@ __device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const Unit &
     float *dst = g.seg_state + (size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + p.tid;
     const uint32_t cnt = S.ocnt[4 * q + row];
     const uint8_t *lst = S.list[p.b];
-    const uint32_t maxcnt = max4rows(cnt);
     float Tl = 1.f;
     (void)phase;
     int rem = p.inside ? (int)cnt : 0;
-    for (uint32_t t = 0; t < maxcnt; t += NE) {
-        // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
-        if (__builtin_amdgcn_ballot_w64(rem > 0 && !(Tl < T_MIN)) == 0ull) break;
-        const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
+    static_assert(LMAX % NE == 0, "a trip reads NE list bytes at a multiple of NE below the row's count");
+    // once a pixel's segment product is below 1e-4 every later segment starts dead whatever the exact value
+    if (__builtin_amdgcn_ballot_w64(rem > 0) != 0ull) do {
+        const uint32_t ep = list_load<NE>(lst, 0);
         float al[NE], pw[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) {
@@ -420,8 +426,8 @@ __device__ __forceinline__ void micro_tloc_unit(const BlendGrid &g, const Unit &
             al[e] = fminf(ALPHA_MAX, r1.y * __expf(pw[e]));
         }
         StepUnroll<NE>::run([&](auto e) { tloc_step_exec<decltype(e)::value>(pw[decltype(e)::value], al[decltype(e)::value], Tl, rem); });
-        rem -= NE;
-    }
+        rem -= NE; lst += NE;
+    } while (__builtin_amdgcn_ballot_w64(rem > 0 && !(Tl < T_MIN)) != 0ull);
     *dst = Tl;
 }
 
@@ -432,7 +438,6 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
     const MPix p = micro_pixel(g, u.tx, u.ty, (int)S.order[4 * q + row], li);
     const uint32_t cnt = S.ocnt[4 * q + row];
     const uint8_t *lst = S.list[p.b];
-    const uint32_t maxcnt = max4rows(cnt);
     const uint32_t posbase = (uint32_t)u.seg * u.L;
 
     float T = 1.f;
@@ -459,16 +464,17 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
     uint32_t last_rel = LAST_NONE;                                        // (index - count of the last entry composited: fwd_step_exec)
     int rem = (!p.inside || dead_on_entry) ? 0 : (int)cnt;               // entries this row still has to look at (fwd_step_exec)
 
-    for (uint32_t t = 0; t < maxcnt; t += NE) {
-        if (__builtin_amdgcn_ballot_w64(rem > 0) == 0ull) break;
+    static_assert(LMAX % NE == 0, "a trip reads NE list bytes at a multiple of NE below the row's count");
+    // (some row has entries left => the trip's NE bytes lie inside every row's list image)
+    if (__builtin_amdgcn_ballot_w64(rem > 0) != 0ull) do {
         // NE entries of every row per trip: independent alpha evaluations, sequential compositing
-        const uint32_t ep = list_load<NE>(lst, min(t, (uint32_t)(LMAX - NE)));
+        const uint32_t ep = list_load<NE>(lst, 0);
         float al[NE], pw[NE]; float2 cg[NE], cb[NE];
 #pragma unroll
         for (int e = 0; e < NE; e++) {
             const uint32_t ent = (ep >> (8 * e)) & 0xffu;
             const float4 r0 = S.ra[ent], r1 = S.rb[ent];
-            cb[e] = S.rc[ent];
+            cb[e] = get_tail(S.rc[ent]);
             cg[e] = make_float2(r1.z, r1.w);
             const float dx = r0.x - p.xf, dy = r0.y - p.yf;
             pw[e] = pair_power(r0.z, r0.w, r1.x, dx, dy);
@@ -478,8 +484,8 @@ __device__ __forceinline__ void micro_fwd_unit(const BlendGrid &g, const BlendFw
             constexpr int E = decltype(e)::value;
             fwd_step_exec<E>(pw[E], al[E], cg[E].x, cg[E].y, cb[E].x, cb[E].y, T, C0, C1, C2, Dp, rem, last_rel);
         });
-        rem -= NE;
-    }
+        rem -= NE; lst += NE;
+    } while (__builtin_amdgcn_ballot_w64(rem > 0) != 0ull);
     const bool done = !p.inside || dead_on_entry || rem < REM_STOPPED / 2;      // (the plain form's `done`: outside, dead on entry or stopped)
     const uint32_t last = last_rel == LAST_NONE ? 0u : posbase + cnt + 1u + last_rel;
     if (u.nseg == 1) {
