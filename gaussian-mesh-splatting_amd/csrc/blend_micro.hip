@@ -283,7 +283,8 @@ template <> __device__ __forceinline__ uint32_t list_load<4>(const uint8_t *lst,
 // (ImageState::tile_cmax; one integer atomic per wave), which the backward needs to bound the colour behind a splat.
 // Returns the Gaussian id of the thread's entry.
 template <bool FILTER, bool WITHD, int LM, bool WIDE>
-__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD, LM, WIDE> &S, const SplatRec *rec, uint32_t *cmax_out)
+__device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u, UnitRecsT<WITHD, LM, WIDE> &S, const SplatRec *rec, uint32_t *cmax_out,
+                                               Phases *ph = nullptr)          // (make EXPERIMENTS=1: stamps 3 = records in, 4 = counts exchanged)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t cn = u.end - u.beg;
@@ -310,6 +311,7 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
     // load and forms the wave's base (the hits of the waves in front) and the block's total with two byte-sum instructions.  (Round 5
     // looped over the waves in front with a dependent LDS byte read each, inside every one of the sixteen block iterations: ~540 VALU
     // and ~180 LDS instructions of staging per wave in a kernel that is bound by VALU issue -- tools/valu_bench.hip.)
+    if (GMS_EXPERIMENTS && ph) { __builtin_amdgcn_s_waitcnt(0); ph->mark(3); }
     uint64_t bal[16];
     uint32_t mycnt = 0;                        // lane b < 16: hits of block b among this wave's 64 entries
 #pragma unroll
@@ -320,6 +322,7 @@ __device__ __forceinline__ uint32_t unit_stage(const BlendGrid &g, const Unit &u
     }
     if (lane < 16) S.wcnt4[lane][wave] = (uint8_t)mycnt;
     __syncthreads();
+    if (GMS_EXPERIMENTS && ph) ph->mark(4);
     const uint32_t w4 = *reinterpret_cast<const uint32_t *>(&S.wcnt4[lane & 15][0]);
     // bytes of the waves in front of this one, summed (v_sad_u8 against zero adds a dword's four bytes)
     const uint32_t basev = __builtin_amdgcn_sad_u8(w4 & ((1u << (8 * wave)) - 1u), 0u, 0u);
@@ -538,7 +541,7 @@ __global__ void __launch_bounds__(BLOCK) micro_head_kernel(BlendGrid g, BlendFwd
         g.seg_state[(size_t)(u.slot0 + u.seg) * SEG_FLOATS + SEG_TLOC * TILE_PIX + threadIdx.x] = 0.f;
         return;
     }
-    unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);
+    unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile, &ph);
     ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);      // (rotate the sorted groups over the block's waves)
     if (u.seg == 0) micro_fwd_unit<NE>(g, o, u, S, q);
@@ -558,8 +561,8 @@ __global__ void __launch_bounds__(BLOCK) micro_fwd_kernel(BlendGrid g, BlendFwdO
     Unit u;
     if (!load_unit_at(g, u, blockIdx.x >> 3, blockIdx.x & 7u)) return;
     if (u.seg == 0) return;
-    if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile);       // last segments are first touched here
-    else unit_stage<false>(g, u, S, o.rec, g.tile_cmax + u.tile);                          // middle segments: filtered by the first launch
+    if (u.seg == u.nseg - 1) unit_stage<true>(g, u, S, o.rec, g.tile_cmax + u.tile, &ph);  // last segments are first touched here
+    else unit_stage<false>(g, u, S, o.rec, g.tile_cmax + u.tile, &ph);                        // middle segments: filtered by the first launch
     ph.mark(1);
     const int q = (int)(((threadIdx.x >> 6) + (blockIdx.x >> 3)) & 3u);
     micro_fwd_unit<NE>(g, o, u, S, q);

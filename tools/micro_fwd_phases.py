@@ -44,6 +44,17 @@ for k, n in names.items():
     a, w = (mid - st)[m], (en - mid)[m]
     print(f"  {n:30s} {int(m.sum()) // 4:5d} blocks  staging mean {a.mean():5.2f} p90 {np.percentile(a, 90):5.2f}   walk mean {w.mean():5.2f} p90 {np.percentile(w, 90):5.2f} max {w.max():5.2f} us"
           f"   share of wave-time: staging {100 * a.sum() / (en - st)[live].sum():4.1f} % walk {100 * w.sum() / (en - st)[live].sum():4.1f} %")
+if (b[:, :, 3][live] > 0).all() and (b[:, :, 4][live] > 0).all():
+    # inside staging: 0 -> 3 unit record, key, splat record (three dependent round trips) + block mask; 3 -> 4 ballots, counts to LDS, barrier;
+    # 4 -> 1 list bytes, block order, barrier
+    r_in, xch = [(b[:, :, k] - t0) / 100.0 for k in (3, 4)]
+    for nm, lo, hi in (("records in", st, r_in), ("counts exchanged (barrier)", r_in, xch), ("lists built (barrier)", xch, mid)):
+        d = (hi - lo)[live]
+        print(f"    staging / {nm:28s} mean {d.mean():5.2f} p50 {np.percentile(d, 50):5.2f} p90 {np.percentile(d, 90):5.2f} max {d.max():5.2f} us")
+    early = live & (st < 2.0)
+    if early.any():
+        d = (r_in - st)[early]
+        print(f"    waves started in the first 2 us ({int(early.sum())}): records in after mean {d.mean():5.2f} p90 {np.percentile(d, 90):5.2f} us")
 blk = np.nonzero(live.all(axis=0))[0]
 if os.environ.get("GMS_PHASES_DUMP"):          # per-block records for offline scheduling studies (tools/unit_order_study.py)
     w7 = b[0, blk, 7]
