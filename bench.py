@@ -723,6 +723,13 @@ def main():
         sq = pmc.get("_sq", {})
         if ktimes.get("mesh_bwd_splat", (0, 0))[1] == 0:       # K0 backward ran as one fused launch (booked as mesh_bwd_face)
             ab["mesh_bwd_face"] += ab["mesh_bwd_splat"]
+        k0_bwd_inside = (getattr(model, "hip_defer_k0", False) and ktimes.get("mesh_bwd_face", (0, 0))[1] == 0
+                         and ktimes.get("preprocess_bwd", (0, 0))[1] > 0)
+        if k0_bwd_inside:
+            # frames rendered from the mesh (ABI 8): preprocess_bwd carries the gradients on through the face -> Gaussian parameterization
+            # itself -- dL/dxyz, dL/dscale, dL/drot, dL/dopacity (44 B) are not written, per splat _alpha / _scale / _opacity come in and
+            # their gradients go out (40 B), per face the indices and corners come in and the corner gradients go out (96 B)
+            ab["preprocess_bwd"] = (569 - 44 + 40) * P + 96 * F
         kernels = {}
         for name, (ms, n) in ktimes.items():
             if n == 0:
@@ -828,6 +835,8 @@ def main():
                                        f"per step") if world > 1 else "single view",
                        "k0": ("inside the rasterizer's preprocess thread (update_alpha / prepare_scaling_rot deferred: games_hip.model.HipMeshMixin.hip_defer_k0)"
                               if getattr(model, "hip_defer_k0", False) else "its own launch"),
+                       "k0_backward": ("inside preprocess_bwd (GmsRasterBackwardArgs.mesh, ABI 8): no mesh_bwd launch" if k0_bwd_inside
+                                       else ("its own launch (mesh_bwd)" if ktimes.get("preprocess_bwd", (0, 0))[1] > 0 else "not profiled (--profile-steps 0)")),
                        "step": (f"K0 fwd + {vps} x (render fwd + bwd)" if vps > 1 else "K0 fwd + render fwd + bwd")
                                + (" + gradient all-reduce" if distributed else "")
                                + (" with the fused L1+SSIM training loss" if args.loss == "l1_ssim" else "")
