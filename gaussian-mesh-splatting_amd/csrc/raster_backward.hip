@@ -398,7 +398,13 @@ __global__ void __launch_bounds__(BLOCK) preprocess_bwd_kernel(PreBwdArgs a, int
 #pragma unroll
             for (int j = 0; j < 12; j++) {
                 const int e4 = (lane + WAVE * j) * 4;
-                if (e4 + 3 < nfl) *reinterpret_cast<float4 *>(dp + e4) = *reinterpret_cast<const float4 *>(wl + e4);
+                // Non-temporal: the 54 MB of dL/dSH are written once and read by nobody in this call.  As plain stores the launch had two
+                // speeds, 45 us in most processes and 53 in about one of four (same binary, same inputs: it goes with where the allocator
+                // put the buffers); streamed past the caches it takes 44 us in every one of ten runs (profiles/r06x4_*, r06x5_*).
+                if (e4 + 3 < nfl) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(*reinterpret_cast<const v4f *>(wl + e4), reinterpret_cast<v4f *>(dp + e4));
+                }
                 else for (int t = 0; t < 4; t++) if (e4 + t < nfl) dp[e4 + t] = wl[e4 + t];
             }
             if (lane * 4 + 3 < nd) *reinterpret_cast<float4 *>(dd + lane * 4) = *reinterpret_cast<const float4 *>(lin_dc + lane * 4);
