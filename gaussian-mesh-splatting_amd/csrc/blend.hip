@@ -105,7 +105,7 @@ __device__ __forceinline__ void tloc_unit(const BlendGrid &g, const SplatRec *re
                 }
 #pragma unroll
                 for (int e = 0; e < NE; e++)
-                    if (val[e] && pw[e] <= 0.f && al[e] >= ALPHA_MIN) Tl *= (1.f - al[e]);
+                    if (val[e]) quad_tloc_step_exec(pw[e], al[e], Tl);          // (val: the same for the whole wave)
             }
         }
     }
@@ -152,7 +152,8 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
     const bool dead_on_entry = T < T_MIN;          // only possible for seg > 0
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = !p.inside || dead_on_entry;
+    int alive = (!p.inside || dead_on_entry) ? 0 : 1;          // (gms_blend.h::quad_step_exec clears it when the stop rule fires)
+#define done (alive == 0)
 
     for (uint32_t base = u.beg; base < u.end; base += QN) {
         if (WPB == 4) { if (__syncthreads_and(done)) break; }
@@ -183,18 +184,9 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
                     al[e] = fminf(ALPHA_MAX, r1[e].y * __expf(pw[e]));
                 }
 #pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    bool act = val[e] && !done && pw[e] <= 0.f && al[e] >= ALPHA_MIN;
-                    const float testT = T * (1.f - al[e]);
-                    if (act && testT < T_MIN) { done = true; act = false; }
-                    if (act) {
-                        const float w = al[e] * T;
-                        C0 += r1[e].z * w; C1 += r1[e].w * w; C2 += r2[e].x * w;
-                        Dp += r2[e].y * w;
-                        T = testT;
-                        last = (base - u.tile_beg) + (uint32_t)k[e] + 1u;
-                    }
-                }
+                for (int e = 0; e < NE; e++)
+                    if (val[e])          // (the same for the whole wave: a scalar branch)
+                        quad_step_exec(pw[e], al[e], r1[e].z, r1[e].w, r2[e].x, r2[e].y, (base - u.tile_beg) + (uint32_t)k[e] + 1u, T, C0, C1, C2, Dp, alive, last);
                 if (__all(done)) break;
             }
         }
@@ -220,6 +212,7 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
         // exactly the (1 - alpha) factors the product would
         if (u.seg == 0) st[SEG_TLOC * TILE_PIX + tid] = done ? 0.f : T;
     }
+#undef done
 }
 
 // First launch: every unit that depends on nothing -- the exact walk of each tile's FIRST segment (single-segment

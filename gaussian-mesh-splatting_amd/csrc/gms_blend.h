@@ -97,6 +97,52 @@ __device__ __forceinline__ float pair_power(float A, float B, float C, float dx,
     return __fmaf_rn(-0.5f, s, -(b * dy));
 }
 
+// ---- The compositing step of the QUADRANT kernels' forward walks, predicated through EXEC (round 6; blend_micro.hip::fwd_step_exec has the
+// reasoning: a walk costs what it issues, and the compiler's form of the nested conditions is ten instructions of mask algebra, saveexec and
+// branches per entry).  A lane's state is `alive` (1 until the pixel stops, lies outside the image or was dead on entry); the entry is the
+// same for the whole wave, so its validity is the caller's (scalar) branch and `pos` -- what n_contrib records -- is a scalar.  The tests
+// narrow EXEC themselves, the stop rule takes its lanes out and clears `alive`, the body runs under what is left.  Same arithmetic, same order.
+__device__ __forceinline__ void quad_step_exec(float pw, float al, float cr, float cg, float cb, float cd, uint32_t pos, float &T, float &C0, float &C1,
+                                               float &C2, float &Dp, int &alive, uint32_t &last)
+{
+    uint64_t sv; float tmp, w;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_lt_i32_e32 vcc, 0, %[alive]\n\t"
+                 "v_cmpx_ge_f32_e32 vcc, 0, %[pw]\n\t"
+                 "v_cmpx_le_f32_e32 vcc, %[amin], %[al]\n\t"
+                 "v_sub_f32_e32 %[tmp], 1.0, %[al]\n\t"
+                 "v_mul_f32_e32 %[tmp], %[T], %[tmp]\n\t"
+                 "v_cmp_ngt_f32_e32 vcc, %[tmin], %[tmp]\n\t"          // NOT (T' < 1e-4): the lanes that composite this entry
+                 "v_cndmask_b32_e32 %[alive], 0, %[alive], vcc\n\t"
+                 "s_and_b64 exec, exec, vcc\n\t"
+                 "v_mul_f32_e32 %[w], %[al], %[T]\n\t"
+                 "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+                 "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+                 "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+                 "v_fmac_f32_e32 %[Dp], %[cd], %[w]\n\t"
+                 "v_mov_b32_e32 %[T], %[tmp]\n\t"
+                 "v_mov_b32_e32 %[last], %[pos]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [tmp] "=&v"(tmp), [w] "=&v"(w), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp),
+                   [alive] "+v"(alive), [last] "+v"(last)
+                 : [pw] "v"(pw), [al] "v"(al), [amin] "s"(ALPHA_MIN), [tmin] "s"(T_MIN), [pos] "s"(pos), [cr] "v"(cr), [cg] "v"(cg), [cb] "v"(cb), [cd] "v"(cd)
+                 : "vcc");
+}
+// ... and of the transmittance products: Tl *= 1 - alpha where power <= 0 and alpha >= 1/255
+__device__ __forceinline__ void quad_tloc_step_exec(float pw, float al, float &Tl)
+{
+    uint64_t sv; float tmp;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "v_cmpx_ge_f32_e32 vcc, 0, %[pw]\n\t"
+                 "v_cmpx_le_f32_e32 vcc, %[amin], %[al]\n\t"
+                 "v_sub_f32_e32 %[tmp], 1.0, %[al]\n\t"
+                 "v_mul_f32_e32 %[Tl], %[Tl], %[tmp]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [tmp] "=&v"(tmp), [Tl] "+v"(Tl)
+                 : [pw] "v"(pw), [al] "v"(al), [amin] "s"(ALPHA_MIN)
+                 : "vcc");
+}
+
 // inclusive rectangle of pixel centres
 struct RectF { float wx0, wy0, wx1, wy1; };
 
