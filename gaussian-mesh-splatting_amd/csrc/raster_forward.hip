@@ -140,12 +140,16 @@ __device__ __forceinline__ void sh_colour(const float *row_lds, float x, float y
 // of mesh_fwd_kernel (gms_mesh.h::splat_from_face) -- instead of loading means3D / scales / rotations / opacities: those four
 // tensors (44 bytes per Gaussian written by K0 and read back here, plus K0's raw copies) never reach HBM and the K0 launch is gone.
 template <int SHDEG, bool SPLIT, int MODE = 0, bool DMA = false, bool K0 = false>
-__global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
+__device__ __forceinline__ void preprocess_fwd_body(const PreArgs &a)
 {
 #pragma clang fp contract(off)
     static_assert(!DMA || (SHDEG == 3 && SPLIT && MODE == 0), "the LDS-DMA staging exists for split degree-3 storage");
     static_assert(!K0 || DMA, "the fused mesh input rides on the LDS-DMA instantiation");
-    constexpr int DMA_WAVE_FLOATS = WAVE * 48;        // 64 x 45 REST floats, then 64 x 3 DC floats
+    // Round 6: the REST rows come in as TWO halves of 32 rows through the same 6 KB of LDS per wave (6 x 1 KiB DMA instructions each,
+    // 1 440 of the 1 536 floats used), the 64 x 3 DC floats behind them: 27 KB per block instead of 49.
+    constexpr int DMA_HALF_ROWS = WAVE / 2, DMA_HALF_Q = 6;                       // rows and DMA instructions per half
+    constexpr int DMA_REST_FLOATS = DMA_HALF_Q * WAVE * 4;                        // 1 536 (>= 32 x 45 = 1 440)
+    constexpr int DMA_WAVE_FLOATS = DMA_REST_FLOATS + WAVE * 3;
     __shared__ __attribute__((aligned(16))) float sh_lds[MODE == 1 ? 2 * TT_SLOTS : (DMA ? 4 * DMA_WAVE_FLOATS : 4 * WAVE * SH_PITCH)];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * BLOCK + tid;
@@ -176,9 +180,9 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         } else if (DMA) {
             float *wl = sh_lds + wave * DMA_WAVE_FLOATS;
             const float *sp = a.shs_rest + (size_t)g0 * RESTF;       // g0 % 64 == 0: 16-byte aligned
-            const int nfl = rows * RESTF;
+            const int nfl = max(0, min(rows, DMA_HALF_ROWS)) * RESTF;        // first half: rows 0 .. 31
 #pragma unroll
-            for (int j = 0; j < NQ; j++) {
+            for (int j = 0; j < DMA_HALF_Q; j++) {
                 const int e4 = (lane + WAVE * j) * 4;                // (a chunk that straddles the end of the array is copied below)
                 if (e4 + 3 < nfl)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + e4),
@@ -187,7 +191,7 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
             const float *dp = a.shs + (size_t)g0 * 3;
             if (lane * 4 + 3 < rows * 3)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dp + lane * 4),
-                                                 (__attribute__((address_space(3))) void *)(wl + WAVE * RESTF), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(wl + DMA_REST_FLOATS), 16, 0, 0);
         } else if (!SPLIT) {
             const float4 *src = reinterpret_cast<const float4 *>(a.shs) + (size_t)g0 * 12;   // M = 16: 12 float4 per row
 #pragma unroll
@@ -301,27 +305,50 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
         float *wl = sh_lds + wave * DMA_WAVE_FLOATS;
         const int g0 = blockIdx.x * BLOCK + wave * WAVE;
         const int rows = max(0, min(WAVE, a.P - g0));          // (the last block's later waves may own no row at all)
-        if (rows < WAVE) {          // last wave of the array: the (at most one) 16-byte chunk of each block that straddles its end
-            const int nfl = rows * RESTF, nd = rows * 3;
-            for (int e = (nfl & ~3) + lane; e < nfl; e += WAVE) wl[e] = a.shs_rest[(size_t)g0 * RESTF + e];
-            for (int e = (nd & ~3) + lane; e < nd; e += WAVE) wl[WAVE * RESTF + e] = a.shs[(size_t)g0 * 3 + e];
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the LDS-DMA copies have landed
-        wave_sync();                               // the rows are this wave's own
+        const float *sp = a.shs_rest + (size_t)g0 * RESTF;
+        float dxc = 0.f, dyc = 0.f, dzc = 0.f;
         if (vis) {
-            float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
-            float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-            float r[48];
+            const float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+            const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+            dxc = dx * inv; dyc = dy * inv; dzc = dz * inv;
+        }
 #pragma unroll
-            for (int c = 0; c < 3; c++) r[c] = wl[WAVE * RESTF + lane * 3 + c];
+        for (int half = 0; half < 2; half++) {
+            const int r0 = half * DMA_HALF_ROWS;                             // first row of this half
+            const int hrows = max(0, min(rows - r0, DMA_HALF_ROWS));
+            if (half == 1) {
+                wave_sync();                           // every lane of the first half has its coefficients in registers
+                const int nfl = hrows * RESTF;
 #pragma unroll
-            for (int m = 0; m < RESTF; m++) r[3 + m] = wl[lane * RESTF + m];
-            const float x = dx * inv, y = dy * inv, z = dz * inv;
+                for (int j = 0; j < DMA_HALF_Q; j++) {
+                    const int e4 = (lane + WAVE * j) * 4;
+                    if (e4 + 3 < nfl)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + r0 * RESTF + e4),
+                                                         (__attribute__((address_space(3))) void *)(wl + WAVE * 4 * j), 16, 0, 0);
+                }
+            }
+            if (hrows < DMA_HALF_ROWS) {   // last wave of the array: the (at most one) 16-byte chunk of each block that straddles its end
+                const int nfl = hrows * RESTF;
+                for (int e = (nfl & ~3) + lane; e < nfl; e += WAVE) wl[e] = sp[r0 * RESTF + e];
+            }
+            if (half == 0 && rows < WAVE) {
+                const int nd = rows * 3;
+                for (int e = (nd & ~3) + lane; e < nd; e += WAVE) wl[DMA_REST_FLOATS + e] = a.shs[(size_t)g0 * 3 + e];
+            }
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): the LDS-DMA copies have landed
+            wave_sync();                               // the rows are this wave's own
+            if (vis && (lane >> 5) == half) {
+                float r[48];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                float v = sh_eval_channel<3>(r, c, x, y, z) + 0.5f;
-                if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
-                rgb[c] = v;
+                for (int c = 0; c < 3; c++) r[c] = wl[DMA_REST_FLOATS + lane * 3 + c];
+#pragma unroll
+                for (int m = 0; m < RESTF; m++) r[3 + m] = wl[(lane - r0) * RESTF + m];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    float v = sh_eval_channel<3>(r, c, dxc, dyc, dzc) + 0.5f;
+                    if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
+                    rgb[c] = v;
+                }
             }
         }
     } else if (SHDEG >= 0) {
@@ -473,6 +500,17 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a)
             atomicAdd(&a.tile_count[(bminy + ty) * a.gx + bminx + tx], 1u);
         }
     }
+}
+
+template <int SHDEG, bool SPLIT, int MODE = 0>
+__global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a) { preprocess_fwd_body<SHDEG, SPLIT, MODE, false, false>(a); }
+// The LDS-DMA instantiations: 27 KB of LDS per block (SH rows in two halves) admits five blocks per CU, and five blocks per CU hold the whole
+// grid of the headline frame (1 171 blocks) in ONE round -- at three (49 KB) and at four (100 registers) a second, half-empty round follows:
+// 35.5 / 34.9 us against 31.5 at five (profiles/r06w1_*, r06w2_*).  The compiler is held to the 96 registers that takes (two to four spilled).
+template <bool K0>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) preprocess_fwd_dma_kernel(PreArgs a)
+{
+    preprocess_fwd_body<3, true, 0, true, K0>(a);
 }
 
 // ------------------------------------------------------------------------------------ K2
@@ -1630,8 +1668,8 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     case 5: GMS_PRE(2, true); break;
     case 6: GMS_PRE(3, false); break;
     case 7:
-        if (mesh) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
-        else if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_kernel<3, true, 0, true><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        if (mesh) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        else if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<false><<<pblocks, BLOCK, 0, stream>>>(pa)));
         else GMS_PRE(3, true);
         break;
     default: GMS_PRE_M(-1, false, 0, stream); break;
