@@ -10,8 +10,8 @@ src, key = sys.argv[1], sys.argv[2]
 stats_path = sys.argv[4] if len(sys.argv) > 4 else None
 dst = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] != "-" else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 t = json.load(open(src))
-names = {"preprocess_fwd": ["preprocess_fwd"], "tile_scan": ["tile_scan"], "emit_instances": ["emit_instances"],
-         "tile_sort": ["tile_presort", "tile_merge"], "blend_head": ["micro_head", "blend_head"], "blend_fwd": ["micro_fwd", "blend_fwd"],
+names = {"preprocess_fwd": ["preprocess_fwd_dma", "preprocess_fwd"], "tile_scan": ["tile_scan"], "emit_instances": ["emit_instances"],
+         "tile_sort": ["tile_presort_reg", "tile_presort", "tile_merge"], "blend_head": ["micro_head", "blend_head"], "blend_fwd": ["micro_fwd", "blend_fwd"],
          "blend_finalize": ["micro_finalize", "blend_finalize"], "blend_bwd": ["micro_bwd", "blend_bwd"], "micro_filter": ["micro_filter"],
          "preprocess_bwd": ["preprocess_bwd"],
          "mesh_fwd": ["mesh_fwd"], "mesh_bwd_splat": ["mesh_bwd_splat"], "mesh_bwd_face": ["mesh_bwd_face_thread", "mesh_bwd_face_wave", "mesh_bwd_fused"]}
