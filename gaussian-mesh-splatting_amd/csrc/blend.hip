@@ -153,16 +153,15 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
     int alive = (!p.inside || dead_on_entry) ? 0 : 1;          // (gms_blend.h::quad_step_exec clears it when the stop rule fires)
-#define done (alive == 0)
 
     for (uint32_t base = u.beg; base < u.end; base += QN) {
-        if (WPB == 4) { if (__syncthreads_and(done)) break; }
-        else { if (__all(done)) break; wave_sync(); }
+        if (WPB == 4) { if (__syncthreads_and(alive == 0)) break; }
+        else { if (__all(alive == 0)) break; wave_sync(); }
         const uint32_t idx = base + qt;
         if (qt < QN && idx < u.end) recs[qt] = o.rec[(uint32_t)g.keys[idx]];
         if (WPB == 4) __syncthreads(); else wave_sync();
         const int cnt = (int)min((uint32_t)QN, u.end - base);
-        if (__all(done)) continue;                 // wave-uniform: this quadrant is finished
+        if (__all(alive == 0)) continue;           // wave-uniform: this quadrant is finished
         for (int chunk = 0; chunk < cnt; chunk += WAVE) {
             uint64_t mask = __ballot(quadrant_hit(recs, chunk + lane, cnt, p, dbg_on(g, 512u)));
             while (mask) {
@@ -187,7 +186,7 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
                 for (int e = 0; e < NE; e++)
                     if (val[e])          // (the same for the whole wave: a scalar branch)
                         quad_step_exec(pw[e], al[e], r1[e].z, r1[e].w, r2[e].x, r2[e].y, (base - u.tile_beg) + (uint32_t)k[e] + 1u, T, C0, C1, C2, Dp, alive, last);
-                if (__all(done)) break;
+                if (__all(alive == 0)) break;
             }
         }
     }
@@ -210,9 +209,8 @@ __device__ __forceinline__ void fwd_unit(const BlendGrid &g, const BlendFwdOut &
         // the first segment's exact walk doubles as its transmittance product: a pixel that terminated here is
         // dead on entry to every later segment (any value < 1e-4 says so); one that did not has multiplied
         // exactly the (1 - alpha) factors the product would
-        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + tid] = done ? 0.f : T;
+        if (u.seg == 0) st[SEG_TLOC * TILE_PIX + tid] = alive == 0 ? 0.f : T;
     }
-#undef done
 }
 
 // First launch: every unit that depends on nothing -- the exact walk of each tile's FIRST segment (single-segment
