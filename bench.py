@@ -760,7 +760,8 @@ def main():
                 continue
             us = sum(kernels[m]["avg_us"] * kernels[m]["launches_per_step"] for m in have_k) / max(vps, 1)
             sb = fn(P, N, F, size * size)
-            tr = [kernels[m]["traffic"] for m in have_k]
+            # (PMC traffic is per launch -- for tile_sort the mean of its launches: a stage's traffic counts every launch of the view)
+            tr = [None if kernels[m]["traffic"] is None else int(kernels[m]["traffic"] * kernels[m]["launches_per_step"] / max(vps, 1)) for m in have_k]
             stages[sname] = {"kernels": have_k, "sum_us_per_view": round(us, 2), "algorithmic_bytes": sb,
                              "achieved_GBps": round(sb / (us * 1e-6) / 1e9, 1) if us > 0 else None,
                              "frac_of_8TBps": round(sb / (us * 1e-6) / 8e12, 4) if us > 0 else None,
