@@ -533,8 +533,8 @@ GmsMeshArgs mesh_args(const Tensor &vertices, const Tensor &faces, const Tensor 
 }
 
 // Forward-only frame of the animated render drivers (games_hip.animate): mesh -> image in the rasterizer's own launches, K0 inside
-// the preprocess thread (GmsRasterForwardArgs.mesh).  Returns (image, radii, inverse depth).
-std::tuple<Tensor, Tensor, Tensor> render_mesh_forward(const Tensor &vertices, const Tensor &faces, const Tensor &_alpha, const Tensor &_scale,
+// the preprocess thread (GmsRasterForwardArgs.mesh).  Returns (image, radii, inverse depth, radii > 0).
+std::tuple<Tensor, Tensor, Tensor, Tensor> render_mesh_forward(const Tensor &vertices, const Tensor &faces, const Tensor &_alpha, const Tensor &_scale,
                                                        const Tensor &_opacity, int64_t mode, int64_t spf, const Tensor &splat_face,
                                                        const Tensor &sh_dc, const Tensor &sh_rest, const Tensor &bg, const Tensor &view,
                                                        const Tensor &proj, const Tensor &campos, int64_t H, int64_t W, double tanx, double tany,
@@ -554,9 +554,10 @@ std::tuple<Tensor, Tensor, Tensor> render_mesh_forward(const Tensor &vertices, c
     GmsMeshArgs m = mesh_args(v, faces, al, sc, mode, spf, Tensor(), splat_face, true, op);
     // (P stands in for means3D: forward_core reads the device and the count from its first tensor argument)
     Tensor stand_in = sh_dc.view({P, 3});
+    Tensor visible = torch::empty({P}, sh_dc.options().dtype(torch::kBool));          // radii > 0, written by the preprocess kernel
     Forward f = forward_core(bg, stand_in, sh_dc, sh_rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
-                             3, false, aa, debug, Tensor(), true, &m);
-    return std::make_tuple(f.color, f.radii, f.invdepth);
+                             3, false, aa, debug, visible, true, &m);
+    return std::make_tuple(f.color, f.radii, f.invdepth, visible);
 }
 
 class MeshFn : public torch::autograd::Function<MeshFn> {
@@ -682,8 +683,10 @@ public:
         GmsMeshArgs m = mesh_args(v, faces, al, sc, mode, spf, Tensor(), sf, true, op);
         m.prezero = mf(vgrad); m.prezero_count = vgrad.defined() ? vgrad.numel() : 0;
         Tensor stand_in = dc.view({P, 3});          // (forward_core reads the device and the count from its first tensor argument)
+        // `visibility_filter` (radii > 0, renderer/gaussian_renderer/__init__.py:108) out of the preprocess kernel, as on the two-node route
+        Tensor visible = torch::empty({P}, fopt.dtype(torch::kBool));
         Forward f = forward_core(bg, stand_in, dc, rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
-                                 3, false, aa, debug, Tensor(), true, &m, &mo, will_backward);
+                                 3, false, aa, debug, visible, true, &m, &mo, will_backward);
         ctx->saved_data["ticket0"] = f.ticket[0]; ctx->saved_data["ticket1"] = f.ticket[1]; ctx->saved_data["launched"] = f.launched_units;
         ctx->save_for_backward({v, faces, al, sc, op, sf.defined() ? sf : torch::empty({0}, fopt), vgrad.defined() ? vgrad : torch::empty({0}, fopt),
                                 mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, dc, rest, f.radii, f.geom, f.binning, f.image,
@@ -693,8 +696,8 @@ public:
         ctx->saved_data["debug"] = debug; ctx->saved_data["H"] = H; ctx->saved_data["W"] = W; ctx->saved_data["mode"] = mode;
         ctx->saved_data["spf"] = spf; ctx->saved_data["used"] = false;
         // the stored Gaussians are by-products for the model's attributes: gradients reach the mesh parameters through THIS node
-        ctx->mark_non_differentiable({f.radii, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act});
-        return {f.color, f.radii, f.invdepth, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act};
+        ctx->mark_non_differentiable({f.radii, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, visible});
+        return {f.color, f.radii, f.invdepth, mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, visible};
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list grads)

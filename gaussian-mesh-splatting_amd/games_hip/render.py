@@ -111,14 +111,15 @@ def _render_training_frame_from_mesh(viewpoint_camera, pc, pipe, bg_color, scali
         z = _zero_cache[key] = torch.zeros((P, 3), dtype=torch.float32, device=_alpha.device)
     screenspace_points = z.detach().requires_grad_(True)
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
-    image, radii, invdepth, xyz, scaling_act, rotation_unit, opacity_act = dgr._C.render_mesh(
+    image, radii, invdepth, xyz, scaling_act, rotation_unit, opacity_act, visible = dgr._C.render_mesh(
         vertices, faces, _alpha, _scale, pc._opacity, pc._features_dc, pc._features_rest, screenspace_points,
         ALPHA_MODES[getattr(pc, "alpha_mode", "relu")], int(_alpha.shape[1]), dgr._empty(_alpha.device), bg_color,
         viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, H, W,
         math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5), float(scaling_modifier), bool(pipe.antialiasing),
         bool(pipe.debug))
     pc._hip_fused_frame(xyz, scaling_act, rotation_unit, opacity_act)
-    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii, "depth": invdepth}
+    # (`visibility_filter` = radii > 0 comes out of the preprocess kernel, as on the two-node route: no elementwise launch)
+    return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii, "depth": invdepth}
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
@@ -199,12 +200,12 @@ def render_mesh_frame(vertices: torch.Tensor, faces: torch.Tensor, viewpoint_cam
     import diff_gaussian_rasterization as dgr
     from .mesh_op import ALPHA_MODES
     H, W = int(viewpoint_camera.image_height), int(viewpoint_camera.image_width)
-    color, radii, invdepth = dgr._C.render_mesh_forward(
+    color, radii, invdepth, visible = dgr._C.render_mesh_forward(
         vertices.float(), faces, pc._alpha, getattr(pc, getattr(pc, "_hip_scale_attr", "_scale")), pc._opacity, ALPHA_MODES[getattr(pc, "alpha_mode", "relu")], int(pc._alpha.shape[1]),
         dgr._empty(vertices.device), pc._features_dc, pc._features_rest, bg_color, viewpoint_camera.world_view_transform,
         viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, H, W, math.tan(viewpoint_camera.FoVx * 0.5),
         math.tan(viewpoint_camera.FoVy * 0.5), float(scaling_modifier), bool(pipe.antialiasing), bool(pipe.debug))
-    return {"render": color, "viewspace_points": None, "visibility_filter": radii > 0, "radii": radii, "depth": invdepth}
+    return {"render": color, "viewspace_points": None, "visibility_filter": visible, "radii": radii, "depth": invdepth}
 
 
 def render_animated(idxs, triangles, viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0,

@@ -25,6 +25,8 @@ def _step(model, cam, bg, defer):
     model.update_alpha(); model.prepare_scaling_rot()
     out = render(cam, model, PipelineParams(), bg)
     img = out["render"]
+    # renderer/gaussian_renderer/__init__.py:108: on either route the filter comes out of the preprocess kernel, not out of a comparison launch
+    assert out["visibility_filter"].dtype == torch.bool and torch.equal(out["visibility_filter"], out["radii"] > 0)
     (img * ((img.detach() - 0.5) / img.numel() * 1000.0)).sum().backward()
     g = {n: getattr(model, n).grad.detach().clone() for n in PARAMS}
     g["viewspace"] = out["viewspace_points"].grad.detach().clone()
