@@ -471,7 +471,7 @@ def main():
         # mean over ALL views of the step (this rank's and the other ranks'): the 1/world of the gradient average is folded
         # into the upstream gradient, so the all-reduce is a plain sum and no 64 MB division pass follows it
         inv_norm = 1.0 / (3.0 * size * size * vps * world)
-        neg_half_norm = torch.tensor(-0.5 * inv_norm, device=device)
+        neg_half_norm = torch.tensor(-0.5 * inv_norm)      # (a 0-dim CPU tensor is a scalar to the elementwise kernel: a device one makes it the strided, unvectorised form)
         packed = PackedGradExchange(params, model._features_dc, model._features_rest, world, force=force_ddp, average=False) if (reduce_grads and distributed and sh_mode == "packed") else None
         reducer = OverlappedGradAllReduce(params, world, average=False, force=force_ddp, algorithm=algo) if (reduce_grads and distributed and packed is None) else None
         exchange = ShFactorExchange(model._features_dc, model._features_rest, world, force=force_ddp, average=False) if (reducer is not None and sh_factor) else None
