@@ -386,7 +386,7 @@ def main():
     all_cams = [syn.orbit_camera(k, width=size, height=size).to(device) for k in range(8)]
 
     if args.loss == "l1_ssim":
-        from games_hip.loss import l1_ssim_loss
+        from games_hip.loss import l1_ssim_loss, backward_seed
         yy, xx = torch.meshgrid(torch.linspace(0, 6, size, device=device), torch.linspace(0, 5, size, device=device), indexing="ij")
         gt_image = (0.5 + 0.4 * torch.sin(2.0 * xx) * torch.cos(1.5 * yy)).expand(3, size, size).contiguous()
 
@@ -511,7 +511,8 @@ def main():
                 loss = l1_ssim_loss(images[0], gt_image, 0.2)
                 for im in images[1:]:
                     loss = loss + l1_ssim_loss(im, gt_image, 0.2)
-                (loss / (vps * world) if vps * world > 1 else loss).backward()
+                loss = loss / (vps * world) if vps * world > 1 else loss
+                loss.backward(backward_seed(loss))          # (as games_hip.train does: a cached ones_like instead of a fill launch per step)
             else:
                 with torch.no_grad():                        # dL/dcolor = (image - 0.5) / (3HW), dense
                     grads = [torch.add(neg_half_norm, im, alpha=inv_norm) for im in images]      # one elementwise kernel each

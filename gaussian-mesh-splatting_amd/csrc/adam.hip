@@ -56,13 +56,23 @@ __global__ void __launch_bounds__(BLOCK) adam_kernel(AdamTable t, float w1, floa
         const int64_t i = base + ((int64_t)j * BLOCK + threadIdx.x) * 4;
         if (i >= n) break;
         if (vec && i + 4 <= n) {
-            float4 p = *(const float4 *)(P + i), m = *(const float4 *)(M + i), v = *(const float4 *)(V + i);
-            const float4 g = *(const float4 *)(G + i);
+            // The moments and the gradient (6 of the 7 floats that move per element) are touched by nobody but this kernel, once per step:
+            // non-temporal, so that the 420 MB of them do not push the PARAMETERS -- which the next frame's preprocess launches read -- out of
+            // the 256 MB Infinity Cache.  The parameters themselves go through the caches as before.
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            float4 p = *(const float4 *)(P + i);
+            const v4f mv = __builtin_nontemporal_load((const v4f *)(M + i)), vv = __builtin_nontemporal_load((const v4f *)(V + i));
+            const v4f gv = __builtin_nontemporal_load((const v4f *)(G + i));
+            float4 m = make_float4(mv.x, mv.y, mv.z, mv.w), v = make_float4(vv.x, vv.y, vv.z, vv.w);
+            const float4 g = make_float4(gv.x, gv.y, gv.z, gv.w);
             adam_update(p.x, g.x, m.x, v.x, w1, beta2, w2, step_size, bc2_sqrt, eps);
             adam_update(p.y, g.y, m.y, v.y, w1, beta2, w2, step_size, bc2_sqrt, eps);
             adam_update(p.z, g.z, m.z, v.z, w1, beta2, w2, step_size, bc2_sqrt, eps);
             adam_update(p.w, g.w, m.w, v.w, w1, beta2, w2, step_size, bc2_sqrt, eps);
-            *(float4 *)(P + i) = p; *(float4 *)(M + i) = m; *(float4 *)(V + i) = v;
+            *(float4 *)(P + i) = p;
+            v4f mo, vo;
+            mo.x = m.x; mo.y = m.y; mo.z = m.z; mo.w = m.w; vo.x = v.x; vo.y = v.y; vo.z = v.z; vo.w = v.w;
+            __builtin_nontemporal_store(mo, (v4f *)(M + i)); __builtin_nontemporal_store(vo, (v4f *)(V + i));
         } else {
             for (int64_t e = i; e < n && e < i + 4; e++) {
                 float p = P[e], m = M[e], v = V[e];

@@ -777,9 +777,12 @@ std::vector<Tensor> render_mesh(const Tensor &vertices, const Tensor &faces, con
 // ---------------------------------------------------------------------------------------------- fused L1 + SSIM
 class L1SsimFn : public torch::autograd::Function<L1SsimFn> {
 public:
-    static Tensor forward(AutogradContext *ctx, Tensor img, Tensor gt, double w_l1, double w_ssim, double bias, bool need_grad)
+    // Returns {value (0-dim, differentiable), (l1, ssim) (reported, not trained on)}: two views of one 3-float buffer.  A single [3] output
+    // that the caller indexes costs the backward a zeros(3) and a copy (SelectBackward) before this node is even reached.
+    static variable_list forward(AutogradContext *ctx, Tensor img, Tensor gt, double w_l1, double w_ssim, double bias, bool need_grad)
     {
         require_gpu(img); require_gpu(gt);
+        ctx->set_materialize_grads(false);      // (the by-products' gradient would otherwise arrive as a zeros tensor: a fill launch per step)
         TORCH_CHECK(img.sizes() == gt.sizes(), "image shapes differ");
         TORCH_CHECK(img.dim() >= 2, "images must be [..., H, W]");
         c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(img.device());
@@ -798,28 +801,34 @@ public:
         check_rc(gms_l1_ssim_forward(&a, mf(dmaps), mf(partials), mf(out), stream_of(x)), "gms_l1_ssim_forward");
         ctx->save_for_backward({x, y, dmaps.defined() ? dmaps : torch::empty({0}, fopt)});
         ctx->saved_data["w_l1"] = w_l1; ctx->saved_data["w_ssim"] = w_ssim; ctx->saved_data["bias"] = bias;
-        return out;
+        Tensor value = out.select(0, 0), stats = out.narrow(0, 1, 2);
+        ctx->mark_non_differentiable({stats});
+        return {value, stats};
     }
 
     static variable_list backward(AutogradContext *ctx, variable_list g)
     {
         auto s = ctx->get_saved_variables();
         const Tensor &x = s[0], &y = s[1], &dmaps = s[2];
+        Tensor none;
+        if (!g[0].defined()) return {none, none, none, none, none, none};          // (the value was not used)
         TORCH_CHECK(dmaps.numel() > 0, "l1_ssim backward called but the forward ran without requires_grad");
         c10::hip::OptionalHIPGuardMasqueradingAsCUDA guard(x.device());
         const int64_t h = x.size(-2), w = x.size(-1), planes = x.numel() / (h * w);
         // only element 0 (the value) is differentiable; the l1 / ssim by-products are reported, not trained on
-        Tensor gv = f32c(g[0].slice(0, 0, 1));
+        Tensor gv = f32c(g[0].reshape({1}));
         Tensor d_img = torch::empty_like(x);
         GmsLossArgs a{(int32_t)planes, (int32_t)h, (int32_t)w, cf(x), cf(y), (float)ctx->saved_data["w_l1"].toDouble(),
                       (float)ctx->saved_data["w_ssim"].toDouble(), (float)ctx->saved_data["bias"].toDouble()};
         check_rc(gms_l1_ssim_backward(&a, cf(dmaps), cf(gv), mf(d_img), stream_of(x)), "gms_l1_ssim_backward");
-        Tensor none;
         return {d_img, none, none, none, none, none};
     }
 };
 
-Tensor l1_ssim(const Tensor &img, const Tensor &gt, double w_l1, double w_ssim, double bias) { return L1SsimFn::apply(img, gt, w_l1, w_ssim, bias, at::GradMode::is_enabled() && img.requires_grad()); }
+std::vector<Tensor> l1_ssim(const Tensor &img, const Tensor &gt, double w_l1, double w_ssim, double bias)
+{
+    return L1SsimFn::apply(img, gt, w_l1, w_ssim, bias, at::GradMode::is_enabled() && img.requires_grad());
+}
 
 // ---------------------------------------------------------------------------------------------- multi-tensor Adam
 void adam_step(const std::vector<Tensor> &params, const std::vector<Tensor> &grads, const std::vector<Tensor> &exp_avg,
@@ -861,7 +870,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mesh_to_gaussians", &mesh_to_gaussians, "differentiable mesh-face -> Gaussian parameterization", nogil());
     m.def("render_mesh_forward", &render_mesh_forward, "forward-only frame straight from a mesh (K0 inside the preprocess thread)", nogil());
     m.def("render_mesh", &render_mesh, "differentiable frame straight from a mesh: [image, radii, invdepth, xyz, scaling_act, rotation_unit, opacity_act]", nogil());
-    m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns [value, l1, ssim]", nogil());
+    m.def("l1_ssim", &l1_ssim, "differentiable w_l1 * L1 + w_ssim * SSIM + bias; returns (value [0-dim], [l1, ssim])", nogil());
     m.def("adam_step", &adam_step, nogil());
     m.def("set_keep_buffers", &set_keep_buffers, "keep references to the last forward's scratch tensors (diagnostics only)");
     m.def("clear_accum", &clear_accum);

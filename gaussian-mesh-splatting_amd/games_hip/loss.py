@@ -16,11 +16,27 @@ from diff_gaussian_rasterization import _lib
 
 
 def _weighted(img, gt, w_l1, w_ssim, bias):
+    """-> (value [0-dim, differentiable], l1, ssim [device scalars, reported only])"""
     if _dgr._C is not None:          # autograd node in C++ (csrc/torch_binding.cpp), same C ABI underneath
         if img.shape != gt.shape:
             raise ValueError(f"image shapes differ: {tuple(img.shape)} vs {tuple(gt.shape)}")
-        return _dgr._C.l1_ssim(img, gt, float(w_l1), float(w_ssim), float(bias))
-    return _WeightedL1Ssim.apply(img, gt, w_l1, w_ssim, bias)
+        # (the node hands the value out as a 0-dim tensor of its own: indexing a [3] result would cost every backward a zeros + copy)
+        value, stats = _dgr._C.l1_ssim(img, gt, float(w_l1), float(w_ssim), float(bias))
+        return value, stats[0], stats[1]
+    out = _WeightedL1Ssim.apply(img, gt, w_l1, w_ssim, bias)
+    return out[0], out[1].detach(), out[2].detach()
+
+
+_seed_cache = {}
+
+
+def backward_seed(loss: torch.Tensor) -> torch.Tensor:
+    """A cached `ones_like(loss)` for `loss.backward(backward_seed(loss))`: autograd otherwise launches a one-element fill per step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _seed_cache.get(key)
+    if one is None:
+        one = _seed_cache[key] = torch.ones(loss.shape, dtype=loss.dtype, device=loss.device)
+    return one
 
 
 def _planes(img1, img2):
@@ -85,9 +101,8 @@ class _L1SsimLoss:
 
     def __call__(self, image, gt_image, lambda_dssim: float = 0.2):
         lam = float(lambda_dssim)
-        out = _weighted(image, gt_image, 1.0 - lam, -lam, lam)
-        self.last_l1, self.last_ssim = out[1].detach(), out[2].detach()
-        return out[0]
+        value, self.last_l1, self.last_ssim = _weighted(image, gt_image, 1.0 - lam, -lam, lam)
+        return value
 
 
 l1_ssim_loss = _L1SsimLoss()

@@ -58,6 +58,7 @@ def training(gaussians, train_cameras: Sequence, opt: OptimizationParamsMesh, pi
         render_fn = render
     if loss_fn is None:
         from .loss import l1_ssim_loss as loss_fn
+    from .loss import backward_seed as _seed
     # K0 deferred into the rasterizer's preprocess thread while the restated render() is in use (games_hip.model.HipMeshMixin.hip_defer_k0;
     # GMS_TRAIN_FUSED=0 keeps the eager launch): update_alpha() / prepare_scaling_rot() below then only mark the model stale
     import os as _os
@@ -83,7 +84,7 @@ def training(gaussians, train_cameras: Sequence, opt: OptimizationParamsMesh, pi
         gt_image = viewpoint_cam.original_image.to(image.device)
         loss = loss_fn(image, gt_image, opt.lambda_dssim)
         try:
-            loss.backward()
+            loss.backward(_seed(loss))          # (train.py:108; the seed is a cached ones_like: no fill launch per iteration)
         except RuntimeError as e:
             # deferred read-back of the instance count (diff_gaussian_rasterization.set_deferred_counts): the frame outgrew its buffers and
             # that could only be seen now.  Redo the step with the blocking form (the capacity hint has been raised meanwhile).
@@ -102,7 +103,7 @@ def training(gaussians, train_cameras: Sequence, opt: OptimizationParamsMesh, pi
                 render_pkg = render_fn(viewpoint_cam, gaussians, pipe, bg)
                 image = render_pkg["render"]
                 loss = loss_fn(image, gt_image, opt.lambda_dssim)
-                loss.backward()
+                loss.backward(_seed(loss))
             finally:
                 _dgr.set_deferred_counts(True)
         with torch.no_grad():
