@@ -81,44 +81,71 @@ __global__ void __launch_bounds__(BLOCK) l1_ssim_fwd_kernel(int H, int W, const 
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < LH * LT; idx += BLOCK) {
-        const int r = idx / LT, c = idx - r * LT;
-        float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+    // Round 6: both passes slide the window over REGISTERS -- a thread takes LQ = 4 neighbouring outputs and reads the 14 inputs they share
+    // once instead of 4 x 11 times (335 LDS reads per thread -> 110).  Every output is still the same eleven products added in the same
+    // order.  Horizontal: items (row, group of four columns), 42 x 8; the rows are 43 words apart and the groups four, so a wave's reads and
+    // writes fall on distinct banks.  (Taking the five moment maps through ONE buffer, one after the other -- 20 KB of LDS per block, the
+    // grid in one round of eight blocks per CU -- was built and is slower: it needs 145 registers, and held to fewer it spills: 38 us at
+    // four waves per SIMD, 113-117 us at six / eight, against 30.)
+    constexpr int LQ = 4, NW = 2 * LR + 1, NIN = LQ + NW - 1;
+    static_assert(LT % LQ == 0 && BLOCK == (LT / LQ) * LT, "vertical pass: one thread per (column, group of four rows)");
+    for (int item = tid; item < LH * (LT / LQ); item += BLOCK) {
+        const int r = item / (LT / LQ), c0 = (item - r * (LT / LQ)) * LQ;
+        float xin[NIN], yin[NIN];
 #pragma unroll
-        for (int k = 0; k < 2 * LR + 1; k++) {
-            const float x = sx[r][c + k], y = sy[r][c + k], w = win.w[k];
-            const float wx = w * x, wy = w * y;
-            a += wx; b += wy; aa += wx * x; bb += wy * y; ab += wx * y;
+        for (int j = 0; j < NIN; j++) { xin[j] = sx[r][c0 + j]; yin[j] = sy[r][c0 + j]; }
+#pragma unroll
+        for (int i = 0; i < LQ; i++) {
+            float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+#pragma unroll
+            for (int k = 0; k < NW; k++) {
+                const float x = xin[i + k], y = yin[i + k], w = win.w[k];
+                const float wx = w * x, wy = w * y;
+                a += wx; b += wy; aa += wx * x; bb += wy * y; ab += wx * y;
+            }
+            hz[0][r][c0 + i] = a; hz[1][r][c0 + i] = b; hz[2][r][c0 + i] = aa; hz[3][r][c0 + i] = bb; hz[4][r][c0 + i] = ab;
         }
-        hz[0][r][c] = a; hz[1][r][c] = b; hz[2][r][c] = aa; hz[3][r][c] = bb; hz[4][r][c] = ab;
     }
     __syncthreads();
     float l1_sum = 0.f, ssim_sum = 0.f;
-    for (int idx = tid; idx < LT * LT; idx += BLOCK) {
-        const int r = idx / LT, c = idx - r * LT;
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy >= H || gx >= W) continue;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    {
+        // vertical: thread = (column c, rows r0 .. r0 + 3)
+        const int c = tid & (LT - 1), r0 = (tid / LT) * LQ;
+        float mom[5][LQ];
 #pragma unroll
-        for (int k = 0; k < 2 * LR + 1; k++) {
-            const float w = win.w[k];
-            m1 += w * hz[0][r + k][c]; m2 += w * hz[1][r + k][c];
-            e11 += w * hz[2][r + k][c]; e22 += w * hz[3][r + k][c]; e12 += w * hz[4][r + k][c];
+        for (int m = 0; m < 5; m++) {
+            float col[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) col[j] = hz[m][r0 + j][c];
+#pragma unroll
+            for (int i = 0; i < LQ; i++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; k++) acc += win.w[k] * col[i + k];
+                mom[m][i] = acc;
+            }
         }
-        const float m1m2 = m1 * m2, m1sq = m1 * m1, m2sq = m2 * m2;
-        const float s1 = e11 - m1sq, s2 = e22 - m2sq, s12 = e12 - m1m2;
-        const float An = 2.f * m1m2 + SSIM_C1, Bn = 2.f * s12 + SSIM_C2;
-        const float Ad = m1sq + m2sq + SSIM_C1, Bd = s1 + s2 + SSIM_C2;
-        const float inv = 1.f / (Ad * Bd);
-        const float S = An * Bn * inv;
-        ssim_sum += S;
-        l1_sum += fabsf(sx[r + LR][c + LR] - sy[r + LR][c + LR]);
-        if (dmaps) {
-            const size_t o = pbase + (size_t)gy * W + gx;
-            // S = An*Bn/(Ad*Bd) with s1, s12 functions of (mu1, E[x^2], E[xy]):
-            dmaps[o] = 2.f * m2 * (Bn - An) * inv - S * 2.f * m1 * (1.f / Ad - 1.f / Bd);   // dS/dmu1
-            dmaps[map_stride + o] = -S / Bd;                                                 // dS/dE[x^2]
-            dmaps[2 * map_stride + o] = 2.f * An * inv;                                      // dS/dE[xy]
+#pragma unroll
+        for (int i = 0; i < LQ; i++) {
+            const int r = r0 + i;
+            const int gy = y0 + r, gx = x0 + c;
+            if (gy >= H || gx >= W) continue;
+            const float m1 = mom[0][i], m2 = mom[1][i], e11 = mom[2][i], e22 = mom[3][i], e12 = mom[4][i];
+            const float m1m2 = m1 * m2, m1sq = m1 * m1, m2sq = m2 * m2;
+            const float s1 = e11 - m1sq, s2 = e22 - m2sq, s12 = e12 - m1m2;
+            const float An = 2.f * m1m2 + SSIM_C1, Bn = 2.f * s12 + SSIM_C2;
+            const float Ad = m1sq + m2sq + SSIM_C1, Bd = s1 + s2 + SSIM_C2;
+            const float inv = 1.f / (Ad * Bd);
+            const float S = An * Bn * inv;
+            ssim_sum += S;
+            l1_sum += fabsf(sx[r + LR][c + LR] - sy[r + LR][c + LR]);
+            if (dmaps) {
+                const size_t o = pbase + (size_t)gy * W + gx;
+                // S = An*Bn/(Ad*Bd) with s1, s12 functions of (mu1, E[x^2], E[xy]):
+                dmaps[o] = 2.f * m2 * (Bn - An) * inv - S * 2.f * m1 * (1.f / Ad - 1.f / Bd);   // dS/dmu1
+                dmaps[map_stride + o] = -S / Bd;                                                 // dS/dE[x^2]
+                dmaps[2 * map_stride + o] = 2.f * An * inv;                                      // dS/dE[xy]
+            }
         }
     }
     const float l1_tot = block_sum(l1_sum, red);
@@ -180,34 +207,52 @@ __global__ void __launch_bounds__(BLOCK) l1_ssim_bwd_kernel(int H, int W, const 
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < LH * LT; idx += BLOCK) {
-        const int r = idx / LT, c = idx - r * LT;
-        float a = 0.f, b = 0.f, d = 0.f;
+    constexpr int LQ = 4, NW = 2 * LR + 1, NIN = LQ + NW - 1;          // (the sliding register windows of the forward)
+    for (int item = tid; item < LH * (LT / LQ); item += BLOCK) {
+        const int r = item / (LT / LQ), c0 = (item - r * (LT / LQ)) * LQ;
 #pragma unroll
-        for (int k = 0; k < 2 * LR + 1; k++) {
-            const float w = win.w[k];
-            a += w * sm[0][r][c + k]; b += w * sm[1][r][c + k]; d += w * sm[2][r][c + k];
+        for (int m = 0; m < 3; m++) {
+            float in[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) in[j] = sm[m][r][c0 + j];
+#pragma unroll
+            for (int i = 0; i < LQ; i++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; k++) acc += win.w[k] * in[i + k];
+                hz[m][r][c0 + i] = acc;
+            }
         }
-        hz[0][r][c] = a; hz[1][r][c] = b; hz[2][r][c] = d;
     }
     __syncthreads();
     const float g = dL_dvalue ? dL_dvalue[0] : 1.f;
     const float gl1 = g * c_l1, gss = g * c_ssim;
-    for (int idx = tid; idx < LT * LT; idx += BLOCK) {
-        const int r = idx / LT, c = idx - r * LT;
-        const int gy = y0 + r, gx = x0 + c;
-        if (gy >= H || gx >= W) continue;
-        float a = 0.f, b = 0.f, d = 0.f;
+    {
+        const int c = tid & (LT - 1), r0 = (tid / LT) * LQ;
+        float v[3][LQ];
 #pragma unroll
-        for (int k = 0; k < 2 * LR + 1; k++) {
-            const float w = win.w[k];
-            a += w * hz[0][r + k][c]; b += w * hz[1][r + k][c]; d += w * hz[2][r + k][c];
+        for (int m = 0; m < 3; m++) {
+            float col[NIN];
+#pragma unroll
+            for (int j = 0; j < NIN; j++) col[j] = hz[m][r0 + j][c];
+#pragma unroll
+            for (int i = 0; i < LQ; i++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NW; k++) acc += win.w[k] * col[i + k];
+                v[m][i] = acc;
+            }
         }
-        const size_t o = pbase + (size_t)gy * W + gx;
-        const float x = img[o], y = gt[o];
-        const float diff = x - y;
-        const float sgn = (float)(diff > 0.f) - (float)(diff < 0.f);
-        dL_dimg[o] = gl1 * sgn + gss * (a + 2.f * x * b + y * d);
+#pragma unroll
+        for (int i = 0; i < LQ; i++) {
+            const int gy = y0 + r0 + i, gx = x0 + c;
+            if (gy >= H || gx >= W) continue;
+            const size_t o = pbase + (size_t)gy * W + gx;
+            const float x = img[o], y = gt[o];
+            const float diff = x - y;
+            const float sgn = (float)(diff > 0.f) - (float)(diff < 0.f);
+            dL_dimg[o] = gl1 * sgn + gss * (v[0][i] + 2.f * x * v[1][i] + y * v[2][i]);
+        }
     }
 }
 
