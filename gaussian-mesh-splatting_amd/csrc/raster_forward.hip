@@ -143,7 +143,7 @@ template <int SHDEG, bool SPLIT, int MODE = 0, bool DMA = false, bool K0 = false
 __device__ __forceinline__ void preprocess_fwd_body(const PreArgs &a)
 {
 #pragma clang fp contract(off)
-    static_assert(!DMA || (SHDEG == 3 && SPLIT && MODE == 0), "the LDS-DMA staging exists for split degree-3 storage");
+    static_assert(!DMA || (SHDEG >= 0 && SHDEG <= 3 && SPLIT && MODE == 0), "the LDS-DMA staging exists for split degree-3 STORAGE (any active degree: the rows come in whole)");
     static_assert(!K0 || DMA, "the fused mesh input rides on the LDS-DMA instantiation");
     // Round 6: the REST rows come in as TWO halves of 32 rows through the same 6 KB of LDS per wave (6 x 1 KiB DMA instructions each,
     // 1 440 of the 1 536 floats used), the 64 x 3 DC floats behind them: 27 KB per block instead of 49.
@@ -345,7 +345,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const PreArgs &a)
                 for (int m = 0; m < RESTF; m++) r[3 + m] = wl[(lane - r0) * RESTF + m];
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    float v = sh_eval_channel<3>(r, c, dxc, dyc, dzc) + 0.5f;
+                    float v = sh_eval_channel<SHDEG>(r, c, dxc, dyc, dzc) + 0.5f;          // (the ACTIVE degree: what sh_colour<SHDEG> evaluates)
                     if (v < 0.f) { clampbits |= 1u << c; v = 0.f; }
                     rgb[c] = v;
                 }
@@ -507,10 +507,12 @@ __global__ void __launch_bounds__(BLOCK) preprocess_fwd_kernel(PreArgs a) { prep
 // The LDS-DMA instantiations: 27 KB of LDS per block (SH rows in two halves) admits five blocks per CU, and five blocks per CU hold the whole
 // grid of the headline frame (1 171 blocks) in ONE round -- at three (49 KB) and at four (100 registers) a second, half-empty round follows:
 // 35.5 / 34.9 us against 31.5 at five (profiles/r06w1_*, r06w2_*).  The compiler is held to the 96 registers that takes (two to four spilled).
-template <bool K0>
+// DEG: the ACTIVE SH degree (train.py:86-87 raises it every 1 000 iterations): frames rendered straight from the mesh take this kernel at
+// every degree -- the storage is degree 3 whatever is active, the rows come in whole and the lower bands are evaluated out of them.
+template <bool K0, int DEG = 3>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(5, 5))) preprocess_fwd_dma_kernel(PreArgs a)
 {
-    preprocess_fwd_body<3, true, 0, true, K0>(a);
+    preprocess_fwd_body<DEG, true, 0, true, K0>(a);
 }
 
 // ------------------------------------------------------------------------------------ K2
@@ -1513,10 +1515,10 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
             return GMS_ERR_INVALID_ARGUMENT;
         }
         if (mesh->P != (int64_t)P || !mesh->vertices || !mesh->faces || !mesh->_alpha || !mesh->_scale || !mesh->_opacity ||
-            (mesh->splats_per_face <= 0 && !mesh->splat_face) || !A->shs || !A->shs_rest || A->M != 16 || A->D != 3 || A->colors_precomp ||
+            (mesh->splats_per_face <= 0 && !mesh->splat_face) || !A->shs || !A->shs_rest || A->M != 16 || A->D < 0 || A->D > 3 || A->colors_precomp ||
             A->cov3D_precomp || (((uintptr_t)A->shs) & 15u) || (((uintptr_t)A->shs_rest) & 15u)) {
             set_error("gms_rasterize_forward: the fused mesh input needs a complete GmsMeshArgs (P equal, _opacity set), split degree-3 SH "
-                      "storage (shs + shs_rest, M = 16, D = 3, 16-byte aligned) and no precomputed colours / covariances");
+                      "storage (shs + shs_rest, M = 16, active degree 0 .. 3, 16-byte aligned) and no precomputed colours / covariances");
             return GMS_ERR_INVALID_ARGUMENT;
         }
         if (!A->viewmatrix || !A->projmatrix || !A->campos || !A->radii || !A->geom_alloc || !A->binning_alloc || !A->image_alloc) {
@@ -1659,6 +1661,14 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
             GMS_PRE_M(DEG, SP, 0, stream);                                            \
         }                                                                             \
     } while (0)
+    if (mesh) {          // (validated above: split degree-3 storage; the active degree picks the instantiation)
+        switch (A->D) {
+        case 0: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true, 0><<<pblocks, BLOCK, 0, stream>>>(pa))); break;
+        case 1: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true, 1><<<pblocks, BLOCK, 0, stream>>>(pa))); break;
+        case 2: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true, 2><<<pblocks, BLOCK, 0, stream>>>(pa))); break;
+        default: GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true, 3><<<pblocks, BLOCK, 0, stream>>>(pa))); break;
+        }
+    } else
     switch ((sh_fast ? A->D : -1) * 2 + (split ? 1 : 0)) {
     case 0: GMS_PRE_M(0, false, 0, stream); break;
     case 1: GMS_PRE_M(0, true, 0, stream); break;
@@ -1668,8 +1678,7 @@ extern "C" int64_t gms_rasterize_forward(const GmsRasterForwardArgs *A, void *st
     case 5: GMS_PRE(2, true); break;
     case 6: GMS_PRE(3, false); break;
     case 7:
-        if (mesh) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<true><<<pblocks, BLOCK, 0, stream>>>(pa)));
-        else if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<false><<<pblocks, BLOCK, 0, stream>>>(pa)));
+        if (pre_dma && !aux) GMS_LAUNCH(GMS_K_PREPROCESS_FWD, stream, (preprocess_fwd_dma_kernel<false><<<pblocks, BLOCK, 0, stream>>>(pa)));
         else GMS_PRE(3, true);
         break;
     default: GMS_PRE_M(-1, false, 0, stream); break;

@@ -653,9 +653,10 @@ public:
     static variable_list forward(AutogradContext *ctx, Tensor vertices_, Tensor faces, Tensor alpha_, Tensor scale_, Tensor opacity_,
                                  Tensor sh_dc, Tensor sh_rest, Tensor means2D, int64_t mode, int64_t spf, Tensor splat_face, Tensor bg,
                                  Tensor view, Tensor proj, Tensor campos, int64_t H, int64_t W, double tanx, double tany, double mod,
-                                 bool aa, bool debug, bool vertex_grad, bool will_backward)
+                                 bool aa, bool debug, bool vertex_grad, bool will_backward, int64_t sh_degree)
     {
         ctx->set_materialize_grads(false);
+        TORCH_CHECK(sh_degree >= 0 && sh_degree <= 3, "render_mesh: active SH degree ", sh_degree, " (storage is degree 3: 0 .. 3)");
         require_gpu(vertices_); require_gpu(alpha_); require_gpu(scale_); require_gpu(opacity_); require_gpu(sh_dc); require_gpu(sh_rest);
         TORCH_CHECK(faces.scalar_type() == torch::kInt64 && faces.is_contiguous() && faces.is_cuda(), "faces must be a contiguous int64 device tensor");
         const auto dev = vertices_.device();
@@ -686,7 +687,8 @@ public:
         // `visibility_filter` (radii > 0, renderer/gaussian_renderer/__init__.py:108) out of the preprocess kernel, as on the two-node route
         Tensor visible = torch::empty({P}, fopt.dtype(torch::kBool));
         Forward f = forward_core(bg, stand_in, dc, rest, Tensor(), Tensor(), Tensor(), Tensor(), Tensor(), view, proj, campos, H, W, tanx, tany, mod,
-                                 3, false, aa, debug, visible, true, &m, &mo, will_backward);
+                                 sh_degree, false, aa, debug, visible, true, &m, &mo, will_backward);
+        ctx->saved_data["D"] = sh_degree;
         ctx->saved_data["ticket0"] = f.ticket[0]; ctx->saved_data["ticket1"] = f.ticket[1]; ctx->saved_data["launched"] = f.launched_units;
         ctx->save_for_backward({v, faces, al, sc, op, sf.defined() ? sf : torch::empty({0}, fopt), vgrad.defined() ? vgrad : torch::empty({0}, fopt),
                                 mo.xyz, mo.scaling_act, mo.rotation_unit, mo.opacity_act, dc, rest, f.radii, f.geom, f.binning, f.image,
@@ -740,14 +742,15 @@ public:
         const bool fused_bwd = fused_mesh_backward() && prezeroed && a.splats_per_face > 0 && a.splats_per_face <= 4 && !gms_get_deterministic() && !g_sh_factor.load();
         MeshGrads mg{d_vertices, d_alpha, d_scale, d_opacity};
         Backward b = backward_core(bg, xyz, radii, Tensor(), oact, sact, runit, ctx->saved_data["mod"].toDouble(), Tensor(), view, proj,
-                                   ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest, 3, campos, geom,
+                                   ctx->saved_data["tanx"].toDouble(), ctx->saved_data["tany"].toDouble(), gcol, grads[2], dc, rest,
+                                   ctx->saved_data["D"].toInt(), campos, geom,
                                    R, ctx->saved_data["cap"].toInt(), units, binning, image,
                                    ctx->saved_data["aa"].toBool(), ctx->saved_data["debug"].toBool(), have_pre ? &pre : nullptr,
                                    fused_bwd ? &a : nullptr, fused_bwd ? &mg : nullptr);
         if (fused_bwd) {
             Tensor none;
             return {d_vertices, none, d_alpha, d_scale, d_opacity, b.dsh, b.dsh_rest, b.dmeans2D,
-                    none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+                    none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
         }
         // ... else through the mesh -> Gaussian parameterization as a launch of its own (fused activations: gradients w.r.t. exp / normalize / sigmoid outputs)
         if (a.splats_per_face <= 0) {
@@ -758,20 +761,20 @@ public:
                                                 mf(d_scale), mf(d_opacity), stream_of(v)), "gms_mesh_to_gaussians_backward");
         Tensor none;
         return {d_vertices, none, d_alpha, d_scale, d_opacity, b.dsh, b.dsh_rest, b.dmeans2D,
-                none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
+                none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none, none};
     }
 };
 
 std::vector<Tensor> render_mesh(const Tensor &vertices, const Tensor &faces, const Tensor &_alpha, const Tensor &_scale, const Tensor &_opacity,
                                 const Tensor &sh_dc, const Tensor &sh_rest, const Tensor &means2D, int64_t mode, int64_t spf, const Tensor &splat_face,
                                 const Tensor &bg, const Tensor &view, const Tensor &proj, const Tensor &campos, int64_t H, int64_t W, double tanx,
-                                double tany, double mod, bool aa, bool debug)
+                                double tany, double mod, bool aa, bool debug, int64_t sh_degree)
 {
     const bool will_backward = at::GradMode::is_enabled() &&
         (vertices.requires_grad() || _alpha.requires_grad() || _scale.requires_grad() || _opacity.requires_grad() || sh_dc.requires_grad() ||
          sh_rest.requires_grad() || means2D.requires_grad());
     return RenderMeshFn::apply(vertices, faces, _alpha, _scale, _opacity, sh_dc, sh_rest, means2D, mode, spf, splat_face, bg, view, proj, campos, H, W,
-                               tanx, tany, mod, aa, debug, vertices.requires_grad(), will_backward);
+                               tanx, tany, mod, aa, debug, vertices.requires_grad(), will_backward, sh_degree);
 }
 
 // ---------------------------------------------------------------------------------------------- fused L1 + SSIM

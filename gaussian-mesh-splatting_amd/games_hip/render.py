@@ -76,7 +76,7 @@ def _zero_points(xyz: torch.Tensor) -> torch.Tensor:
 def _fused_training_ok(pc, pipe, override_color) -> bool:
     """Can this DIFFERENTIATED frame be rendered straight from the mesh (games_hip.model.HipMeshMixin.hip_defer_k0)?  The model
     deferred its K0 (update_alpha() since the last optimizer step, nothing has asked for the derived values), uniform splats per
-    face, split degree-3 SH storage at full degree, the rasterizer's native SH / cov3D stages."""
+    face, split degree-3 SH STORAGE (any active degree), the rasterizer's native SH / cov3D stages."""
     import os
     import diff_gaussian_rasterization as dgr
     if not (hasattr(pc, "__dict__") and pc.__dict__.get("_hip_pending")) or not torch.is_grad_enabled():
@@ -90,7 +90,7 @@ def _fused_training_ok(pc, pipe, override_color) -> bool:
         return False
     P = int(a.shape[0] * a.shape[1])
     sc = getattr(pc, getattr(pc, "_hip_scale_attr", "_scale"), None)
-    return (int(pc.active_sh_degree) == 3 and torch.is_tensor(op) and op.numel() == P and torch.is_tensor(sc) and sc.numel() == P
+    return (0 <= int(pc.active_sh_degree) <= 3 and torch.is_tensor(op) and op.numel() == P and torch.is_tensor(sc) and sc.numel() == P
             and dc.is_contiguous() and fr.is_contiguous() and dc.shape[0] == P and torch.is_tensor(getattr(pc, "faces", None)))
 
 
@@ -116,7 +116,7 @@ def _render_training_frame_from_mesh(viewpoint_camera, pc, pipe, bg_color, scali
         ALPHA_MODES[getattr(pc, "alpha_mode", "relu")], int(_alpha.shape[1]), dgr._empty(_alpha.device), bg_color,
         viewpoint_camera.world_view_transform, viewpoint_camera.full_proj_transform, viewpoint_camera.camera_center, H, W,
         math.tan(viewpoint_camera.FoVx * 0.5), math.tan(viewpoint_camera.FoVy * 0.5), float(scaling_modifier), bool(pipe.antialiasing),
-        bool(pipe.debug))
+        bool(pipe.debug), int(pc.active_sh_degree))          # (the ACTIVE degree: train.py:86-87 raises it every 1 000 iterations)
     pc._hip_fused_frame(xyz, scaling_act, rotation_unit, opacity_act)
     # (`visibility_filter` = radii > 0 comes out of the preprocess kernel, as on the two-node route: no elementwise launch)
     return {"render": image, "viewspace_points": screenspace_points, "visibility_filter": visible, "radii": radii, "depth": invdepth}

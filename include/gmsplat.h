@@ -128,7 +128,7 @@ typedef struct GmsRasterForwardArgs {
      * differentiated.  When non-NULL the preprocess thread derives its Gaussian from the mesh (barycentric centre, face frame ->
      * activated scale and unit quaternion, sigmoid opacity: the arithmetic of gms_mesh_to_gaussians_forward with fused_activations,
      * bit for bit) and `means3D`, `opacities`, `scales`, `rotations` are ignored (may be NULL): the K0 launch and the 84 bytes per
-     * Gaussian it writes disappear.  Needs mesh->P == P, mesh->_opacity, split degree-3 SH storage (shs + shs_rest, M = 16, D = 3)
+     * Gaussian it writes disappear.  Needs mesh->P == P, mesh->_opacity, split degree-3 SH STORAGE (shs + shs_rest, M = 16; the ACTIVE degree D is 0 .. 3)
      * and no precomputed colours / covariances.  `mesh->prezero` / `prezero_count` are honoured as in gms_mesh_to_gaussians_forward (the
      * [V,3] buffer the mesh backward will accumulate into is cleared by this launch). */
     const struct GmsMeshArgs *mesh;

@@ -85,13 +85,42 @@ def test_deferred_values_are_materialised_for_every_reader_and_served_from_the_f
     assert torch.equal(xyz.detach(), xyz_frame) and torch.equal(model._xyz.detach(), xyz_frame)
     assert torch.equal(model.get_scaling.detach(), sc_frame) and torch.equal(model.get_rotation.detach(), rot_frame)
     assert torch.equal(model.get_opacity.detach(), op_frame)
-    # the SH ramp of training (active_sh_degree < 3) and the python-stage flags take the two-node route
+    # the python-stage flags take the two-node route (the SH ramp of training does not: test_fused_training_frame_during_the_sh_ramp)
     model.update_alpha(); model.prepare_scaling_rot()
-    model.active_sh_degree = 2
-    out2 = render(cam, model, PipelineParams(), bg)
+    pipe = PipelineParams(); pipe.convert_SHs_python = True
+    out2 = render(cam, model, pipe, bg)
     assert model.__dict__.get("_hip_pending") is None and out2["render"].requires_grad
-    model.active_sh_degree = 3
     model.hip_defer_k0 = False
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2])
+def test_fused_training_frame_during_the_sh_ramp(degree):
+    """train.py:86-87 raises the active SH degree every 1 000 iterations: below 3 the frame is still rendered straight from the mesh
+    (`preprocess_fwd_dma_kernel<true, degree>`: the stored rows come in whole, the active bands are evaluated) and the backward leaves
+    the inactive bands' gradients zero, exactly as the two-node graph does -- bit for bit in deterministic mode."""
+    import diff_gaussian_rasterization as dgr
+    model = _model()
+    cam = syn.orbit_camera(1, width=160, height=128).to("cuda")
+    bg = torch.tensor([0.1, 0.5, 0.8], device="cuda")
+    was = dgr.deterministic()
+    dgr.set_deterministic(True)
+    try:
+        model.active_sh_degree = degree
+        _step(model, cam, bg, False)
+        img0, radii0, g0 = _step(model, cam, bg, False)
+        img1, radii1, g1 = _step(model, cam, bg, True)
+        assert model.__dict__.get("_hip_pending") is True               # the frame took the fused route
+    finally:
+        dgr.set_deterministic(was)
+        model.active_sh_degree = 3
+        model.hip_defer_k0 = False
+    assert torch.equal(img1, img0) and torch.equal(radii1, radii0)
+    for k in g0:
+        assert torch.equal(g1[k], g0[k]), k
+    nb = (degree + 1) ** 2 - 1
+    assert float(g1["_features_rest"][:, nb:].abs().max()) == 0.0          # bands above the active degree: untouched
+    if nb:
+        assert float(g1["_features_rest"][:, :nb].abs().max()) > 0.0
 
 
 def test_training_loop_walks_the_same_trajectory_with_and_without_the_deferred_k0(monkeypatch):
